@@ -1,0 +1,262 @@
+#!/usr/bin/env python3
+"""Generate the committed golden vectors by RUNNING THE REFERENCE (build container only).
+
+Imports the reference's own modules from /root/reference/src (read-only; the five viz/IO packages
+it imports at module scope but never touches on this path are replaced by MagicMock), drives them
+exactly as train.py:123-184 does (functorch combine_state_for_ensemble + vmap, step_batch_loss,
+backward, AdamW), asserts that oracle/ref_cpu.py reproduces every tensor, and writes
+tests/golden/<case>.npz.  Only arrays are written -- no reference source or bytecode.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_golden.py
+
+The GPU box has no /root/reference; tests read only the .npz files.
+"""
+import math
+import os
+import sys
+from types import SimpleNamespace
+from unittest.mock import MagicMock
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference/src")
+sys.dont_write_bytecode = True
+for _m in ["skimage", "skimage.measure", "cv2", "imgviz", "open3d", "trimesh", "plotly",
+           "plotly.graph_objs", "plotly.subplots"]:
+    sys.modules[_m] = MagicMock()
+
+import loss as ref_loss  # noqa: E402
+import render_rays as ref_rr  # noqa: E402
+import scene_cateogries as ref_sc  # noqa: E402
+import trainer as ref_trainer  # noqa: E402
+from functorch import combine_state_for_ensemble, vmap  # noqa: E402
+
+from oracle import ref_cpu as O  # noqa: E402
+
+N1_N2 = {16: (2, 14), 32: (4, 28), 10: (1, 9)}
+
+
+def rand_pose(gen, sim3):
+    q = torch.randn(4, generator=gen)
+    q = q / q.norm()
+    w, x, y, z = q.tolist()
+    Rm = torch.tensor([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                       [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                       [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    T = torch.eye(4)
+    s = (0.3 + 0.7 * torch.rand(1, generator=gen)).item() if sim3 else 1.0
+    T[:3, :3] = Rm * s
+    T[:3, 3] = torch.rand(3, generator=gen) * 2 - 1
+    return T
+
+
+def make_pool(gen, R, n_obj, all_invalid=False, labels_all=None):
+    """Synthetic pool slice per SURVEY §8(d)."""
+    u = torch.randint(0, 1200, (R,), generator=gen).float()
+    v = torch.randint(0, 680, (R,), generator=gen).float()
+    dirs = torch.stack([(u - 599.5) / 600.0, (v - 339.5) / 600.0, torch.ones(R)], -1)
+    T = torch.empty(R, 4, 4)
+    for g0 in range(0, R, 16):
+        T_wc = rand_pose(gen, False)
+        T_wo = rand_pose(gen, True)
+        T[g0:g0 + 16] = torch.linalg.inv(T_wc) @ T_wo
+    depth = 0.5 + 3.0 * torch.rand(R, generator=gen)
+    depth[torch.rand(R, generator=gen) < 0.05] = 0.0
+    if all_invalid:
+        depth[: R // 2] = 0.0
+    pr = torch.rand(R, generator=gen)
+    state = torch.where(pr < 0.70, 1, torch.where(pr < 0.95, 0, 2)).to(torch.uint8)
+    if labels_all is not None:
+        state[:] = labels_all
+    rgb = torch.randint(0, 256, (R, 3), generator=gen, dtype=torch.uint8)
+    rgbs = torch.cat([rgb, state[:, None]], -1)
+    idx = torch.randint(0, n_obj, (R,), generator=gen)
+    return rgbs, depth, dirs, T, idx
+
+
+def run_case(name, seed, C, R, S, L, n_obj=4, single_obj=False, empty_mask_cls=None,
+             all_invalid=False, keep_emb=True):
+    torch.manual_seed(seed)
+    gen = torch.Generator().manual_seed(1000 + seed)
+    n1, n2 = N1_N2[S]
+    eps, stop_eps = 0.1, 0.05
+    scale = 2.0 if L == 256 else 3.0
+    if single_obj:
+        n_obj = 1
+    cfg = SimpleNamespace(training_device="cpu", obj_scale=scale, n_unidir_funcs=5,
+                          net_hyperparams=dict(shape_blocks=2, texture_blocks=1, W=32, latent_dim=L),
+                          hidden_feature_size=32)
+    trainers = [ref_trainer.Trainer(cfg, cls_id=c + 1, inst_ids=list(range(n_obj))) for c in range(C)]
+    # perturb B so its gradient/updates are exercised away from the symmetric init
+    for t in trainers:
+        with torch.no_grad():
+            t.pe.B_layer.weight.add_(0.01 * torch.randn(21, 3, generator=gen))
+
+    opt = torch.optim.AdamW([torch.autograd.Variable(torch.tensor(0))], lr=1e-3, weight_decay=0.013)
+    for t in trainers:
+        opt.add_param_group({"params": t.shape_codes.parameters(), "lr": 1e-3, "weight_decay": 0.013})
+        opt.add_param_group({"params": t.texture_codes.parameters(), "lr": 1e-3, "weight_decay": 0.013})
+    fc_model, fc_param, fc_buffer = combine_state_for_ensemble([t.fc_occ_map for t in trainers])
+    [p.requires_grad_() for p in fc_param]
+    opt.add_param_group({"params": fc_param})
+    pe_model, pe_param, pe_buffer = combine_state_for_ensemble([t.pe for t in trainers])
+    [p.requires_grad_() for p in pe_param]
+    opt.add_param_group({"params": pe_param})
+
+    names = [n for n, _ in trainers[0].fc_occ_map.named_parameters()]
+    mlp0 = {n: p.detach().clone() for n, p in zip(names, fc_param)}
+    B0 = pe_param[0].detach().clone()
+    shape0 = torch.stack([t.shape_codes.weight.detach().clone() for t in trainers])
+    tex0 = torch.stack([t.texture_codes.weight.detach().clone() for t in trainers])
+
+    # ---- sampling via the reference, recording the draws per ray -------------------------------
+    pool = [make_pool(gen, R, n_obj, all_invalid=all_invalid and c == 0,
+                      labels_all=(0 if empty_mask_cls == c else None)) for c in range(C)]
+    ns = SimpleNamespace(n_bins_cam2surface=n1, n_bins=n2, surface_eps=eps, stop_eps=stop_eps,
+                         data_device="cpu", min_bound=0.0, this_obj=1)
+    outs, us, gs, origins_l, dirs_l = [], [], [], [], []
+    for c in range(C):
+        rgbs, depth, dirs, T, idx = pool[c]
+        fn = ref_sc.origin_dirs_W if single_obj else ref_sc.origin_dirs_O
+        origins, dirs_o = fn(T, dirs)
+        o2, d2 = (O.origin_dirs_W if single_obj else O.origin_dirs_O)(T, dirs)
+        assert torch.equal(origins, o2) and torch.equal(dirs_o, d2)
+        state = torch.get_rng_state()
+        ref_out = ref_sc.sceneCategory.sample_3d_points(ns, rgbs, depth, origins, dirs_o)
+        # replay the draws in the reference's order (scene_cateogries.py:489-539) into per-ray rows
+        torch.set_rng_state(state)
+        u = torch.zeros(R, S)
+        g = torch.zeros(R, n2)
+        invalid = depth <= 0.0
+        valid = ~invalid
+        if invalid.any():
+            u[invalid] = torch.rand(int(invalid.sum()), S)
+        if valid.any():
+            u[valid, :n1] = torch.rand(int(valid.sum()), n1)
+            obj = (rgbs[:, 3] == 1) & valid
+            if obj.any():
+                g[obj] = torch.empty(int(obj.sum()), n2).normal_(mean=0.0, std=eps / 3.0)
+            oth = (rgbs[:, 3] != 1) & valid
+            if oth.any():
+                u[oth, n1:] = torch.rand(int(oth.sum()), n2)
+        mine = O.sample_3d_points(rgbs, depth, origins, dirs_o, u, g, n1, n2, eps, stop_eps)
+        for a, b in zip(ref_out, mine):
+            assert torch.equal(a, b), "oracle sampling != reference"
+        outs.append(ref_out)
+        us.append(u)
+        gs.append(g)
+        origins_l.append(origins)
+        dirs_l.append(dirs_o)
+
+    gt_rgb = torch.stack([o[0] for o in outs]) / 255.0
+    gt_depth = torch.stack([o[1] for o in outs])
+    depth_mask = torch.stack([o[2] for o in outs])
+    labels = torch.stack([o[3] for o in outs])
+    pts = torch.stack([o[4] for o in outs])
+    z = torch.stack([o[5] for o in outs])
+    indices = torch.stack([p[4] for p in pool])
+
+    # ---- reference train step (train.py:136-184) -----------------------------------------------
+    cs = torch.stack([trainers[c].shape_codes(indices[c])[:, None, :] for c in range(C)])
+    ct = torch.stack([trainers[c].texture_codes(indices[c])[:, None, :] for c in range(C)])
+    emb = vmap(pe_model)(pe_param, pe_buffer, pts)
+    alpha, color = vmap(fc_model)(fc_param, fc_buffer, emb, cs, ct)
+    loss, ld, lcol = ref_loss.step_batch_loss(alpha, color, gt_depth, gt_rgb, labels, depth_mask, z)
+    cls_dict = {c: SimpleNamespace(trainer=trainers[c], training_device="cpu",
+                                   obj_ids=list(range(n_obj))) for c in range(C)}
+    rs, rt = ref_loss.step_batch_loss_reg(cls_dict, torch.arange(C))
+    loss = loss + 0.0005 * (rs + rt).sum()
+    loss.backward()
+
+    occ = ref_rr.occupancy_activation(alpha.squeeze(-1))
+    term = ref_rr.occupancy_to_termination(occ, is_batch=True)
+    depth_r = ref_rr.render(term, z)
+    var_r = ref_rr.render(term, (z - depth_r[..., None]) ** 2)
+    rgb_r = ref_rr.render(term[..., None], color, dim=-2)
+    opa_r = term.sum(-1)
+
+    zero = lambda p: torch.zeros_like(p) if p.grad is None else p.grad.detach().clone()
+    grads = {n: zero(p) for n, p in zip(names, fc_param)}
+    gB = zero(pe_param[0])
+    gshape = torch.stack([zero(t.shape_codes.weight) for t in trainers])
+    gtex = torch.stack([zero(t.texture_codes.weight) for t in trainers])
+    opt.step()
+
+    # ---- oracle must reproduce everything ------------------------------------------------------
+    mlp_o = {n: v.clone().requires_grad_() for n, v in mlp0.items()}
+    B_o = B0.clone().requires_grad_()
+    sh_o = [shape0[c].clone().requires_grad_() for c in range(C)]
+    tx_o = [tex0[c].clone().requires_grad_() for c in range(C)]
+    batch = dict(pts=pts, z=z, gt_depth=gt_depth, gt_rgb=gt_rgb, labels=labels,
+                 depth_mask=depth_mask, indices=indices)
+    loss_o, aux = O.forward_loss(mlp_o, B_o, scale, sh_o, tx_o, batch)
+    loss_o.backward()
+
+    def close(a, b, what, tol=2e-6):
+        a, b = a.detach().double(), b.detach().double()
+        err = (a - b).norm() / max(b.norm().item(), 1e-30) if b.norm() > 0 else (a - b).abs().max()
+        assert err <= tol, f"{name}: oracle {what} off by {err:.3e}"
+
+    close(aux["emb"], emb, "emb")
+    close(aux["sigmas"], alpha, "sigmas")
+    close(aux["rgbs"], color, "rgbs")
+    close(aux["term"], term, "term")
+    close(aux["depth"], depth_r, "depth")
+    close(aux["var"], var_r, "var")
+    close(aux["rgb"], rgb_r, "rgb")
+    close(aux["opacity"], opa_r, "opacity")
+    close(loss_o, loss, "loss")
+    for k in ("depth", "color", "opacity"):
+        close(aux["loss_" + k], ld[k], "loss_" + k)
+    for n in names:
+        close(zero(mlp_o[n]), grads[n], "grad " + n, 2e-5)
+    close(zero(B_o), gB, "grad B", 2e-5)
+    close(torch.stack([zero(s) for s in sh_o]), gshape, "grad shape", 2e-5)
+    close(torch.stack([zero(s) for s in tx_o]), gtex, "grad tex", 2e-5)
+
+    # ---- write fixture -------------------------------------------------------------------------
+    f = lambda t: t.detach().cpu().numpy()
+    d = dict(meta=np.array([C, R, S, L, n_obj, n1, n2, int(single_obj)], dtype=np.int64),
+             scale=np.float32(scale), eps=np.float32(eps), stop_eps=np.float32(stop_eps),
+             pool_rgbs=f(torch.stack([p[0] for p in pool])), pool_depth=f(torch.stack([p[1] for p in pool])),
+             pool_dirs=f(torch.stack([p[2] for p in pool])), pool_T=f(torch.stack([p[3] for p in pool])),
+             indices=f(indices), u=f(torch.stack(us)), g=f(torch.stack(gs)),
+             origins=f(torch.stack(origins_l)), dirs_o=f(torch.stack(dirs_l)),
+             z=f(z), pts=f(pts), gt_rgb=f(gt_rgb), gt_depth=f(gt_depth), depth_mask=f(depth_mask),
+             labels=f(labels), B=f(B0), shape_codes=f(shape0), texture_codes=f(tex0),
+             sigmas=f(alpha), rgbs=f(color), occ=f(occ), term=f(term), depth=f(depth_r), var=f(var_r),
+             rgb=f(rgb_r), opacity=f(opa_r), loss=f(loss), loss_depth=f(ld["depth"]),
+             loss_color=f(ld["color"]), loss_opacity=f(ld["opacity"]), reg_shape=f(rs),
+             reg_texture=f(rt), grad_B=f(gB), grad_shape_codes=f(gshape), grad_texture_codes=f(gtex),
+             new_B=f(pe_param[0]),
+             new_shape_codes=f(torch.stack([t.shape_codes.weight for t in trainers])),
+             new_texture_codes=f(torch.stack([t.texture_codes.weight for t in trainers])))
+    if keep_emb:
+        d["emb"] = f(emb)
+    for n, p in zip(names, fc_param):
+        d["mlp." + n] = f(mlp0[n])
+        d["grad." + n] = f(grads[n])
+        d["new." + n] = f(p)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **d)
+    print(f"{name}: loss={loss.item():.6f}  -> {os.path.getsize(path) / 1e6:.2f} MB")
+
+
+def main():
+    run_case("s0_c1_r64_s16_l256", 0, 1, 64, 16, 256)
+    run_case("s1_c1_r64_s16_l256", 1, 1, 64, 16, 256, keep_emb=False)
+    run_case("s2_c1_r64_s16_l256", 2, 1, 64, 16, 256, keep_emb=False)
+    run_case("s0_c2_r64_s16_l32", 0, 2, 64, 16, 32)
+    run_case("s0_c1_r512_s32_l256", 0, 1, 512, 32, 256, keep_emb=False)
+    run_case("s0_c1_r120_s10_l256", 0, 1, 120, 10, 256, keep_emb=False)  # the real config shape
+    run_case("edge_empty_mask", 3, 2, 64, 16, 32, empty_mask_cls=1, keep_emb=False)
+    run_case("edge_invalid_depth", 4, 1, 64, 16, 256, all_invalid=True, keep_emb=False)
+    run_case("edge_single_obj_W", 5, 1, 64, 16, 256, single_obj=True, keep_emb=False)
+
+
+if __name__ == "__main__":
+    main()
