@@ -1,0 +1,111 @@
+"""ctypes binding of libcnr_hip.so (the C-ABI declared in include/cnr_hip.h).
+
+There is NO CPU fallback: if the library is missing, or a tensor is not a contiguous device tensor of
+the documented dtype, the call raises.  (tests/ may install a test double for host-logic tests on a
+GPU-less box through :func:`install_test_double`; nothing in the product ever does.)
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcnr_hip.so")
+
+_vp, _i, _i64, _u64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_uint64, ctypes.c_float
+
+# name -> argtypes ; every function returns int.  Mirrors include/cnr_hip.h one to one.
+SIGNATURES = {
+    "cnr_version": [],
+    "cnr_device_info": [_vp, _vp, _vp],
+    "cnr_sample_maxdepth": [_vp, _vp, _i, _i, _vp],
+    "cnr_sample_rays": [_vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64, _vp, _i, _i, _i, _i, _i, _f, _f, _f,
+                        _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "cnr_pe_fwd": [_vp, _vp, _vp, _i, _i64, _f, _vp],
+    "cnr_pe_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i64, _f, _vp],
+    "cnr_mlp_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "cnr_mlp_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "cnr_composite_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
+    "cnr_composite_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
+    "cnr_loss_fwd_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp,
+                         _i, _i, _vp],
+    "cnr_adamw_step": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i64, _f, _vp],
+}
+
+_lib = None
+_double = None
+
+
+class CnrError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libcnr_hip.so; raise loudly when it is absent (build with __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CnrError(f"{LIB_PATH} not found: the HIP extension is not built "
+                           "(run `python -c 'import __graft_entry__ as g; g.build()'`); there is no CPU path")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_int
+        _lib = lib
+    return _lib
+
+
+def install_test_double(obj):
+    """tests/ only: route calls to `obj.<name>(*tensors_and_scalars)` instead of the HIP library."""
+    global _double
+    _double = obj
+
+
+def _ptr(t, dtype=None, allow_none=False):
+    if t is None:
+        if allow_none:
+            return None
+        raise CnrError("required tensor is None")
+    if not t.is_cuda:
+        raise CnrError("cnr kernels take device tensors only (got a CPU tensor); there is no CPU path")
+    if not t.is_contiguous():
+        raise CnrError("cnr kernels take contiguous tensors")
+    if dtype is not None and t.dtype != dtype:
+        raise CnrError(f"expected dtype {dtype}, got {t.dtype}")
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    """args: torch tensors (passed as device pointers), None (NULL) or python scalars."""
+    if _double is not None:
+        rc = getattr(_double, name)(*args)
+        if rc:
+            raise CnrError(f"{name} (test double) returned {rc}")
+        return
+    lib = load()
+    conv = []
+    for a in args:
+        if torch.is_tensor(a):
+            conv.append(_ptr(a))
+        else:
+            conv.append(a)
+    rc = getattr(lib, name)(*conv, _stream())
+    if rc != 0:
+        raise CnrError(f"{name} failed with code {rc}" + (" (argument error)" if rc < 0 else " (hipError_t)"))
+
+
+def version():
+    return load().cnr_version()
+
+
+def device_info():
+    n_cu, lds, is950 = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    rc = load().cnr_device_info(ctypes.byref(n_cu), ctypes.byref(lds), ctypes.byref(is950))
+    if rc != 0:
+        raise CnrError(f"cnr_device_info failed with {rc}")
+    return {"n_cu": n_cu.value, "lds_bytes": lds.value, "gfx950": bool(is950.value)}

@@ -1,0 +1,127 @@
+// a14-a15: masks, L1 residuals, masked means and their gradient w.r.t. the rendered values in ONE
+// launch and with no host synchronisation (src/loss.py:18-74, src/render_rays.py:52-95).  The
+// reference syncs the host six times per step here ((mask_num == 0).any() and (loss > 1e5).any() in each
+// of three reduce_batch_loss calls); this kernel keeps both checks on the device:
+//   - "any class has an empty mask -> that loss term is zero, with no gradient, for ALL classes"
+//     (render_rays.py:67-72) is evaluated by every block from the labels of all classes;
+//   - "loss explode" (render_rays.py:87-89, exit(-1) there) is reported in flags[c] bit 0.
+// One 256-thread block per class.
+#include "cnr_common.h"
+
+namespace {
+__device__ __forceinline__ float block_sum(float v, float* sm /*[4]*/) {
+  v = cnr::wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sm[0] + sm[1] + sm[2] + sm[3];
+}
+__device__ __forceinline__ float sgn(float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
+
+__global__ __launch_bounds__(256) void loss_kernel(
+    const float* __restrict__ depth, const float* __restrict__ var, const float* __restrict__ rgb,
+    const float* __restrict__ opacity, const float* __restrict__ gt_depth, const float* __restrict__ gt_rgb,
+    const uint8_t* __restrict__ labels, const uint8_t* __restrict__ depth_mask, float color_scaling,
+    float opacity_scaling, float grad_scale, float* __restrict__ losses, int32_t* __restrict__ flags,
+    float* __restrict__ d_depth, float* __restrict__ d_rgb, float* __restrict__ d_opacity, int C, int R) {
+  __shared__ float sm[4];
+  const int c = blockIdx.x;
+  // ---- mask counts of every class (cheap: 2 bytes per ray) -----------------------------------
+  bool empty_d = false, empty_c = false, empty_o = false;
+  float nd = 0.f, nc = 0.f, no = 0.f;
+  for (int cc = 0; cc < C; ++cc) {
+    float a = 0.f, b = 0.f, d = 0.f;
+    for (int r = threadIdx.x; r < R; r += 256) {
+      const uint8_t lab = labels[(size_t)cc * R + r];
+      const bool mo = lab != 0, ms = lab != 2, md = depth_mask[(size_t)cc * R + r] != 0;
+      a += (md && mo) ? 1.f : 0.f; b += mo ? 1.f : 0.f; d += ms ? 1.f : 0.f;
+    }
+    a = block_sum(a, sm); b = block_sum(b, sm); d = block_sum(d, sm);
+    empty_d |= (a == 0.f); empty_c |= (b == 0.f); empty_o |= (d == 0.f);
+    if (cc == c) { nd = a; nc = b; no = d; }
+  }
+  const float wd = empty_d ? 0.f : 1.0f / (nd + 1e-10f);
+  const float wc = empty_c ? 0.f : 1.0f / (nc + 1e-10f);
+  const float wo = empty_o ? 0.f : 1.0f / (no + 1e-10f);
+  // ---- per-ray residuals, gradients ------------------------------------------------------------
+  float ld = 0.f, lc = 0.f, lo = 0.f;
+  for (int r = threadIdx.x; r < R; r += 256) {
+    const size_t i = (size_t)c * R + r;
+    const uint8_t lab = labels[i];
+    const bool mo = lab != 0, ms = lab != 2, md = (depth_mask[i] != 0) && mo;
+    const float rd = depth[i] - gt_depth[i];
+    const float info = 1.0f / (sqrtf(var[i]) + 1e-4f);
+    const float fd = md ? 1.f : 0.f, fo = mo ? 1.f : 0.f, fs = ms ? 1.f : 0.f;
+    ld += fabsf(rd) * fd * info;
+    d_depth[i] = grad_scale * sgn(rd) * fd * info * wd;
+    float cs = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float rc = rgb[i * 3 + k] - gt_rgb[i * 3 + k];
+      cs += fabsf(rc);
+      d_rgb[i * 3 + k] = grad_scale * color_scaling * sgn(rc) * fo * wc;
+    }
+    lc += cs * fo;
+    const float ro = opacity[i] - fo;
+    lo += fabsf(ro) * fs;
+    d_opacity[i] = grad_scale * opacity_scaling * sgn(ro) * fs * wo;
+  }
+  ld = block_sum(ld, sm) * wd; lc = block_sum(lc, sm) * wc; lo = block_sum(lo, sm) * wo;
+  if (threadIdx.x == 0) {
+    losses[0 * C + c] = ld; losses[1 * C + c] = lc; losses[2 * C + c] = lo;
+    int32_t fl = 0;
+    if (ld > 100000.f || lc > 100000.f || lo > 100000.f) fl |= 1;
+    if (empty_d) fl |= 2;
+    if (empty_c) fl |= 4;
+    if (empty_o) fl |= 8;
+    flags[c] = fl;
+  }
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                    float lr, float b1, float b2, float eps, float wd,
+                                                    float step_size, float inv_bc2_sqrt, float gunscale) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i] * gunscale;
+    float pi = p[i] * (1.0f - lr * wd);
+    const float mi = m[i] + (gi - m[i]) * (1.0f - b1);
+    const float vi = v[i] * b2 + (1.0f - b2) * gi * gi;
+    const float denom = sqrtf(vi) * inv_bc2_sqrt + eps;
+    pi -= step_size * (mi / denom);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+  }
+}
+}  // namespace
+
+extern "C" int cnr_loss_fwd_bwd(const float* depth, const float* var, const float* rgb, const float* opacity,
+                                const float* gt_depth, const float* gt_rgb, const uint8_t* labels,
+                                const uint8_t* depth_mask, float color_scaling, float opacity_scaling,
+                                float grad_scale, float* losses, int32_t* flags, float* d_depth, float* d_rgb,
+                                float* d_opacity, int C, int R, void* stream) {
+  if (!depth || !var || !rgb || !opacity || !gt_depth || !gt_rgb || !labels || !depth_mask || !losses ||
+      !flags || !d_depth || !d_rgb || !d_opacity || C <= 0 || R <= 0)
+    return CNR_E_ARG;
+  hipLaunchKernelGGL(loss_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, depth, var, rgb, opacity,
+                     gt_depth, gt_rgb, labels, depth_mask, color_scaling, opacity_scaling, grad_scale, losses,
+                     flags, d_depth, d_rgb, d_opacity, C, R);
+  CNR_LAUNCH_CHECK();
+  return CNR_OK;
+}
+
+extern "C" int cnr_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                              float lr, float beta1, float beta2, float eps, float weight_decay,
+                              int64_t step_count, float grad_unscale, void* stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || step_count <= 0) return CNR_E_ARG;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step_count);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step_count);
+  const float step_size = (float)((double)lr / bc1);
+  const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad,
+                     exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step_size, inv_bc2_sqrt,
+                     grad_unscale);
+  CNR_LAUNCH_CHECK();
+  return CNR_OK;
+}

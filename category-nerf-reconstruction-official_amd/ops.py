@@ -1,0 +1,260 @@
+"""torch.autograd.Function wrappers over the C-ABI kernels (modular, exact-fp32 tier).
+
+Every Function works on plain tensors or on class-batched tensors (leading C dim, decided by the
+parameter rank) and carries a ``vmap`` rule, so the reference's own
+``functorch.combine_state_for_ensemble`` + ``vmap(fmodel)(params, buffers, *stacked_inputs)``
+(src/utils.py:24-28, train.py:154-155) dispatches straight into the class-batched kernels.
+"""
+import torch
+from torch.autograd import Function
+
+from . import _C
+
+E1, E2, E, W, NLAT = 87, 42, 129, 32, 4
+TRUNK_LAYERS = [  # (state_dict prefix, out, in) in blob order (include/cnr_hip.h: CNR_TRUNK_PARAMS)
+    ("encoding_xyz.0", 32, 87), ("shape_layer_1.0", 32, 32), ("shape_layer_2.0", 32, 32),
+    ("cat_layer.0", 32, 119), ("encoding_shape", 32, 32), ("sigma.0", 1, 32),
+    ("encoding_viewdir.0", 32, 74), ("texture_layer_1.0", 32, 32), ("rgb.0", 16, 32), ("rgb.2", 3, 16),
+]
+TRUNK_PARAMS = sum(o * i + o for _, o, i in TRUNK_LAYERS)
+assert TRUNK_PARAMS == 13892
+LATENT_LAYERS = ["shape_latent_layer_1.0", "cat_latent_layer.0", "shape_latent_layer_2.0",
+                 "texture_latent_layer_1.0"]  # zlat slot order
+
+
+def _to_batch0(args, in_dims, batch_size):
+    out = []
+    for a, d in zip(args, in_dims):
+        if not torch.is_tensor(a):
+            out.append(a)
+        elif d is None:
+            out.append(a.unsqueeze(0).expand(batch_size, *a.shape))
+        else:
+            out.append(a.movedim(d, 0))
+    return out
+
+
+def pack_trunk(params, C):
+    """20 tensors (w, b per TRUNK_LAYERS entry; optional leading C) -> (C, 13892) fp32 blob."""
+    return torch.cat([p.reshape(C, -1) for p in params], dim=1).contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+# a8  UniDirsEmbed
+# ------------------------------------------------------------------------------------------------
+class UniDirsEmbedFn(Function):
+    """x (..., 3), B (21, 3)  or class-batched x (C, ..., 3), B (C, 21, 3) -> (..., 129)."""
+
+    @staticmethod
+    def forward(x, B, scale):
+        C = B.shape[0] if B.dim() == 3 else 1
+        xs = x.contiguous().float()
+        N = xs.numel() // (3 * C)
+        e = torch.empty(*x.shape[:-1], E, device=x.device, dtype=torch.float32)
+        _C.call("cnr_pe_fwd", xs, B.contiguous(), e, C, N, float(scale))
+        return e
+
+    @staticmethod
+    def setup_context(ctx, inputs, output):
+        x, B, scale = inputs
+        ctx.save_for_backward(x, B)
+        ctx.scale = float(scale)
+
+    @staticmethod
+    def backward(ctx, de):
+        x, B = ctx.saved_tensors
+        C = B.shape[0] if B.dim() == 3 else 1
+        xs = x.contiguous().float()
+        N = xs.numel() // (3 * C)
+        dB = torch.zeros_like(B, memory_format=torch.contiguous_format)
+        dx = torch.empty_like(xs) if ctx.needs_input_grad[0] else None
+        _C.call("cnr_pe_bwd", xs, B.contiguous(), de.contiguous(), dB, dx, C, N, ctx.scale)
+        return dx, dB, None
+
+    @staticmethod
+    def vmap(info, in_dims, x, B, scale):
+        x, B, scale = _to_batch0((x, B, scale), in_dims, info.batch_size)
+        return UniDirsEmbedFn.apply(x, B, scale), 0
+
+
+# ------------------------------------------------------------------------------------------------
+# a9  CodeNeRF trunk (the ten per-sample Linear layers), exact fp32
+# ------------------------------------------------------------------------------------------------
+class CodeNeRFTrunkFn(Function):
+    """e (R,S,129), zlat (R,4,32), 20 trunk tensors -> sigmas (R,S,1), rgbs (R,S,3); or all with a
+    leading class dim C."""
+
+    @staticmethod
+    def forward(e, zlat, *params):
+        batched = params[0].dim() == 3
+        C = params[0].shape[0] if batched else 1
+        S = e.shape[-2]
+        R = e.numel() // (C * S * E)
+        trunk = pack_trunk(params, C)
+        ec, zc = e.contiguous(), zlat.contiguous()
+        sig = torch.empty(*e.shape[:-1], 1, device=e.device, dtype=torch.float32)
+        rgb = torch.empty(*e.shape[:-1], 3, device=e.device, dtype=torch.float32)
+        _C.call("cnr_mlp_fwd_f32", ec, zc, trunk, sig, rgb, C, R, S)
+        return sig, rgb
+
+    @staticmethod
+    def setup_context(ctx, inputs, output):
+        e, zlat = inputs[0], inputs[1]
+        params = inputs[2:]
+        C = params[0].shape[0] if params[0].dim() == 3 else 1
+        ctx.save_for_backward(e, zlat, *params)
+        ctx.C = C
+
+    @staticmethod
+    def backward(ctx, dsig, drgb):
+        e, zlat, *params = ctx.saved_tensors
+        C = ctx.C
+        S = e.shape[-2]
+        R = e.numel() // (C * S * E)
+        trunk = pack_trunk(params, C)
+        ec, zc = e.contiguous(), zlat.contiguous()
+        de = torch.empty_like(ec)
+        dz = torch.zeros_like(zc)
+        dtrunk = torch.zeros_like(trunk)
+        _C.call("cnr_mlp_bwd_f32", ec, zc, trunk, dsig.contiguous(), drgb.contiguous(), de, dz, dtrunk, C, R, S)
+        grads, off = [], 0
+        for p in params:
+            cnt = p.numel() // C
+            grads.append(dtrunk[:, off:off + cnt].reshape(p.shape))
+            off += cnt
+        return (de, dz, *grads)
+
+    @staticmethod
+    def vmap(info, in_dims, *args):
+        args = _to_batch0(args, in_dims, info.batch_size)
+        return CodeNeRFTrunkFn.apply(*args), (0, 0)
+
+
+# ------------------------------------------------------------------------------------------------
+# a11-a13  composite
+# ------------------------------------------------------------------------------------------------
+class CompositeFn(Function):
+    """alpha (..., S), color (..., S, 3), z (..., S) -> term (..., S), depth, var, opacity (...), rgb (..., 3).
+    var is non-differentiable (src/loss.py:46 detaches it)."""
+
+    @staticmethod
+    def forward(alpha, color, z):
+        S = alpha.shape[-1]
+        NR = alpha.numel() // S
+        a, c, zz = alpha.contiguous(), color.contiguous(), z.contiguous()
+        lead = alpha.shape[:-1]
+        kw = dict(device=alpha.device, dtype=torch.float32)
+        term = torch.empty(*lead, S, **kw)
+        depth, var, opa = torch.empty(*lead, **kw), torch.empty(*lead, **kw), torch.empty(*lead, **kw)
+        rgb = torch.empty(*lead, 3, **kw)
+        _C.call("cnr_composite_fwd", a, c, zz, term, depth, var, rgb, opa, NR, S, 0)
+        return term, depth, var, rgb, opa
+
+    @staticmethod
+    def setup_context(ctx, inputs, output):
+        ctx.save_for_backward(*inputs)
+        ctx.mark_non_differentiable(output[2])
+
+    @staticmethod
+    def backward(ctx, d_term, d_depth, d_var, d_rgb, d_opa):
+        alpha, color, z = ctx.saved_tensors
+        S = alpha.shape[-1]
+        NR = alpha.numel() // S
+        a, c, zz = alpha.contiguous(), color.contiguous(), z.contiguous()
+        d_alpha, d_color = torch.empty_like(a), torch.empty_like(c)
+        cont = lambda t: None if t is None else t.contiguous()
+        _C.call("cnr_composite_bwd", a, c, zz, cont(d_depth), cont(d_rgb), cont(d_opa), cont(d_term),
+                d_alpha, d_color, NR, S, 0)
+        return d_alpha, d_color, None
+
+
+class TerminationFn(Function):
+    """occupancy (..., S) -> termination (..., S): occ_i * prod_{j<i}(1 - occ_j + 1e-10)
+    (src/render_rays.py:25-33), the stand-alone form trainer / registration code calls."""
+
+    @staticmethod
+    def forward(occ):
+        S = occ.shape[-1]
+        o = occ.contiguous().float()
+        term = torch.empty_like(o)
+        _C.call("cnr_composite_fwd", o, None, None, term, None, None, None, None, o.numel() // S, S, 1)
+        return term
+
+    @staticmethod
+    def setup_context(ctx, inputs, output):
+        ctx.save_for_backward(inputs[0])
+
+    @staticmethod
+    def backward(ctx, d_term):
+        (occ,) = ctx.saved_tensors
+        S = occ.shape[-1]
+        o = occ.contiguous().float()
+        d_occ = torch.empty_like(o)
+        _C.call("cnr_composite_bwd", o, None, None, None, None, None, d_term.contiguous(), d_occ, None,
+                o.numel() // S, S, 1)
+        return d_occ
+
+
+# ------------------------------------------------------------------------------------------------
+# a14-a15  masked L1 losses (one launch, no host sync)
+# ------------------------------------------------------------------------------------------------
+class RenderLossFn(Function):
+    """(C,R) renders + ground truth + u8 labels / depth mask -> losses (3, C) [depth, colour, opacity]
+    and flags (C,) int32 (include/cnr_hip.h).  Gradients flow to depth, rgb, opacity."""
+
+    @staticmethod
+    def forward(depth, var, rgb, opacity, gt_depth, gt_rgb, labels, depth_mask):
+        C, R = depth.shape
+        kw = dict(device=depth.device, dtype=torch.float32)
+        losses = torch.empty(3, C, **kw)
+        flags = torch.empty(C, device=depth.device, dtype=torch.int32)
+        dd, dr, do = torch.empty(C, R, **kw), torch.empty(C, R, 3, **kw), torch.empty(C, R, **kw)
+        _C.call("cnr_loss_fwd_bwd", depth.contiguous(), var.contiguous(), rgb.contiguous(),
+                opacity.contiguous(), gt_depth.contiguous().float(), gt_rgb.contiguous().float(),
+                labels.contiguous(), depth_mask.contiguous(), 1.0, 1.0, 1.0, losses, flags, dd, dr, do, C, R)
+        return losses, flags, dd, dr, do
+
+    @staticmethod
+    def setup_context(ctx, inputs, output):
+        losses, flags, dd, dr, do = output
+        ctx.save_for_backward(dd, dr, do)
+        ctx.mark_non_differentiable(flags, dd, dr, do)
+
+    @staticmethod
+    def backward(ctx, g, _gf, _g1, _g2, _g3):
+        dd, dr, do = ctx.saved_tensors
+        return dd * g[0][:, None], None, dr * g[1][:, None, None], do * g[2][:, None], None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# a2-a5  sampling (no gradient: poses are not optimised)
+# ------------------------------------------------------------------------------------------------
+def sample_rays(rgbs, depth, dirs_c, T, n1, n2, eps, stop_eps, min_bound=0.0, world_frame=False,
+                u=None, g=None, seed=0, offset=0, want_rays=False):
+    """Class-batched pool slice (C,R,...) -> dict(z, pts, gt_rgb, depth_mask, labels[, origins, dirs_o]).
+    u/g given -> parity mode (identical draws); else in-kernel Philox(seed, offset)."""
+    C, R = depth.shape
+    S = n1 + n2
+    dev = depth.device
+    kw = dict(device=dev, dtype=torch.float32)
+    mb = torch.empty(C, **kw)
+    _C.call("cnr_sample_maxdepth", depth.contiguous(), mb, C, R)
+    z, pts = torch.empty(C, R, S, **kw), torch.empty(C, R, S, 3, **kw)
+    gt = torch.empty(C, R, 3, **kw)
+    dm = torch.empty(C, R, device=dev, dtype=torch.uint8)
+    lab = torch.empty(C, R, device=dev, dtype=torch.uint8)
+    org = torch.empty(C, R, 3, **kw) if want_rays else None
+    dro = torch.empty(C, R, 3, **kw) if want_rays else None
+    cont = lambda t: None if t is None else t.contiguous()
+    _C.call("cnr_sample_rays", rgbs.contiguous(), depth.contiguous(), dirs_c.contiguous(), T.contiguous(),
+            cont(u), cont(g), int(seed), int(offset), mb, int(bool(world_frame)), C, R, n1, n2,
+            float(eps), float(stop_eps), float(min_bound), z, pts, org, dro, gt, dm, lab)
+    out = dict(z=z, pts=pts, gt_rgb=gt, depth_mask=dm, labels=lab, gt_depth=depth)
+    if want_rays:
+        out.update(origins=org, dirs_o=dro)
+    return out
+
+
+def adamw_step(param, grad, exp_avg, exp_avg_sq, lr, betas, eps, weight_decay, step, grad_unscale=1.0):
+    _C.call("cnr_adamw_step", param, grad, exp_avg, exp_avg_sq, param.numel(), float(lr), float(betas[0]),
+            float(betas[1]), float(eps), float(weight_decay), int(step), float(grad_unscale))

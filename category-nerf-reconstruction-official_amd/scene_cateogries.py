@@ -1,0 +1,190 @@
+"""Per-category ray pool + sample generator with the reference's surface
+(src/scene_cateogries.py: ``sceneCategory.get_training_samples``, ``sample_3d_points``, the free
+functions ``origin_dirs_O/W``, ``stratified_bins``, ``normal_bins_sampling``, ``cameraInfo``).
+
+Differences by design: the ray pool is DEVICE-resident (the reference slices CPU
+tensors and pays an H2D copy per step), and the whole of a2-a5 for a pool slice is one HIP launch
+(cnr_sample_rays) with no count_nonzero host syncs.  Building the pool from dataset frames
+(:107-350) is out of scope; :func:`synthetic_pool` generates the SURVEY §8(d) random-pose pool and
+``sceneCategory.from_pool`` accepts any pool with the same fields.
+"""
+import copy
+
+import numpy as np
+import torch
+
+from . import ops, trainer
+
+
+# ---- free functions (reference signatures) -------------------------------------------------------
+def origin_dirs_O(T_CO, dirs_C):
+    """src/scene_cateogries.py:24-36."""
+    assert T_CO.shape[0] == dirs_C.shape[0]
+    assert T_CO.shape[1:] == (4, 4)
+    assert dirs_C.shape[1] == 3
+    T_OC = torch.linalg.inv(T_CO)
+    return T_OC[:, :3, -1], (T_OC[:, :3, :3] @ dirs_C[..., None]).squeeze(-1)
+
+
+def origin_dirs_W(T_WC, dirs_C):
+    """src/scene_cateogries.py:38-47."""
+    assert T_WC.shape[0] == dirs_C.shape[0]
+    assert T_WC.shape[1:] == (4, 4)
+    assert dirs_C.shape[1] == 3
+    return T_WC[:, :3, -1], (T_WC[:, :3, :3] @ dirs_C[..., None]).squeeze(-1)
+
+
+def stratified_bins(min_depth, max_depth, n_bins, n_rays, type=torch.float32, device="cuda:0", z_fixed=False):
+    """src/scene_cateogries.py:51-81 (stand-alone form; the train step samples in cnr_sample_rays)."""
+    lim = torch.linspace(0, 1, n_bins + 1, dtype=type, device=device)
+    if not torch.is_tensor(min_depth):
+        min_depth = torch.ones(n_rays, dtype=type, device=device) * min_depth
+    if not torch.is_tensor(max_depth):
+        max_depth = torch.ones(n_rays, dtype=type, device=device) * max_depth
+    rng = max_depth - min_depth
+    lower = (rng[..., None] * lim + min_depth[..., None])[:, :-1]
+    assert lower.shape == (n_rays, n_bins)
+    return lower + torch.rand(n_rays, n_bins, device=device, dtype=torch.float32) * (rng / n_bins)[..., None]
+
+
+def normal_bins_sampling(depth, n_bins, n_rays, delta, device="cuda:0"):
+    """src/scene_cateogries.py:84-96."""
+    bins = torch.empty(n_rays, n_bins, dtype=torch.float32, device=device).normal_(mean=0., std=delta / 3.)
+    bins = torch.clip(bins.sort().values, -delta, delta)
+    z_vals = depth[:, None] + bins
+    assert z_vals.shape == (n_rays, n_bins)
+    return z_vals
+
+
+class cameraInfo:
+    """src/scene_cateogries.py:600-629: pinhole directions, z-depth convention (not normalised)."""
+
+    def __init__(self, cfg) -> None:
+        self.width, self.height = cfg.W, cfg.H
+        self.fx, self.fy, self.cx, self.cy = cfg.fx, cfg.fy, cfg.cx, cfg.cy
+        self.rays_dir_cache = self.get_rays_dirs()
+
+    def get_rays_dirs(self, depth_type="z"):
+        if depth_type != "z":
+            raise Exception("Get camera rays directions with euclidean depth not yet implemented")
+        dirs = torch.ones((self.width, self.height, 3))
+        dirs[:, :, 0] = ((torch.arange(end=self.width) - self.cx) / self.fx)[:, None]
+        dirs[:, :, 1] = ((torch.arange(end=self.height) - self.cy) / self.fy)
+        return dirs
+
+
+# ---- synthetic pool --------------------------------------------------------------
+def _rand_rot(gen, n, device):
+    q = torch.randn(n, 4, generator=gen, device=device)
+    q = q / q.norm(dim=-1, keepdim=True)
+    w, x, y, z = q.unbind(-1)
+    return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                        2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                        2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1).view(n, 3, 3)
+
+
+def synthetic_pool(n_rays, n_obj, generator, device, width=1200, height=680, fx=600.0, fy=600.0,
+                   cx=599.5, cy=339.5, pose_group=1024):
+    """Random-pose ray pool: fields rgbs (N,4) u8 [r,g,b,state], depth (N,), dirs (N,3), T_co (N,4,4),
+    T_wc (N,4,4), indices (N,) int64.  Same generator recipe on CPU (oracle timing) and GPU."""
+    g = generator
+    N = n_rays
+    u = torch.randint(0, width, (N,), generator=g, device=device).float()
+    v = torch.randint(0, height, (N,), generator=g, device=device).float()
+    dirs = torch.stack([(u - cx) / fx, (v - cy) / fy, torch.ones(N, device=device)], -1)
+    ng = (N + pose_group - 1) // pose_group
+    eye = torch.eye(4, device=device)
+    T_wc = eye.repeat(ng, 1, 1)
+    T_wc[:, :3, :3] = _rand_rot(g, ng, device)
+    T_wc[:, :3, 3] = torch.rand(ng, 3, generator=g, device=device) * 2 - 1
+    T_wo = eye.repeat(ng, 1, 1)
+    s = 0.3 + 0.7 * torch.rand(ng, 1, 1, generator=g, device=device)
+    T_wo[:, :3, :3] = _rand_rot(g, ng, device) * s
+    T_wo[:, :3, 3] = torch.rand(ng, 3, generator=g, device=device) * 2 - 1
+    T_co = torch.linalg.inv(T_wc) @ T_wo
+    grp = torch.arange(N, device=device) // pose_group
+    depth = 0.5 + 3.0 * torch.rand(N, generator=g, device=device)
+    depth = torch.where(torch.rand(N, generator=g, device=device) < 0.05, torch.zeros_like(depth), depth)
+    pr = torch.rand(N, generator=g, device=device)
+    state = torch.where(pr < 0.70, 1, torch.where(pr < 0.95, 0, 2)).to(torch.uint8)
+    rgb = torch.randint(0, 256, (N, 3), generator=g, device=device, dtype=torch.uint8)
+    return dict(rgbs=torch.cat([rgb, state[:, None]], -1).contiguous(), depth=depth.contiguous(),
+                dirs=dirs.contiguous(), T_co=T_co[grp].contiguous(), T_wc=T_wc[grp].contiguous(),
+                indices=torch.randint(0, n_obj, (N,), generator=g, device=device))
+
+
+# ---- per-category scene object ------------------------------------------------------------------------
+class sceneCategory():
+    """shared MLP + instance-specific codes for one category; single batch holds all its instances.
+
+    Construct with :meth:`from_pool` (the dataset-driven ``__init__`` of the reference,
+    src/scene_cateogries.py:107-350, is out of scope)."""
+
+    other_obj, this_obj, unknown_obj = 0, 1, 2  # pixel states (:141-143)
+
+    def __init__(self, cfg, cls_id, inst_dict, sample_dict, cached_rays_dir):
+        raise NotImplementedError("building the ray pool from dataset frames is out of scope; "
+                                  "use sceneCategory.from_pool(cfg, cls_id, obj_ids, pool)")
+
+    @classmethod
+    def from_pool(cls, cfg, cls_id, obj_ids, pool, seed=0):
+        self = object.__new__(cls)
+        assert cls_id != 0, "background branch is a 'next' row"
+        self.cls_id = cls_id
+        self.obj_ids = list(obj_ids)
+        self.data_device = cfg.data_device
+        self.training_device = cfg.training_device
+        self.obj_scale = cfg.obj_scale
+        self.hidden_feature_size = cfg.hidden_feature_size
+        self.n_bins_cam2surface = cfg.n_bins_cam2surface
+        self.min_bound, self.max_bound = cfg.min_depth, cfg.max_depth
+        self.n_bins = cfg.n_bins
+        self.surface_eps, self.stop_eps = cfg.surface_eps, cfg.stop_eps
+        dev = self.data_device
+        self.rgbs_batch_all = pool["rgbs"].to(dev)
+        self.depth_batch_all = pool["depth"].to(dev)
+        self.ray_dirs_batch_all = pool["dirs"].to(dev)
+        self.t_co_batch_all = pool["T_co"].to(dev)
+        self.t_wc_batch_all = pool["T_wc"].to(dev) if len(self.obj_ids) == 1 else None
+        self.batch_indices_all = pool["indices"].to(dev)
+        self.i_batch = 0
+        self.parity_draws = None  # (u, g) tensors for the next get_training_samples call (tests)
+        self._seed, self._calls = int(seed) * 7919 + int(cls_id) + 1, 0
+        trainer_cfg = copy.copy(cfg)
+        trainer_cfg.obj_scale = self.obj_scale
+        self.trainer = trainer.Trainer(trainer_cfg, cls_id, self.obj_ids)
+        return self
+
+    def sample_3d_points(self, sampled_rgbs, sampled_depth, T, dirs_c, world_frame, u=None, g=None):
+        """a2-a5 for one slice (leading class dim of 1 added for the kernel)."""
+        self._calls += 1
+        out = ops.sample_rays(sampled_rgbs[None], sampled_depth[None], dirs_c[None], T[None],
+                              self.n_bins_cam2surface, self.n_bins, self.surface_eps, self.stop_eps,
+                              min_bound=self.min_bound, world_frame=world_frame, u=u, g=g,
+                              seed=self._seed, offset=self._calls * 4)
+        return out
+
+    def get_training_samples(self, n_samples):
+        """-> (gt_rgb uint8 (R,3), gt_depth (R,), depth_mask bool (R,), obj_mask uint8 (R,),
+        input_pcs (R,S,3), sampled_z (R,S), indices int64 (R,))  -- src/scene_cateogries.py:421-451."""
+        sl = slice(self.i_batch, self.i_batch + n_samples)
+        batch_indices = self.batch_indices_all[sl]
+        rgbs, depth, dirs = self.rgbs_batch_all[sl], self.depth_batch_all[sl], self.ray_dirs_batch_all[sl]
+        single = len(self.obj_ids) == 1
+        T = self.t_wc_batch_all[sl] if single else self.t_co_batch_all[sl]
+        u, g = self.parity_draws if self.parity_draws is not None else (None, None)
+        self.parity_draws = None
+        out = self.sample_3d_points(rgbs, depth, T, dirs, single, u=u, g=g)
+        self.i_batch += n_samples
+        if self.i_batch >= self.rgbs_batch_all.shape[0] - n_samples:  # reshuffle per epoch (:439-449)
+            rand_idx = torch.randperm(self.rgbs_batch_all.shape[0], device=self.data_device)
+            self.batch_indices_all = self.batch_indices_all[rand_idx]
+            self.rgbs_batch_all = self.rgbs_batch_all[rand_idx]
+            self.depth_batch_all = self.depth_batch_all[rand_idx]
+            self.ray_dirs_batch_all = self.ray_dirs_batch_all[rand_idx]
+            self.t_co_batch_all = self.t_co_batch_all[rand_idx]
+            if single:
+                self.t_wc_batch_all = self.t_wc_batch_all[rand_idx]
+            self.i_batch = 0
+        return (rgbs[:, :3], depth, out["depth_mask"][0].bool(), out["labels"][0], out["pts"][0],
+                out["z"][0], batch_indices)

@@ -1,0 +1,67 @@
+"""Model holder with the reference's surface (src/trainer.py:11-60,125-151): ``.pe``,
+``.fc_occ_map``, ``.shape_codes``, ``.texture_codes``, ``.inst_id_to_index``, ``.n_obj``,
+``.obj_scale``, ``.emb_size1/2``, ``.eval_points``.  Meshing (marching cubes / trimesh) is out of
+scope."""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import embedding, model, render_rays
+
+
+class Trainer:
+    def __init__(self, cfg, cls_id, inst_ids):
+        self.cls_id = cls_id
+        self.inst_id_to_index = {inst_id: inst_ids.index(inst_id) for inst_id in inst_ids}
+        self.n_obj = len(inst_ids)
+        self.device = cfg.training_device
+        self.obj_scale = cfg.obj_scale
+        self.n_unidir_funcs = cfg.n_unidir_funcs
+        self.emb_size1 = 21 * (3 + 1) + 3
+        self.emb_size2 = 21 * (5 + 1) + 3 - self.emb_size1
+        if cls_id == 0:
+            raise NotImplementedError("background OccupancyMap path is a 'next' row (SURVEY.md §8(f).1)")
+        self.net_hyperparams = cfg.net_hyperparams
+        self.load_codeNeRF()
+        self.load_codes()
+        self.extent_dict = None
+        self.bound_extent = 0.9
+        self.scale_template = None
+
+    def load_codeNeRF(self):
+        self.fc_occ_map = model.CodeNeRF(self.emb_size1, self.emb_size2, **self.net_hyperparams).to(self.device)
+        self.fc_occ_map.apply(model.init_weights).to(self.device)
+        self.pe = embedding.UniDirsEmbed(max_deg=self.n_unidir_funcs, scale=self.obj_scale).to(self.device)
+
+    def load_codes(self):
+        embdim = self.net_hyperparams['latent_dim']
+        d = self.n_obj
+        self.shape_codes = nn.Embedding(d, embdim)
+        self.texture_codes = nn.Embedding(d, embdim)
+        self.shape_codes.weight = nn.Parameter(torch.randn(d, embdim) / math.sqrt(embdim / 2))
+        self.texture_codes.weight = nn.Parameter(torch.randn(d, embdim) / math.sqrt(embdim / 2))
+        self.shape_codes = self.shape_codes.to(self.device)
+        self.texture_codes = self.texture_codes.to(self.device)
+
+    def eval_points(self, points, inst_id=None, chunk_size=500000):
+        """Forward-only occupancy / colour of (N,3) points for one object (src/trainer.py:125-151)."""
+        obj_idx = torch.tensor(self.inst_id_to_index[inst_id], device=self.device)
+        shape_code, texture_code = self.shape_codes(obj_idx), self.texture_codes(obj_idx)
+        alpha, color = [], []
+        n_chunks = int(np.ceil(points.shape[0] / chunk_size))
+        with torch.no_grad():
+            for k in range(n_chunks):
+                pts = points[k * chunk_size:(k + 1) * chunk_size, None, :]         # (n,1,3): S = 1
+                emb = self.pe(pts)
+                n = pts.shape[0]
+                a_k, c_k = self.fc_occ_map(emb, shape_code.expand(n, 1, -1), texture_code.expand(n, 1, -1))
+                alpha.append(a_k.reshape(-1))
+                color.append(c_k.reshape(-1, 3))
+        alpha, color = torch.cat(alpha), torch.cat(color)
+        occ = render_rays.occupancy_activation(alpha).detach()
+        if occ.max() == 0:
+            print("no occ")
+            return None
+        return (occ, color)

@@ -1,0 +1,130 @@
+/*
+ * cnr_hip.h -- C-ABI of libcnr_hip.so: MI355X (gfx950) kernels for the volumetric-rendering
+ * train-step hot path of Taekbum/category-nerf-reconstruction-official.
+ *
+ * The reference is pure Python/PyTorch: there is no FFI to replace.  Each entry
+ * point below therefore cites the reference *function* whose arithmetic it implements; the Python
+ * binding (category-nerf-reconstruction-official_amd/_C.py, ctypes) sits under the reference's own
+ * call surface (trainer.py / scene_cateogries.py / embedding.py / model.py / render_rays.py /
+ * loss.py).  INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to caller-allocated, contiguous, row-major memory;
+ *     f32 unless the name says otherwise.  No hidden allocation, no host sync, no global state.
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream).
+ *   - return 0 on success, a CNR_E_* code (<0) for argument errors, or a positive hipError_t.
+ *   - C = classes (the functorch vmap axis of train.py:154-155), R = rays per class,
+ *     S = samples per ray, N = R*S, L = latent dim, E = 129 = E1 (87) + E2 (42).
+ */
+#ifndef CNR_HIP_H
+#define CNR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CNR_OK 0
+#define CNR_E_ARG (-1)     /* bad size / null pointer                                  */
+#define CNR_E_SHAPE (-2)   /* shape not supported by this kernel (see function doc)    */
+#define CNR_E_ALIGN (-3)   /* pointer not aligned as documented                        */
+
+#define CNR_E1 87
+#define CNR_E2 42
+#define CNR_E 129
+#define CNR_W 32
+#define CNR_NDIR 21
+#define CNR_NFREQ 6
+/* fp32 trunk blob: the 10 per-sample Linear layers of CodeNeRF (src/model.py:35-54) in
+ * state_dict order, each as weight (out x in, row-major) followed by bias (out):
+ *   encoding_xyz.0 87->32 | shape_layer_1.0 32->32 | shape_layer_2.0 32->32 | cat_layer.0 119->32
+ *   encoding_shape 32->32 | sigma.0 32->1 | encoding_viewdir.0 74->32 | texture_layer_1.0 32->32
+ *   rgb.0 32->16 | rgb.2 16->3                                              = 13 892 floats   */
+#define CNR_TRUNK_PARAMS 13892
+/* latent slots of zlat (.., 4, 32): post-ReLU outputs of the four latent layers, per ray:
+ *   0 shape_latent_layer_1 | 1 cat_latent_layer | 2 shape_latent_layer_2 | 3 texture_latent_layer_1 */
+#define CNR_NLAT 4
+
+/* library / device probe: returns CNR_OK and fills n_cu, lds_bytes when a gfx950 device is current */
+int cnr_version(void);
+int cnr_device_info(int* n_cu, int* lds_bytes, int* gcn_arch_is_gfx950);
+
+/* ---- a2-a5: ray transform + depth-guided sampling (src/scene_cateogries.py:24-47, 51-96, 453-546)
+ * One pool slice of R rays (per class; C slices batched).  Inputs:
+ *   rgbs  (C,R,4) u8  [r,g,b,state]      depth (C,R)      dirs_c (C,R,3)     T (C,R,4,4)
+ *   u     (C,R,n1+n2) uniform [0,1) draws, g (C,R,n2) N(0,(eps/3)^2) draws  (parity mode), or both
+ *         NULL with `seed`/`offset` != 0 for in-kernel Philox draws (perf mode).
+ *   world_frame: 0 -> origin_dirs_O (T is T_CO, inverted in-kernel, sim3 closed form is NOT assumed:
+ *         a general 3x3 inverse is used), 1 -> origin_dirs_W (T is T_WC).
+ *   max_bound (C,) : per-class max(depth) over the slice (reference :486); computed by
+ *         cnr_sample_maxdepth below so that no host sync is needed.
+ * Outputs: z (C,R,S) with S = n1+n2, pts (C,R,S,3), origins (C,R,3) and dirs_o (C,R,3) (may be NULL),
+ *   gt_rgb (C,R,3) f32 already /255 (train.py:144), depth_mask (C,R) u8, labels (C,R) u8. */
+int cnr_sample_maxdepth(const float* depth, float* max_bound, int C, int R, void* stream);
+int cnr_sample_rays(const uint8_t* rgbs, const float* depth, const float* dirs_c, const float* T,
+                    const float* u, const float* g, uint64_t seed, uint64_t offset,
+                    const float* max_bound, int world_frame, int C, int R, int n1, int n2,
+                    float eps, float stop_eps, float min_bound,
+                    float* z, float* pts, float* origins, float* dirs_o,
+                    float* gt_rgb, uint8_t* depth_mask, uint8_t* labels, void* stream);
+
+/* ---- a8: UniDirsEmbed (src/embedding.py:82-92).  x (C,N,3), B (C,21,3) -> e (C,N,129).
+ * e[0:3] = x/scale ; e[3+21k+j] = sin(pi * 2^k * (B_j . x/scale)), k = 0..5.
+ * bwd: de (C,N,129) -> dB (C,21,3) (accumulated with atomics: zero it first), dx NULL or (C,N,3). */
+int cnr_pe_fwd(const float* x, const float* B, float* e, int C, int64_t N, float scale, void* stream);
+int cnr_pe_bwd(const float* x, const float* B, const float* de, float* dB, float* dx,
+               int C, int64_t N, float scale, void* stream);
+
+/* ---- a9: CodeNeRF trunk, exact fp32 (src/model.py:56-84 with do_cat=True, noise_std=None).
+ * e (C,R,S,129), zlat (C,R,4,32) post-ReLU latent-layer outputs per ray (slots above),
+ * trunk (C,13892) -> sigmas (C,R,S) (= raw*10), rgbs (C,R,S,3).
+ * bwd recomputes the forward, then: dsig (C,R,S), drgb (C,R,S,3) ->
+ *   de (C,R,S,129), dzlat (C,R,4,32) and dtrunk (C,13892); dzlat/dtrunk are ACCUMULATED (zero first). */
+int cnr_mlp_fwd_f32(const float* e, const float* zlat, const float* trunk, float* sigmas, float* rgbs,
+                    int C, int R, int S, void* stream);
+int cnr_mlp_bwd_f32(const float* e, const float* zlat, const float* trunk,
+                    const float* dsig, const float* drgb,
+                    float* de, float* dzlat, float* dtrunk, int C, int R, int S, void* stream);
+
+/* ---- a11-a13: occupancy_activation + occupancy_to_termination + render x4
+ * (src/render_rays.py:3-7,25-33,46-50 ; src/loss.py:41-48).  NR = C*R rays.
+ * alpha (NR,S), color (NR,S,3), z (NR,S) -> term (NR,S) [may be NULL], depth, var, opacity (NR,), rgb (NR,3).
+ * bwd: d_depth, d_opacity (NR,), d_rgb (NR,3) [var is detached in the reference] and optional
+ * d_term (NR,S) [NULL = none] -> d_alpha (NR,S), d_color (NR,S,3).
+ * in_is_occ = 1: `alpha` already holds occupancies (occupancy_to_termination called on its own, as
+ * src/trainer.py:147 / src/category_registration.py:152 do); d_alpha is then d/d(occupancy).
+ * color/z and the outputs that need them may be NULL. */
+int cnr_composite_fwd(const float* alpha, const float* color, const float* z, float* term,
+                      float* depth, float* var, float* rgb, float* opacity,
+                      int64_t NR, int S, int in_is_occ, void* stream);
+int cnr_composite_bwd(const float* alpha, const float* color, const float* z,
+                      const float* d_depth, const float* d_rgb, const float* d_opacity,
+                      const float* d_term, float* d_alpha, float* d_color,
+                      int64_t NR, int S, int in_is_occ, void* stream);
+
+/* ---- a14-a15 fused: masks + L1 losses + masked means + their gradient w.r.t. the rendered values
+ * (src/loss.py:18-74, src/render_rays.py:52-95).  Per class c: mask counts are reduced in-kernel
+ * (no host sync, no workspace).  Reference quirk kept: if ANY class has an empty mask for a term, that term is
+ * zero (no gradient) for ALL classes (render_rays.py:67-72).
+ * inputs (C,R): depth, var, opacity, gt_depth ; rgb, gt_rgb (C,R,3) ; labels, depth_mask (C,R) u8.
+ * outputs: losses (3,C) [depth,color,opacity]; flags (C,) i32: bit0 = "loss explode" (> 1e5,
+ *   render_rays.py:87-89 -- reported, never exit()), bits1-3 = the depth / colour / opacity term was
+ *   zeroed because some class has an empty mask; d_depth/d_opacity (C,R), d_rgb (C,R,3) = dLoss/d(render),
+ *   already multiplied by color_scaling / opacity_scaling and by `grad_scale`. */
+int cnr_loss_fwd_bwd(const float* depth, const float* var, const float* rgb, const float* opacity,
+                     const float* gt_depth, const float* gt_rgb, const uint8_t* labels,
+                     const uint8_t* depth_mask, float color_scaling, float opacity_scaling,
+                     float grad_scale, float* losses, int32_t* flags,
+                     float* d_depth, float* d_rgb, float* d_opacity, int C, int R, void* stream);
+
+/* ---- a18: AdamW on one flat fp32 buffer (train.py:40,183; torch.optim.AdamW semantics,
+ * amsgrad=False, maximize=False).  step_count is the 1-based step number held on the host. */
+int cnr_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                   float lr, float beta1, float beta2, float eps, float weight_decay,
+                   int64_t step_count, float grad_unscale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CNR_HIP_H */
