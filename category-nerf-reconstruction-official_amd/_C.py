@@ -109,3 +109,36 @@ def device_info():
     if rc != 0:
         raise CnrError(f"cnr_device_info failed with {rc}")
     return {"n_cu": n_cu.value, "lds_bytes": lds.value, "gfx950": bool(is950.value)}
+
+
+# ---- optional per-kernel HIP-event timing (bench.py's roofline leg) -------------------------------------
+_timing = None  # {name: [(start_event, end_event), ...]} when enabled
+
+
+def enable_kernel_timing(names):
+    """Record a HIP event pair (on the launch stream) around every call of the named entry points."""
+    global _timing
+    _timing = {n: [] for n in names}
+
+
+def kernel_timings_ms():
+    """-> {name: [ms, ...]} ; synchronises.  Disables timing."""
+    global _timing
+    torch.cuda.synchronize()
+    out = {n: [a.elapsed_time(b) for a, b in evs] for n, evs in (_timing or {}).items()}
+    _timing = None
+    return out
+
+
+_raw_call = call
+
+
+def call(name, *args):  # noqa: F811
+    if _timing is not None and name in _timing:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        _raw_call(name, *args)
+        b.record()
+        _timing[name].append((a, b))
+    else:
+        _raw_call(name, *args)
