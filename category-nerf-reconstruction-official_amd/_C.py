@@ -30,7 +30,12 @@ SIGNATURES = {
     "cnr_loss_fwd_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp,
                          _i, _i, _vp],
     "cnr_adamw_step": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i64, _f, _vp],
+    "cnr_pack_bytes": [],
+    "cnr_pack_weights": [_vp, _vp, _i, _vp],
+    "cnr_field_fwd": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _vp],
+    "cnr_field_bwd": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
 }
+_RESTYPE64 = {"cnr_pack_bytes"}
 
 _lib = None
 _double = None
@@ -51,7 +56,7 @@ def load():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_int
+            fn.restype = ctypes.c_int64 if name in _RESTYPE64 else ctypes.c_int
         _lib = lib
     return _lib
 
@@ -101,6 +106,10 @@ def call(name, *args):
 
 def version():
     return load().cnr_version()
+
+
+def pack_bytes():
+    return int(load().cnr_pack_bytes())
 
 
 def device_info():

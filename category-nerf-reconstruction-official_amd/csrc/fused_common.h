@@ -1,0 +1,149 @@
+// Layout contract of the fused f16-MFMA path (fused_fwd.hip / fused_bwd.hip / pack kernel).
+//
+// Orientation: every layer is computed TRANSPOSED, D = W * X^T with v_mfma_f32_32x32x16_f16:
+//   A = W        (rows = output features, K = input features)      -- pre-packed fragments in LDS
+//   B = X^T      (K = input features, columns = 32 samples = lanes) -- built in registers
+//   D = (W X^T)  32 output features x 32 samples: column (sample) = lane & 31,
+//                row(reg, h) = (reg & 3) + 8 * (reg >> 2) + 4 * h,  h = lane >> 5, reg in [0,16)
+// so that a layer's accumulators, converted pairwise to f16, ARE the next layer's B operand with no
+// lane movement (MI355X guide, "An accumulator tile as the next MFMA's operand"): B fragment of
+// k-step s, element j of lane half h  <->  feature 16 s + 8 (j >> 2) + 4 h + (j & 3).  The packed A
+// fragments carry the matching K permutation.
+//
+// Positional-encoding features are produced directly in B-operand layout.  Each lane half owns a set
+// of directions (half 0: dirs 0..10, half 1: dirs 11..20 + one zero dummy) so a lane evaluates only 33
+// dot-product terms and 66 sines per sample:
+//   E1 (6 k-steps, 48 slots per half): slot q = 11 * band + d, band 0..3, d 0..10 ; q 44..46 = t (half 0)
+//   E2 (3 k-steps, 24 slots per half): slot q = 11 * (band - 4) + d, band 4..5
+//   slot q lives in k-step q / 8, element q % 8.
+#pragma once
+#include "cnr_common.h"
+
+namespace fz {
+using namespace cnr;
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+// ---- forward A-fragment k-step table ---------------------------------------------------------------
+constexpr int KK_XYZ = 0, KK_S1 = 6, KK_CAT = 8, KK_S2 = 16, KK_ES = 18, KK_VD = 20, KK_T1 = 25,
+              KK_R0 = 27, KK_R2 = 29, NKK_FWD = 30;
+// ---- backward (transposed) A-fragment table: rows = INPUT features of the layer (one 32-row block
+// each), K = output features (k-steps of 16).  E1 / E2 row blocks are in slot order (16 slots per half
+// per block: block row (reg, h) <-> slot 16 * blk + reg of half h).
+constexpr int KT_R2 = 0;     // rgb.2^T     : rows a7 (16 used)      K = 3   -> 1 k-step
+constexpr int KT_R0 = 1;     // rgb.0^T     : rows a6 (32)           K = 16  -> 1
+constexpr int KT_T1 = 2;     // texture_1^T : rows a5 (32)           K = 32  -> 2
+constexpr int KT_VD_Y = 4;   // viewdir^T   : rows y4 (32)                    -> 2
+constexpr int KT_VD_E = 6;   //               rows E2 slots, 2 blocks         -> 2 x 2
+constexpr int KT_ES = 10;    // enc_shape^T : rows a3                         -> 2
+constexpr int KT_S2 = 12;    // shape_2^T   : rows a2                         -> 2
+constexpr int KT_CAT_Y = 14; // cat^T       : rows a1                         -> 2
+constexpr int KT_CAT_E = 16; //               rows E1 slots, 3 blocks         -> 3 x 2
+constexpr int KT_S1 = 22;    // shape_1^T   : rows a0                         -> 2
+constexpr int KT_XYZ_E = 24; // xyz^T       : rows E1 slots, 3 blocks         -> 3 x 2
+constexpr int NKK_BWD = 30;
+
+constexpr int FRAG_BYTES = 1024;  // 64 lanes x 16 B
+// f32 constants section (floats): acc-init biases of the non-latent layers, sigma head
+constexpr int CF_B_XYZ = 0, CF_B_ES = 32, CF_B_VD = 64, CF_B_R0 = 96, CF_B_R2 = 128, CF_W_SG = 160,
+              CF_B_SG = 192, CF_FLOATS = 256;
+constexpr int PK_OFF_FWD = 0;
+constexpr int PK_OFF_CONST = NKK_FWD * FRAG_BYTES;                 // 30720
+constexpr int PK_OFF_BWD = PK_OFF_CONST + CF_FLOATS * 4;           // 31744
+constexpr int PK_BYTES = PK_OFF_BWD + NKK_BWD * FRAG_BYTES;        // 62464
+
+// e-feature (0..128) held by slot q of lane-half h ; -1 = empty slot.  part 0 = E1, 1 = E2.
+__host__ __device__ inline int slot_feature(int part, int h, int q) {
+  if (part == 0) {
+    if (q < 44) {
+      const int band = q / 11, d = q % 11;
+      if (h == 0) return 3 + 21 * band + d;
+      return d < 10 ? 3 + 21 * band + 11 + d : -1;
+    }
+    if (q < 47 && h == 0) return q - 44;
+    return -1;
+  }
+  if (q < 22) {
+    const int band = 4 + q / 11, d = q % 11;
+    if (h == 0) return 3 + 21 * band + d;
+    return d < 10 ? 3 + 21 * band + 11 + d : -1;
+  }
+  return -1;
+}
+// feature (0..31) of an accumulator-derived B operand: k-step s, half h, element j
+__host__ __device__ inline int acc_feature(int s, int h, int j) { return 16 * s + 8 * (j >> 2) + 4 * h + (j & 3); }
+// accumulator row of (reg, h)
+__host__ __device__ inline int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+// ---------------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ h8 pack8(const f16v& a, int s, bool relu) {
+  h8 r;
+#pragma unroll
+  for (int j = 0; j < 8; j += 2) {
+    f2 v = {a[8 * s + j], a[8 * s + j + 1]};
+    h2 p = __builtin_convertvector(v, h2);
+    if (relu) { h2 z = {(_Float16)0, (_Float16)0}; p = __builtin_elementwise_max(p, z); }
+    r[j] = p[0]; r[j + 1] = p[1];
+  }
+  return r;
+}
+__device__ __forceinline__ h8 pack8f(const float* v) {
+  h8 r;
+#pragma unroll
+  for (int j = 0; j < 8; j += 2) {
+    f2 x = {v[j], v[j + 1]};
+    h2 p = __builtin_convertvector(x, h2);
+    r[j] = p[0]; r[j + 1] = p[1];
+  }
+  return r;
+}
+// accumulator init from 32 floats in natural feature order at p (LDS or global): lane needs rows
+// 8 g + 4 h + (0..3), g = 0..3
+__device__ __forceinline__ f16v acc_init(const float* p, int h) {
+  f16v a;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const f4 v = *reinterpret_cast<const f4*>(p + 8 * g + 4 * h);
+    a[4 * g + 0] = v[0]; a[4 * g + 1] = v[1]; a[4 * g + 2] = v[2]; a[4 * g + 3] = v[3];
+  }
+  return a;
+}
+__device__ __forceinline__ h8 lds_frag(const unsigned char* lds_w, int kk, int lane) {
+  return *reinterpret_cast<const h8*>(lds_w + kk * FRAG_BYTES + lane * 16);
+}
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+
+// Positional encoding of one sample in B-operand layout.  Bh: this lane-half's 11 direction rows
+// (row 10 of half 1 is zero).  ONES puts 1.0 into two empty half-0 slots (E1 slot 47, E2 slot 22): their
+// forward weights are zero, and in the backward's dW products they collect the bias gradients.
+template <bool ONES>
+__device__ __forceinline__ void pe_slots(const float (&Bh)[33], float t0, float t1, float t2, int h,
+                                         h8 (&E1f)[6], h8 (&E2f)[3]) {
+  float v[72];
+#pragma unroll
+  for (int d = 0; d < 11; ++d) {
+    const float p = Bh[3 * d] * t0 + Bh[3 * d + 1] * t1 + Bh[3 * d + 2] * t2;
+    // sin(pi 2^b p) = v_sin(2^(b-1) p)  (hardware sine takes revolutions)
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+      const float arg = p * (0.5f * (float)(1 << b));
+      const int q = b < 4 ? 11 * b + d : 48 + 11 * (b - 4) + d;
+      v[q] = __builtin_amdgcn_sinf(arg);
+    }
+  }
+  const float one = (ONES && h == 0) ? 1.0f : 0.0f;
+  v[44] = h == 0 ? t0 : 0.0f; v[45] = h == 0 ? t1 : 0.0f; v[46] = h == 0 ? t2 : 0.0f; v[47] = one;
+  v[70] = one; v[71] = 0.0f;
+#pragma unroll
+  for (int s = 0; s < 6; ++s) E1f[s] = pack8f(&v[8 * s]);
+#pragma unroll
+  for (int s = 0; s < 3; ++s) E2f[s] = pack8f(&v[48 + 8 * s]);
+}
+
+}  // namespace fz

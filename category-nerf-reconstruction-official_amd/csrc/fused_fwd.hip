@@ -1,0 +1,236 @@
+// Fused field forward for the train / render path: pts -> UniDirsEmbed (a8) -> CodeNeRF trunk (a9)
+// -> sigmas, rgbs, one launch, nothing but 12 B in and 16 B out per sample touches HBM.
+// f16 MFMA operands (v_mfma_f32_32x32x16_f16), fp32 accumulate, fp32 positional encoding with the
+// hardware sine, fp32 VALU sigma head (the x10 logit is the precision-critical output: it never sees an
+// f16 rounding of its inputs' last layer).  See fused_common.h for the operand-layout contract.
+//
+// Work split: tile = 32 consecutive samples; one wave processes a tile at a time (grid-stride), four
+// waves per workgroup share the packed weight image in LDS (31 KB), >= 2 waves per SIMD for VALU rate.
+// Latent conditioning arrives as per-row effective biases  bias'_l[row] = W_l z_l[row] + b_l  (row =
+// object, or ray for per-ray codes): W_l (a + z) + b = W_l a + bias'_l, so the latent add costs no VALU.
+#include "fused_common.h"
+
+namespace {
+using namespace fz;
+
+// ---------------------------------------------------------------------------------------------------
+// weight packing (device): fp32 trunk blob (C, 13892) -> packed image (C, PK_BYTES)
+// ---------------------------------------------------------------------------------------------------
+struct LayerRef { int w_off, ld, out; };
+
+__device__ __forceinline__ float fwd_elem(const float* __restrict__ Wt, int kk, int r, int h, int j) {
+  // A[r][k] of forward k-step kk ; returns 0 for padding
+  int s, w_off, ld, out, col = -1;
+  if (kk < KK_S1) { s = kk - KK_XYZ; w_off = OFF_XYZ_W; ld = E1; out = 32;
+    const int f = slot_feature(0, h, 8 * s + j); col = f; }
+  else if (kk < KK_CAT) { s = kk - KK_S1; w_off = OFF_S1_W; ld = 32; out = 32; col = acc_feature(s, h, j); }
+  else if (kk < KK_S2) { s = kk - KK_CAT; w_off = OFF_CAT_W; ld = 32 + E1; out = 32;
+    if (s < 2) col = acc_feature(s, h, j);
+    else { const int f = slot_feature(0, h, 8 * (s - 2) + j); col = f < 0 ? -1 : 32 + f; } }
+  else if (kk < KK_ES) { s = kk - KK_S2; w_off = OFF_S2_W; ld = 32; out = 32; col = acc_feature(s, h, j); }
+  else if (kk < KK_VD) { s = kk - KK_ES; w_off = OFF_ES_W; ld = 32; out = 32; col = acc_feature(s, h, j); }
+  else if (kk < KK_T1) { s = kk - KK_VD; w_off = OFF_VD_W; ld = 32 + E2; out = 32;
+    if (s < 2) col = acc_feature(s, h, j);
+    else { const int f = slot_feature(1, h, 8 * (s - 2) + j); col = f < 0 ? -1 : 32 + (f - E1); } }
+  else if (kk < KK_R0) { s = kk - KK_T1; w_off = OFF_T1_W; ld = 32; out = 32; col = acc_feature(s, h, j); }
+  else if (kk < KK_R2) { s = kk - KK_R0; w_off = OFF_R0_W; ld = 32; out = 16; col = acc_feature(s, h, j); }
+  else { s = 0; w_off = OFF_R2_W; ld = 16; out = 3; col = acc_feature(0, h, j); }
+  if (col < 0 || r >= out) return 0.0f;
+  return Wt[w_off + r * ld + col];
+}
+
+__device__ __forceinline__ float bwd_elem(const float* __restrict__ Wt, int kt, int r, int h, int j) {
+  // A[r][k] of the transposed product: r = input feature (or E slot row), k = output feature
+  int s, w_off, ld, out, in_col = -1;
+  const int hh = (r >> 2) & 1, reg = (r & 3) + 4 * (r >> 3);  // inverse of acc_row
+  if (kt < KT_R0) { s = 0; w_off = OFF_R2_W; ld = 16; out = 3; in_col = r < 16 ? r : -1; }
+  else if (kt < KT_T1) { s = 0; w_off = OFF_R0_W; ld = 32; out = 16; in_col = r; }
+  else if (kt < KT_VD_Y) { s = kt - KT_T1; w_off = OFF_T1_W; ld = 32; out = 32; in_col = r; }
+  else if (kt < KT_VD_E) { s = kt - KT_VD_Y; w_off = OFF_VD_W; ld = 32 + E2; out = 32; in_col = r; }
+  else if (kt < KT_ES) { const int b = (kt - KT_VD_E) >> 1; s = (kt - KT_VD_E) & 1; w_off = OFF_VD_W; ld = 32 + E2; out = 32;
+    const int q = 16 * b + reg; const int f = q < 24 ? slot_feature(1, hh, q) : -1; in_col = f < 0 ? -1 : 32 + (f - E1); }
+  else if (kt < KT_S2) { s = kt - KT_ES; w_off = OFF_ES_W; ld = 32; out = 32; in_col = r; }
+  else if (kt < KT_CAT_Y) { s = kt - KT_S2; w_off = OFF_S2_W; ld = 32; out = 32; in_col = r; }
+  else if (kt < KT_CAT_E) { s = kt - KT_CAT_Y; w_off = OFF_CAT_W; ld = 32 + E1; out = 32; in_col = r; }
+  else if (kt < KT_S1) { const int b = (kt - KT_CAT_E) >> 1; s = (kt - KT_CAT_E) & 1; w_off = OFF_CAT_W; ld = 32 + E1; out = 32;
+    const int f = slot_feature(0, hh, 16 * b + reg); in_col = f < 0 ? -1 : 32 + f; }
+  else if (kt < KT_XYZ_E) { s = kt - KT_S1; w_off = OFF_S1_W; ld = 32; out = 32; in_col = r; }
+  else { const int b = (kt - KT_XYZ_E) >> 1; s = (kt - KT_XYZ_E) & 1; w_off = OFF_XYZ_W; ld = E1; out = 32;
+    const int f = slot_feature(0, hh, 16 * b + reg); in_col = f; }
+  const int o = acc_feature(s, h, j);
+  if (in_col < 0 || o >= out) return 0.0f;
+  return Wt[w_off + o * ld + in_col];
+}
+
+__global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ trunk, unsigned char* __restrict__ packed) {
+  const int c = blockIdx.y;
+  const float* Wt = trunk + (size_t)c * TRUNK;
+  unsigned char* out = packed + (size_t)c * PK_BYTES;
+  const int kk = blockIdx.x;  // 0 .. NKK_FWD + NKK_BWD (+1 for constants)
+  if (kk < NKK_FWD + NKK_BWD) {
+    for (int e = threadIdx.x; e < 64 * 8; e += 256) {
+      const int lane = e >> 3, j = e & 7, r = lane & 31, h = lane >> 5;
+      const float v = kk < NKK_FWD ? fwd_elem(Wt, kk, r, h, j) : bwd_elem(Wt, kk - NKK_FWD, r, h, j);
+      const size_t base = kk < NKK_FWD ? (size_t)PK_OFF_FWD + (size_t)kk * FRAG_BYTES
+                                       : (size_t)PK_OFF_BWD + (size_t)(kk - NKK_FWD) * FRAG_BYTES;
+      reinterpret_cast<_Float16*>(out + base)[lane * 8 + j] = (_Float16)v;
+    }
+  } else {
+    float* cf = reinterpret_cast<float*>(out + PK_OFF_CONST);
+    for (int i = threadIdx.x; i < CF_FLOATS; i += 256) {
+      float v = 0.0f;
+      const int o = i & 31;
+      if (i < 32) v = Wt[OFF_XYZ_B + o];
+      else if (i < 64) v = Wt[OFF_ES_B + o];
+      else if (i < 96) v = Wt[OFF_VD_B + o];
+      else if (i < 128) v = o < 16 ? Wt[OFF_R0_B + o] : 0.0f;
+      else if (i < 160) v = o < 3 ? Wt[OFF_R2_B + o] : 0.0f;
+      else if (i < 192) v = Wt[OFF_SG_W + o];
+      else if (i == CF_B_SG) v = Wt[OFF_SG_B];
+      cf[i] = v;
+    }
+  }
+}
+
+}  // namespace
+
+namespace {
+
+__global__ __launch_bounds__(256, 2) void field_fwd_kernel(
+    const float* __restrict__ pts, const float* __restrict__ Bdir, const unsigned char* __restrict__ packed,
+    const float* __restrict__ biasrows, const int* __restrict__ ray_row, float inv_scale,
+    float* __restrict__ sigmas, float* __restrict__ rgbs, int64_t N /* samples per class */, int S, int R) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int c = blockIdx.y;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, h = lane >> 5, col = lane & 31;
+  // stage forward fragments + constants + this class's direction matrix into LDS
+  {
+    const unsigned char* src = packed + (size_t)c * PK_BYTES;
+    for (int i = threadIdx.x * 16; i < PK_OFF_BWD; i += 256 * 16)
+      *reinterpret_cast<f4*>(smem + i) = *reinterpret_cast<const f4*>(src + i);
+    float* Bl = reinterpret_cast<float*>(smem + PK_OFF_BWD);  // [2][33] per-half rows
+    for (int i = threadIdx.x; i < 66; i += 256) {
+      const int hh = i / 33, k = i % 33, d = k / 3;
+      Bl[i] = (hh == 1 && d == 10) ? 0.0f : Bdir[(size_t)c * 63 + (11 * hh + d) * 3 + (k % 3)];
+    }
+  }
+  __syncthreads();
+  const float* cf = reinterpret_cast<const float*>(smem + PK_OFF_CONST);
+  float Bh[33];
+  {
+    const float* Bl = reinterpret_cast<const float*>(smem + PK_OFF_BWD) + 33 * h;
+#pragma unroll
+    for (int i = 0; i < 33; ++i) Bh[i] = Bl[i];
+  }
+  const int64_t ntiles = (N + 31) / 32;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wv; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+    // the weight fragments are loop-invariant LDS loads: stop LICM from hoisting 120 VGPRs of them
+    asm volatile("" ::: "memory");
+    const int64_t n = tile * 32 + col;
+    const bool live = n < N;
+    const int64_t nc = live ? n : N - 1;
+    const int64_t gs = (int64_t)c * N + nc;
+    const float* pp = pts + gs * 3;
+    const float t0 = pp[0] * inv_scale, t1 = pp[1] * inv_scale, t2 = pp[2] * inv_scale;
+    const int64_t ray = (int64_t)c * R + nc / S;
+    const int64_t row = ray_row ? (int64_t)ray_row[ray] : ray;
+    const float* brow = biasrows + row * (CNR_NLAT * 32);
+
+    h8 E1f[6], E2f[3];
+    pe_slots<false>(Bh, t0, t1, t2, h, E1f, E2f);
+
+    // L0 encoding_xyz
+    f16v acc = acc_init(cf + CF_B_XYZ, h);
+#pragma unroll
+    for (int s = 0; s < 6; ++s) acc = MFMA(lds_frag(smem, KK_XYZ + s, lane), E1f[s], acc);
+    h8 H0 = pack8(acc, 0, true), H1 = pack8(acc, 1, true);
+    // L1 shape_layer_1 (latent slot 0 folded into the bias row)
+    acc = acc_init(brow + 0 * 32, h);
+    acc = MFMA(lds_frag(smem, KK_S1 + 0, lane), H0, acc);
+    acc = MFMA(lds_frag(smem, KK_S1 + 1, lane), H1, acc);
+    H0 = pack8(acc, 0, true); H1 = pack8(acc, 1, true);
+    // L2 cat_layer: [a1 | e1]
+    acc = acc_init(brow + 1 * 32, h);
+    acc = MFMA(lds_frag(smem, KK_CAT + 0, lane), H0, acc);
+    acc = MFMA(lds_frag(smem, KK_CAT + 1, lane), H1, acc);
+#pragma unroll
+    for (int s = 0; s < 6; ++s) acc = MFMA(lds_frag(smem, KK_CAT + 2 + s, lane), E1f[s], acc);
+    H0 = pack8(acc, 0, true); H1 = pack8(acc, 1, true);
+    // L3 shape_layer_2
+    acc = acc_init(brow + 2 * 32, h);
+    acc = MFMA(lds_frag(smem, KK_S2 + 0, lane), H0, acc);
+    acc = MFMA(lds_frag(smem, KK_S2 + 1, lane), H1, acc);
+    H0 = pack8(acc, 0, true); H1 = pack8(acc, 1, true);
+    // L4 encoding_shape (no activation)
+    acc = acc_init(cf + CF_B_ES, h);
+    acc = MFMA(lds_frag(smem, KK_ES + 0, lane), H0, acc);
+    acc = MFMA(lds_frag(smem, KK_ES + 1, lane), H1, acc);
+    // sigma head in fp32 on the VALU: raw = w_sigma . y4 + b
+    float raw;
+    {
+      const f16v ws = acc_init(cf + CF_W_SG, h);
+      float part = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) part = fmaf(ws[i], acc[i], part);
+      raw = part + __shfl_xor(part, 32, 64) + cf[CF_B_SG];
+    }
+    H0 = pack8(acc, 0, false); H1 = pack8(acc, 1, false);
+    // L6 encoding_viewdir: [y4 | e2]
+    acc = acc_init(cf + CF_B_VD, h);
+    acc = MFMA(lds_frag(smem, KK_VD + 0, lane), H0, acc);
+    acc = MFMA(lds_frag(smem, KK_VD + 1, lane), H1, acc);
+#pragma unroll
+    for (int s = 0; s < 3; ++s) acc = MFMA(lds_frag(smem, KK_VD + 2 + s, lane), E2f[s], acc);
+    H0 = pack8(acc, 0, true); H1 = pack8(acc, 1, true);
+    // L7 texture_layer_1
+    acc = acc_init(brow + 3 * 32, h);
+    acc = MFMA(lds_frag(smem, KK_T1 + 0, lane), H0, acc);
+    acc = MFMA(lds_frag(smem, KK_T1 + 1, lane), H1, acc);
+    H0 = pack8(acc, 0, true); H1 = pack8(acc, 1, true);
+    // L8 rgb.0 (16 outputs = rows 0..15 = registers 0..7)
+    acc = acc_init(cf + CF_B_R0, h);
+    acc = MFMA(lds_frag(smem, KK_R0 + 0, lane), H0, acc);
+    acc = MFMA(lds_frag(smem, KK_R0 + 1, lane), H1, acc);
+    H0 = pack8(acc, 0, true);
+    // L9 rgb.2 (3 outputs = rows 0..2 = registers 0..2 of half 0)
+    acc = acc_init(cf + CF_B_R2, h);
+    acc = MFMA(lds_frag(smem, KK_R2, lane), H0, acc);
+    if (live && h == 0) {
+      sigmas[gs] = raw * 10.0f;
+      float* o = rgbs + gs * 3;
+      o[0] = 1.0f / (1.0f + __expf(-acc[0]));
+      o[1] = 1.0f / (1.0f + __expf(-acc[1]));
+      o[2] = 1.0f / (1.0f + __expf(-acc[2]));
+    }
+  }
+}
+}  // namespace
+
+extern "C" int64_t cnr_pack_bytes(void) { return (int64_t)fz::PK_BYTES; }
+
+extern "C" int cnr_pack_weights(const float* trunk, void* packed, int C, void* stream) {
+  if (!trunk || !packed || C <= 0) return CNR_E_ARG;
+  if (((uintptr_t)packed & 15) != 0) return CNR_E_ALIGN;
+  dim3 grid(fz::NKK_FWD + fz::NKK_BWD + 1, (unsigned)C);
+  hipLaunchKernelGGL(pack_kernel, grid, dim3(256), 0, (hipStream_t)stream, trunk, (unsigned char*)packed);
+  CNR_LAUNCH_CHECK();
+  return CNR_OK;
+}
+
+extern "C" int cnr_field_fwd(const float* pts, const float* B, const void* packed, const float* biasrows,
+                             const int* ray_row, float scale, float* sigmas, float* rgbs, int C, int R, int S,
+                             void* stream) {
+  if (!pts || !B || !packed || !biasrows || !sigmas || !rgbs || C <= 0 || R <= 0 || S <= 0 || !(scale > 0.f))
+    return CNR_E_ARG;
+  if (((uintptr_t)packed & 15) != 0 || ((uintptr_t)biasrows & 15) != 0) return CNR_E_ALIGN;
+  const int64_t N = (int64_t)R * S;
+  const int64_t ntiles = (N + 31) / 32;
+  int64_t blocks = (ntiles + 3) / 4;
+  if (blocks > 2048) blocks = 2048;
+  const size_t lds = (size_t)fz::PK_OFF_BWD + 66 * sizeof(float) + 8;
+  dim3 grid((unsigned)blocks, (unsigned)C);
+  hipLaunchKernelGGL(field_fwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, pts, B,
+                     (const unsigned char*)packed, biasrows, ray_row, 1.0f / scale, sigmas, rgbs, N, S, R);
+  CNR_LAUNCH_CHECK();
+  return CNR_OK;
+}

@@ -258,3 +258,72 @@ def sample_rays(rgbs, depth, dirs_c, T, n1, n2, eps, stop_eps, min_bound=0.0, wo
 def adamw_step(param, grad, exp_avg, exp_avg_sq, lr, betas, eps, weight_decay, step, grad_unscale=1.0):
     _C.call("cnr_adamw_step", param, grad, exp_avg, exp_avg_sq, param.numel(), float(lr), float(betas[0]),
             float(betas[1]), float(eps), float(weight_decay), int(step), float(grad_unscale))
+
+
+# ================================================================================================
+# fused f16-MFMA field path
+# ================================================================================================
+# (weight offset, bias offset, leading dim) of the four latent-conditioned layers inside the trunk blob,
+# in biasrows slot order (include/cnr_hip.h)
+_LATENT_TARGETS = [(2816, 3840, 32), (4928, 8736, 119), (3872, 4896, 32), (12257, 13281, 32)]
+
+
+def bias_rows(trunk, zlat):
+    """trunk (C,13892), zlat (C,rows,4,32) post-ReLU latent outputs -> (C,rows,4,32) effective biases
+    W_l z_l + b_l of shape_layer_1 / cat_layer[:, :32] / shape_layer_2 / texture_layer_1 (differentiable)."""
+    C = trunk.shape[0]
+    outs = []
+    for k, (wo, bo, ld) in enumerate(_LATENT_TARGETS):
+        Wk = trunk[:, wo:wo + 32 * ld].view(C, 32, ld)[:, :, :32]
+        bk = trunk[:, bo:bo + 32]
+        outs.append(torch.baddbmm(bk[:, None, :], zlat[:, :, k, :], Wk.transpose(1, 2)))
+    return torch.stack(outs, dim=2)
+
+
+def pack_weights(trunk):
+    """fp32 trunk blob (C,13892) -> packed f16 operand image (C, cnr_pack_bytes()) uint8, on device."""
+    C = trunk.shape[0]
+    packed = torch.empty(C, _C.pack_bytes(), device=trunk.device, dtype=torch.uint8)
+    _C.call("cnr_pack_weights", trunk.contiguous(), packed, C)
+    return packed
+
+
+def field_fwd(pts, B, packed, biasrows, ray_row, scale):
+    """pts (C,R,S,3) -> sigmas (C,R,S), rgbs (C,R,S,3); biasrows (rows,4,32) flat over classes."""
+    C, R, S, _ = pts.shape
+    sig = torch.empty(C, R, S, device=pts.device, dtype=torch.float32)
+    rgb = torch.empty(C, R, S, 3, device=pts.device, dtype=torch.float32)
+    _C.call("cnr_field_fwd", pts.contiguous(), B.contiguous(), packed, biasrows.contiguous(), ray_row,
+            float(scale), sig, rgb, C, R, S)
+    return sig, rgb
+
+
+class FusedFieldFn(Function):
+    """pts (C,R,S,3), B (C,21,3), trunk (C,13892), biasrows (C*rows,4,32) -> sigmas (C,R,S), rgbs (C,R,S,3)
+    on the f16-MFMA kernels; backward = cnr_field_bwd (recompute).  ray_row (C,R) int32 or None,
+    rows_per_class = rows of biasrows per class, grad_scale = power-of-two loss scale for the f16 chain."""
+
+    @staticmethod
+    def forward(pts, B, trunk, biasrows, ray_row, scale, rows_per_class, grad_scale, max_blocks):
+        packed = pack_weights(trunk)
+        sig, rgb = field_fwd(pts, B, packed, biasrows, ray_row, scale)
+        return sig, rgb, packed
+
+    @staticmethod
+    def setup_context(ctx, inputs, output):
+        pts, B, trunk, biasrows, ray_row, scale, rows_per_class, grad_scale, max_blocks = inputs
+        ctx.save_for_backward(pts, B, biasrows, output[2])
+        ctx.ray_row, ctx.scale, ctx.rpc, ctx.gs, ctx.mb = ray_row, float(scale), int(rows_per_class), float(grad_scale), int(max_blocks)
+        ctx.trunk_shape = trunk.shape
+        ctx.mark_non_differentiable(output[2])
+
+    @staticmethod
+    def backward(ctx, d_sig, d_rgb, _):
+        pts, B, biasrows, packed = ctx.saved_tensors
+        C, R, S, _3 = pts.shape
+        dtrunk = torch.zeros(ctx.trunk_shape, device=pts.device, dtype=torch.float32)
+        dB = torch.zeros_like(B, memory_format=torch.contiguous_format)
+        dbr = torch.zeros_like(biasrows, memory_format=torch.contiguous_format)
+        _C.call("cnr_field_bwd", pts.contiguous(), B.contiguous(), packed, biasrows.contiguous(), ctx.ray_row,
+                ctx.scale, d_sig.contiguous(), d_rgb.contiguous(), ctx.gs, dtrunk, dB, dbr, C, R, S, ctx.rpc, ctx.mb)
+        return None, dB, dtrunk, dbr, None, None, None, None, None

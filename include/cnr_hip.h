@@ -124,6 +124,38 @@ int cnr_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_a
                    float lr, float beta1, float beta2, float eps, float weight_decay,
                    int64_t step_count, float grad_unscale, void* stream);
 
+/* ================= fused f16-MFMA field path (a8 + a9 in one launch) ================================
+ * Packed operand image per class, produced on device from the fp32 trunk blob: forward A fragments,
+ * fp32 constants, transposed (backward) A fragments -- layout contract in csrc/fused_common.h.
+ * The four latent layers and the code tables stay in PyTorch (per-object work);
+ * they reach the kernels as effective bias rows
+ *     biasrows[row][slot][32] = W_l . relu(latent_l(code[row])) + b_l ,
+ *     slot 0 shape_layer_1 | 1 cat_layer (first 32 columns) | 2 shape_layer_2 | 3 texture_layer_1
+ * (row = object, or ray when codes are per ray) because W (a + z) + b = W a + (W z + b).
+ * ray_row (C*R,) int32 maps a ray to its row (NULL: row = ray). */
+int64_t cnr_pack_bytes(void);
+int cnr_pack_weights(const float* trunk, void* packed, int C, void* stream);
+
+/* pts (C,R,S,3), B (C,21,3), packed (C,cnr_pack_bytes()), biasrows (rows,4,32) -> sigmas (C,R,S) = raw*10,
+ * rgbs (C,R,S,3).  f16 MFMA operands / fp32 accumulate, fp32 PE, fp32 sigma head.  Any S. */
+int cnr_field_fwd(const float* pts, const float* B, const void* packed, const float* biasrows,
+                  const int* ray_row, float scale, float* sigmas, float* rgbs, int C, int R, int S,
+                  void* stream);
+
+/* Backward of cnr_field_fwd (recomputes the forward per tile): d_sigma (C,R,S) = dL/dsigmas,
+ * d_rgb (C,R,S,3) -> dtrunk (C,13892), dB (C,21,3), dbiasrows (rows,4,32); all three ACCUMULATED
+ * (zero them first).  dtrunk receives no bias gradient for the four latent-conditioned layers: those
+ * biases reach the kernel only through biasrows, whose gradient the caller back-propagates (PyTorch).
+ * grad_scale: power-of-two loss scale applied to d_sigma / d_rgb on load and removed on store (the
+ * data-gradient chain runs on f16 MFMA operands); scaled d_sigma is clamped to +-8192.
+ * rows_per_class: rows of biasrows per class when rows are laid out class-major and ray_row != NULL
+ * (<= 32 enables the in-LDS row accumulation); pass R when ray_row == NULL.  S <= 240.
+ * max_blocks: workgroups per class (0 = 256); fewer, longer workgroups amortise the dW flush. */
+int cnr_field_bwd(const float* pts, const float* B, const void* packed, const float* biasrows,
+                  const int* ray_row, float scale, const float* d_sigma, const float* d_rgb,
+                  float grad_scale, float* dtrunk, float* dB, float* dbiasrows, int C, int R, int S,
+                  int rows_per_class, int max_blocks, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

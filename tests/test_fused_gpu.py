@@ -1,0 +1,249 @@
+"""GPU: fused f16-MFMA field path against the reference's golden vectors / the oracle.
+north_star bar: rendered RGB / depth / occupancy within 1e-3 relative L2 of the fp32 reference path."""
+import pytest
+import torch
+
+from conftest import Golden, golden_names, rel_l2
+from oracle import ref_cpu as O
+
+pytestmark = pytest.mark.gpu
+NORTH_STAR_TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def cnr(dev):
+    import cnr_amd
+    assert cnr_amd._C.device_info()["gfx950"]
+    return cnr_amd
+
+
+def trunk_blob(cnr, mlp):
+    parts = []
+    for n, _, _ in cnr.ops.TRUNK_LAYERS:
+        C = mlp[n + ".weight"].shape[0]
+        parts += [mlp[n + ".weight"].reshape(C, -1), mlp[n + ".bias"].reshape(C, -1)]
+    return torch.cat(parts, dim=1).contiguous()
+
+
+def latent_rows(cnr, mlp, shape_codes, texture_codes):
+    """code tables (C,n_obj,L) -> zlat (C,n_obj,4,32)"""
+    zl = []
+    for i, n in enumerate(cnr.ops.LATENT_LAYERS):
+        code = texture_codes if i == 3 else shape_codes
+        zl.append(torch.relu(torch.baddbmm(mlp[n + ".bias"][:, None, :], code, mlp[n + ".weight"].transpose(1, 2))))
+    return torch.stack(zl, dim=2)
+
+
+def fused_forward(cnr, g_or_inputs):
+    mlp, B, pts, shape, tex, idx, scale, n_obj = g_or_inputs
+    C, R, S, _ = pts.shape
+    trunk = trunk_blob(cnr, mlp)
+    packed = cnr.ops.pack_weights(trunk)
+    zlat = latent_rows(cnr, mlp, shape, tex)
+    brows = cnr.ops.bias_rows(trunk, zlat).reshape(C * n_obj, 4, 32)
+    ray_row = (idx + torch.arange(C, device=idx.device)[:, None] * n_obj).to(torch.int32).contiguous()
+    return cnr.ops.field_fwd(pts, B, packed, brows, ray_row, scale)
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_fused_forward_golden(cnr, dev, name):
+    g = Golden(name, dev)
+    sig, rgb = fused_forward(cnr, (g.mlp(), g.t("B"), g.t("pts"), g.t("shape_codes"), g.t("texture_codes"),
+                                   g.t("indices"), g.scale, g.n_obj))
+    # per-sample network outputs (looser: x10 logit), then the north-star quantities
+    assert rel_l2(sig, g.t("sigmas").squeeze(-1)) < 5e-3
+    assert rel_l2(rgb, g.t("rgbs")) < NORTH_STAR_TOL
+    occ = torch.sigmoid(sig)
+    assert rel_l2(occ, g.t("occ")) < NORTH_STAR_TOL
+    _, depth, var, rgbr, opa = cnr.ops.CompositeFn.apply(sig, rgb, g.t("z"))
+    assert rel_l2(depth, g.t("depth")) < NORTH_STAR_TOL
+    assert rel_l2(rgbr, g.t("rgb")) < NORTH_STAR_TOL
+    assert rel_l2(opa, g.t("opacity")) < NORTH_STAR_TOL
+
+
+@pytest.mark.parametrize("C,R,S,L,wscale", [(1, 2048, 64, 256, 1.0), (2, 4096, 128, 32, 1.0), (1, 8192, 128, 256, 1.0),
+                                            (1, 2048, 64, 256, 2.0)])
+def test_fused_forward_full_size(cnr, dev, C, R, S, L, wscale):
+    """BASELINE.json shapes (cfg2, cfg4, cfg5) + the 2x-weights stress of BASELINE.md §4."""
+    gen = torch.Generator().manual_seed(4321)
+    n_obj = 4
+    mlp = {k: v * (wscale if k.endswith("weight") else 1.0) for k, v in O.init_codenerf_params(C, 32, L, gen).items()}
+    B = torch.tensor(O.UNIDIRS).view(21, 3).repeat(C, 1, 1) + 0.01 * torch.randn(C, 21, 3, generator=gen)
+    pts = torch.rand(C, R, S, 3, generator=gen) * 2 - 1
+    z = torch.sort(torch.rand(C, R, S, generator=gen) * 3 + 0.5, dim=-1).values
+    shape = torch.randn(C, n_obj, L, generator=gen) / (L / 2) ** 0.5
+    tex = torch.randn(C, n_obj, L, generator=gen) / (L / 2) ** 0.5
+    idx = torch.randint(0, n_obj, (C, R), generator=gen)
+    cs = torch.stack([shape[c][idx[c]][:, None] for c in range(C)])
+    ct = torch.stack([tex[c][idx[c]][:, None] for c in range(C)])
+    e = O.unidirs_embed(pts, B, 2.0)
+    sig_ref, rgb_ref = O.codenerf_forward(mlp, e, cs, ct)
+    occ, term, depth, var, rgb, opa = O.composite(sig_ref.squeeze(-1), rgb_ref, z)
+    d = lambda t: t.to(dev)
+    sig, col = fused_forward(cnr, ({k: d(v) for k, v in mlp.items()}, d(B), d(pts), d(shape), d(tex), d(idx), 2.0, n_obj))
+    _, depth_, var_, rgb_, opa_ = cnr.ops.CompositeFn.apply(sig, col, d(z))
+    errs = dict(occ=rel_l2(torch.sigmoid(sig), occ), depth=rel_l2(depth_, depth), rgb=rel_l2(rgb_, rgb),
+                opacity=rel_l2(opa_, opa), rgbs=rel_l2(col, rgb_ref))
+    print(f"fused f16 parity C{C} R{R} S{S} L{L} w x{wscale}: " + " ".join(f"{k}={v:.2e}" for k, v in errs.items()))
+    for k, v in errs.items():
+        assert v < NORTH_STAR_TOL, (k, v)
+
+
+# ---- fused backward ----------------------------------------------------------------------------------
+def _fused_step(cnr, g, dev, grad_scale, max_blocks=0):
+    """Full train-step graph on the fused kernels: torch holds the flat trunk, latent layers and codes."""
+    mlp = g.mlp()
+    C, n_obj = g.C, g.n_obj
+    trunk = trunk_blob(cnr, mlp).requires_grad_()
+    lat = {n: (mlp[n + ".weight"].clone().requires_grad_(), mlp[n + ".bias"].clone().requires_grad_())
+           for n in cnr.ops.LATENT_LAYERS}
+    B = g.t("B").clone().requires_grad_()
+    shape = g.t("shape_codes").clone().requires_grad_()
+    tex = g.t("texture_codes").clone().requires_grad_()
+    zl = []
+    for i, n in enumerate(cnr.ops.LATENT_LAYERS):
+        code = tex if i == 3 else shape
+        zl.append(torch.relu(torch.baddbmm(lat[n][1][:, None, :], code, lat[n][0].transpose(1, 2))))
+    zlat = torch.stack(zl, dim=2)                                   # (C, n_obj, 4, 32)
+    brows = cnr.ops.bias_rows(trunk, zlat).reshape(C * n_obj, 4, 32)
+    ray_row = (g.t("indices") + torch.arange(C, device=dev)[:, None] * n_obj).to(torch.int32).contiguous()
+    sig, rgb, _ = cnr.ops.FusedFieldFn.apply(g.t("pts"), B, trunk, brows, ray_row, g.scale, n_obj, grad_scale, max_blocks)
+    _term, depth, var, rgbr, opa = cnr.ops.CompositeFn.apply(sig, rgb, g.t("z"))
+    losses, flags, _, _, _ = cnr.ops.RenderLossFn.apply(depth, var, rgbr, opa, g.t("gt_depth"), g.t("gt_rgb"),
+                                                        g.t("labels"), g.t("depth_mask").to(torch.uint8))
+    loss = (losses[0] + 5.0 * losses[1] + 10.0 * losses[2]).sum()
+    reg = sum(torch.norm(shape[c], dim=-1).sum() + torch.norm(tex[c], dim=-1).sum() for c in range(C)) if n_obj > 1 else 0.0
+    loss = loss + 0.0005 * reg
+    loss.backward()
+    return dict(loss=loss, trunk=trunk, lat=lat, B=B, shape=shape, tex=tex)
+
+
+def _ste_half(x):
+    """round to f16 in the forward, identity in the backward (what an f16 MFMA operand is)."""
+    return x + (x.half().float() - x).detach()
+
+
+def _emulated_f16_step(cnr, g, dev):
+    """The fused kernels' arithmetic restated with torch ops: fp32 PE -> f16 operands (weights, PE features,
+    post-ReLU activations) -> fp32 accumulate, fp32 sigma head, latent layers folded into bias rows.
+    Its autograd gradient is what an exact-arithmetic backward of the f16 forward would return; it shares
+    the kernel's ReLU masks, which the fp32 reference does not (see test_fused_backward_vs_fp32_reference)."""
+    q = _ste_half
+    mlp = g.mlp()
+    C, n_obj = g.C, g.n_obj
+    P = {k: v.clone().requires_grad_() for k, v in mlp.items()}
+    B = g.t("B").clone().requires_grad_()
+    shape = g.t("shape_codes").clone().requires_grad_()
+    tex = g.t("texture_codes").clone().requires_grad_()
+    idx = g.t("indices")
+    W = lambda n: P[n + ".weight"]
+    b = lambda n: P[n + ".bias"][:, None, None, :]
+    lin = lambda n, x: torch.matmul(x, q(W(n)).transpose(-1, -2)[:, None])
+    # differentiable PE (oracle formula, on device)
+    t = g.t("pts") / g.scale
+    proj = torch.matmul(t, B.transpose(-1, -2)[:, None])
+    bands = 2.0 ** torch.arange(6, device=dev, dtype=torch.float32)
+    xb = (proj[..., None, :] * bands[:, None]).reshape(*proj.shape[:-1], -1)
+    e = torch.cat([t, torch.sin(xb * torch.pi)], dim=-1)
+    e1, e2 = q(e[..., :87]), q(e[..., 87:])
+    zrow = {}
+    for i, n in enumerate(cnr.ops.LATENT_LAYERS):
+        code = tex if i == 3 else shape
+        zrow[i] = torch.relu(torch.baddbmm(P[n + ".bias"][:, None, :], code, P[n + ".weight"].transpose(1, 2)))
+    gather = lambda zr: torch.stack([zr[c][idx[c]] for c in range(C)])[:, :, None, :]   # (C,R,1,32)
+    fold = lambda n, zr, cols=None: torch.matmul(gather(zr), (W(n) if cols is None else W(n)[:, :, :cols]).transpose(-1, -2)[:, None])
+    a0 = q(torch.relu(lin("encoding_xyz.0", e1) + b("encoding_xyz.0")))
+    a1 = q(torch.relu(lin("shape_layer_1.0", a0) + fold("shape_layer_1.0", zrow[0]) + b("shape_layer_1.0")))
+    Wc = q(W("cat_layer.0"))
+    pre2 = torch.matmul(a1, Wc[:, :, :32].transpose(-1, -2)[:, None]) + torch.matmul(e1, Wc[:, :, 32:].transpose(-1, -2)[:, None]) \
+        + fold("cat_layer.0", zrow[1], 32) + b("cat_layer.0")
+    a2 = q(torch.relu(pre2))
+    a3 = q(torch.relu(lin("shape_layer_2.0", a2) + fold("shape_layer_2.0", zrow[2]) + b("shape_layer_2.0")))
+    y4 = lin("encoding_shape", a3) + b("encoding_shape")
+    sig = (torch.matmul(y4, W("sigma.0").transpose(-1, -2)[:, None]) + b("sigma.0")).squeeze(-1) * 10.0
+    Wv = q(W("encoding_viewdir.0"))
+    a5 = q(torch.relu(torch.matmul(q(y4), Wv[:, :, :32].transpose(-1, -2)[:, None])
+                      + torch.matmul(e2, Wv[:, :, 32:].transpose(-1, -2)[:, None]) + b("encoding_viewdir.0")))
+    a6 = q(torch.relu(lin("texture_layer_1.0", a5) + fold("texture_layer_1.0", zrow[3]) + b("texture_layer_1.0")))
+    a7 = q(torch.relu(lin("rgb.0", a6) + b("rgb.0")))
+    rgb = torch.sigmoid(lin("rgb.2", a7) + b("rgb.2"))
+    return P, B, shape, tex, sig, rgb
+
+
+def _torch_loss(sig, rgb, g):
+    """loss.py:18-74 with device tensors (plain torch; test-side restatement of the oracle's step_batch_loss)."""
+    mask_obj = g.t("labels") != 0
+    mask_sem = g.t("labels") != 2
+    md = g.t("depth_mask") & mask_obj
+    occ = torch.sigmoid(sig)
+    free = torch.cat([torch.ones_like(occ[..., :1]), (1.0 - occ + 1e-10)[..., :-1]], -1)
+    term = occ * torch.cumprod(free, -1)
+    z = g.t("z")
+    depth = (term * z).sum(-1)
+    var = (term * (z - depth[..., None]) ** 2).sum(-1).detach()
+    col = (term[..., None] * rgb).sum(-2)
+    opa = term.sum(-1)
+
+    def red(l, m, v=None):
+        if (m.sum(-1) == 0).any():
+            return torch.zeros(l.shape[0], device=l.device)
+        if v is not None:
+            l = l / (torch.sqrt(v) + 1e-4)
+        return l.sum(-1) / (m.sum(-1) + 1e-10)
+    ld = red((depth - g.t("gt_depth")).abs() * md, md, var)
+    lc = red((col - g.t("gt_rgb")).abs().sum(-1) * mask_obj, mask_obj)
+    lo = red((opa - mask_obj.float()).abs() * mask_sem, mask_sem)
+    return (ld + 5.0 * lc + 10.0 * lo).sum()
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_fused_backward_vs_emulated_f16(cnr, dev, name):
+    """Kernel gradients == autograd of the torch emulation of the same f16 pipeline (same ReLU masks):
+    5e-3 relative L2 per tensor; what is left is the f16 rounding of dPre in the chain / dW operands."""
+    g = Golden(name, dev)
+    out = _fused_step(cnr, g, dev, grad_scale=float(2 ** 10))
+    P, B, shape, tex, sig, rgb = _emulated_f16_step(cnr, g, dev)
+    loss = _torch_loss(sig, rgb, g)
+    if g.n_obj > 1:
+        loss = loss + 0.0005 * sum(torch.norm(shape[c], dim=-1).sum() + torch.norm(tex[c], dim=-1).sum() for c in range(g.C))
+    loss.backward()
+    assert rel_l2(out["loss"], loss) < 1e-4
+    TOL = 5e-3
+    off = 0
+    latent_biased = {"shape_layer_1.0", "cat_layer.0", "shape_layer_2.0", "texture_layer_1.0"}
+    for n, o, i in cnr.ops.TRUNK_LAYERS:
+        for kind, cnt, shp in (("weight", o * i, (g.C, o, i)), ("bias", o, (g.C, o))):
+            got = out["trunk"].grad[:, off:off + cnt].reshape(shp)
+            ref = P[n + "." + kind].grad
+            assert rel_l2(got, ref) < TOL, (n, kind, rel_l2(got, ref))
+            off += cnt
+    for n in cnr.ops.LATENT_LAYERS:
+        assert rel_l2(out["lat"][n][0].grad, P[n + ".weight"].grad) < TOL, n
+        assert rel_l2(out["lat"][n][1].grad, P[n + ".bias"].grad) < TOL, n
+    assert rel_l2(out["B"].grad, B.grad) < TOL
+    assert rel_l2(out["shape"].grad, shape.grad) < TOL
+    assert rel_l2(out["tex"].grad, tex.grad) < TOL
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_fused_backward_vs_fp32_reference(cnr, dev, name):
+    """Against the reference's fp32 autograd gradients.  The f16 forward (1e-3) flips the ReLU mask of the
+    ~0.1 % of units whose pre-activation is within 1e-3 of zero; each flip toggles a whole contribution, so the
+    gradient differs by ~sqrt(1e-3) = 3 % in relative L2 while pointing the same way.  Bars: 0.15 relative L2
+    per tensor, cosine similarity of the full trunk gradient > 0.995, loss within 2e-3."""
+    g = Golden(name, dev)
+    out = _fused_step(cnr, g, dev, grad_scale=float(2 ** 10))
+    assert rel_l2(out["loss"], g.t("loss")) < 2e-3
+    mlp_ref = {k[5:]: g.t(k) for k in g.z.files if k.startswith("grad.")}
+    off, dot, n1, n2 = 0, 0.0, 0.0, 0.0
+    for n, o, i in cnr.ops.TRUNK_LAYERS:
+        for kind, cnt, shp in (("weight", o * i, (g.C, o, i)), ("bias", o, (g.C, o))):
+            got = out["trunk"].grad[:, off:off + cnt].reshape(shp).double()
+            ref = mlp_ref[n + "." + kind].double()
+            assert rel_l2(got, ref) < 0.15, (n, kind, rel_l2(got, ref))
+            dot += float((got * ref).sum()); n1 += float(got.pow(2).sum()); n2 += float(ref.pow(2).sum())
+            off += cnt
+    assert dot / (n1 * n2) ** 0.5 > 0.995
+    assert rel_l2(out["B"].grad, g.t("grad_B")) < 0.15
+    assert rel_l2(out["shape"].grad, g.t("grad_shape_codes")) < 0.15
+    assert rel_l2(out["tex"].grad, g.t("grad_texture_codes")) < 0.15
