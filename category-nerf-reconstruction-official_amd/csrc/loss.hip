@@ -81,7 +81,13 @@ __global__ __launch_bounds__(256) void loss_kernel(
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v, int64_t n,
                                                     float lr, float b1, float b2, float eps, float wd,
-                                                    float step_size, float inv_bc2_sqrt, float gunscale) {
+                                                    float step_size, float inv_bc2_sqrt, float gunscale,
+                                                    const int64_t* __restrict__ d_state) {
+  if (d_state) {  // step number lives on the device (hipGraph replay): bias corrections computed here
+    const double t = (double)(d_state[2] + 1);
+    step_size = (float)((double)lr / (1.0 - pow((double)b1, t)));
+    inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow((double)b2, t)));
+  }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float gi = g[i] * gunscale;
     float pi = p[i] * (1.0f - lr * wd);
@@ -111,8 +117,9 @@ extern "C" int cnr_loss_fwd_bwd(const float* depth, const float* var, const floa
 
 extern "C" int cnr_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                               float lr, float beta1, float beta2, float eps, float weight_decay,
-                              int64_t step_count, float grad_unscale, void* stream) {
-  if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || step_count <= 0) return CNR_E_ARG;
+                              int64_t step_count, float grad_unscale, const int64_t* d_state, void* stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || (step_count <= 0 && !d_state)) return CNR_E_ARG;
+  if (step_count <= 0) step_count = 1;
   const double bc1 = 1.0 - pow((double)beta1, (double)step_count);
   const double bc2 = 1.0 - pow((double)beta2, (double)step_count);
   const float step_size = (float)((double)lr / bc1);
@@ -121,7 +128,7 @@ extern "C" int cnr_adamw_step(float* param, const float* grad, float* exp_avg, f
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad,
                      exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step_size, inv_bc2_sqrt,
-                     grad_unscale);
+                     grad_unscale, d_state);
   CNR_LAUNCH_CHECK();
   return CNR_OK;
 }

@@ -33,10 +33,12 @@ __device__ __forceinline__ float linspace01(int i, int n) {
   return (i < steps / 2) ? step * (float)i : 1.0f - step * (float)(steps - i - 1);
 }
 
-__global__ void maxdepth_kernel(const float* __restrict__ depth, float* __restrict__ max_bound, int R) {
+__global__ void maxdepth_kernel(const float* __restrict__ depth, float* __restrict__ max_bound, int R,
+                                const int64_t* __restrict__ d_state, int64_t pool_rows) {
   const int c = blockIdx.x;
   float m = -INFINITY;
-  for (int r = threadIdx.x; r < R; r += blockDim.x) m = fmaxf(m, depth[(size_t)c * R + r]);
+  const int64_t base = pool_rows > 0 ? (int64_t)c * pool_rows + d_state[0] : (int64_t)c * R;
+  for (int r = threadIdx.x; r < R; r += blockDim.x) m = fmaxf(m, depth[base + r]);
   __shared__ float sm[16];
   m = cnr::wave_max(m);
   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
@@ -74,23 +76,31 @@ __device__ __forceinline__ void bitonic128(float& v0, float& v1, int lane) {
 __global__ __launch_bounds__(256) void sample_kernel(
     const uint8_t* __restrict__ rgbs, const float* __restrict__ depth, const float* __restrict__ dirs_c,
     const float* __restrict__ T, const float* __restrict__ u, const float* __restrict__ g,
-    uint64_t seed, uint64_t offset, const float* __restrict__ max_bound, int world_frame,
+    uint64_t seed, uint64_t offset, const int64_t* __restrict__ d_state, int64_t pool_rows,
+    const float* __restrict__ max_bound, int world_frame,
     int C, int R, int n1, int n2, float eps, float stop_eps, float min_bound,
     float* __restrict__ z, float* __restrict__ pts, float* __restrict__ origins,
-    float* __restrict__ dirs_o, float* __restrict__ gt_rgb, uint8_t* __restrict__ depth_mask,
-    uint8_t* __restrict__ labels) {
+    float* __restrict__ dirs_o, float* __restrict__ gt_rgb, float* __restrict__ gt_depth,
+    uint8_t* __restrict__ depth_mask, uint8_t* __restrict__ labels) {
   const int lane = threadIdx.x & 63;
   const int64_t ray = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (ray >= (int64_t)C * R) return;
   const int c = (int)(ray / R);
   const int S = n1 + n2;
+  // pool row of this ray: either the slice itself (pool_rows == 0) or row cursor + r of a device-resident
+  // (C, pool_rows, ...) pool whose cursor lives on the device (hipGraph replay advances it, no host work)
+  int64_t prow = ray;
+  if (pool_rows > 0) {
+    prow = (int64_t)c * pool_rows + d_state[0] + (ray - (int64_t)c * R);
+    offset += (uint64_t)d_state[1] * 4;
+  }
 
   // ---- a2: origin / direction in object (or world) frame -----------------------------------
-  const float* Tm = T + ray * 16;
+  const float* Tm = T + prow * 16;
   float m00 = Tm[0], m01 = Tm[1], m02 = Tm[2], t0 = Tm[3];
   float m10 = Tm[4], m11 = Tm[5], m12 = Tm[6], t1 = Tm[7];
   float m20 = Tm[8], m21 = Tm[9], m22 = Tm[10], t2 = Tm[11];
-  const float dx = dirs_c[ray * 3 + 0], dy = dirs_c[ray * 3 + 1], dz = dirs_c[ray * 3 + 2];
+  const float dx = dirs_c[prow * 3 + 0], dy = dirs_c[prow * 3 + 1], dz = dirs_c[prow * 3 + 2];
   float ox, oy, oz, ex, ey, ez;
   if (world_frame) {
     ox = t0; oy = t1; oz = t2;
@@ -115,8 +125,8 @@ __global__ __launch_bounds__(256) void sample_kernel(
     ez = i20 * dx + i21 * dy + i22 * dz;
   }
 
-  const float d = depth[ray];
-  const uint8_t state = rgbs[ray * 4 + 3];
+  const float d = depth[prow];
+  const uint8_t state = rgbs[prow * 4 + 3];
   const bool invalid = d <= min_bound;
   const bool this_obj = (state == 1) && !invalid;
   if (lane == 0) {
@@ -125,7 +135,8 @@ __global__ __launch_bounds__(256) void sample_kernel(
     depth_mask[ray] = invalid ? 0 : 1;
     labels[ray] = state;
   }
-  if (lane < 3) gt_rgb[ray * 3 + lane] = (float)rgbs[ray * 4 + lane] / 255.0f;
+  if (lane < 3) gt_rgb[ray * 3 + lane] = (float)rgbs[prow * 4 + lane] / 255.0f;
+  if (lane == 3 && gt_depth) gt_depth[ray] = d;
 
   // ---- a4: sorted, clipped Gaussian offsets for "this object" rays --------------------------
   float g0 = INFINITY, g1 = INFINITY;  // elements lane and lane+64 of the ray's n2 draws
@@ -185,33 +196,49 @@ __global__ __launch_bounds__(256) void sample_kernel(
     }
   }
 }
+__global__ void advance_kernel(int64_t* state, int64_t add_rows) {
+  if (threadIdx.x == 0) { state[0] += add_rows; state[1] += 1; state[2] += 1; }
+}
 }  // namespace
 
-extern "C" int cnr_sample_maxdepth(const float* depth, float* max_bound, int C, int R, void* stream) {
-  if (!depth || !max_bound || C <= 0 || R <= 0) return CNR_E_ARG;
-  hipLaunchKernelGGL(maxdepth_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, depth, max_bound, R);
+// device-side step state {pool cursor (rows), rng step, optimiser step}: advanced by a 1-thread kernel so that a
+// captured hipGraph of the whole train step replays with no host-side argument patching
+extern "C" int cnr_step_advance(int64_t* d_state, int64_t add_rows, void* stream) {
+  if (!d_state) return CNR_E_ARG;
+  hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_state, add_rows);
+  CNR_LAUNCH_CHECK();
+  return CNR_OK;
+}
+
+extern "C" int cnr_sample_maxdepth(const float* depth, float* max_bound, const int64_t* d_state,
+                                   int64_t pool_rows, int C, int R, void* stream) {
+  if (!depth || !max_bound || C <= 0 || R <= 0 || pool_rows < 0 || (pool_rows > 0 && !d_state)) return CNR_E_ARG;
+  hipLaunchKernelGGL(maxdepth_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, depth, max_bound, R, d_state,
+                     pool_rows);
   CNR_LAUNCH_CHECK();
   return CNR_OK;
 }
 
 extern "C" int cnr_sample_rays(const uint8_t* rgbs, const float* depth, const float* dirs_c, const float* T,
                                const float* u, const float* g, uint64_t seed, uint64_t offset,
+                               const int64_t* d_state, int64_t pool_rows,
                                const float* max_bound, int world_frame, int C, int R, int n1, int n2,
                                float eps, float stop_eps, float min_bound, float* z, float* pts,
-                               float* origins, float* dirs_o, float* gt_rgb, uint8_t* depth_mask,
-                               uint8_t* labels, void* stream) {
+                               float* origins, float* dirs_o, float* gt_rgb, float* gt_depth,
+                               uint8_t* depth_mask, uint8_t* labels, void* stream) {
   if (!rgbs || !depth || !dirs_c || !T || !max_bound || !z || !pts || !gt_rgb || !depth_mask || !labels)
     return CNR_E_ARG;
   if (C <= 0 || R <= 0 || n1 < 0 || n2 <= 0) return CNR_E_ARG;
   if (n2 > 128) return CNR_E_SHAPE;
   if ((u == nullptr) != (g == nullptr)) return CNR_E_ARG;
+  if (pool_rows < 0 || (pool_rows > 0 && (!d_state || pool_rows < R))) return CNR_E_ARG;
   const int64_t rays = (int64_t)C * R;
   const int waves_per_block = 4;
   const int64_t blocks = (rays + waves_per_block - 1) / waves_per_block;
   hipLaunchKernelGGL(sample_kernel, dim3((unsigned)blocks), dim3(64 * waves_per_block), 0,
-                     (hipStream_t)stream, rgbs, depth, dirs_c, T, u, g, seed, offset, max_bound,
-                     world_frame, C, R, n1, n2, eps, stop_eps, min_bound, z, pts, origins, dirs_o,
-                     gt_rgb, depth_mask, labels);
+                     (hipStream_t)stream, rgbs, depth, dirs_c, T, u, g, seed, offset, d_state, pool_rows,
+                     max_bound, world_frame, C, R, n1, n2, eps, stop_eps, min_bound, z, pts, origins, dirs_o,
+                     gt_rgb, gt_depth, depth_mask, labels);
   CNR_LAUNCH_CHECK();
   return CNR_OK;
 }

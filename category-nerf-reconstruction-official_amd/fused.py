@@ -1,0 +1,216 @@
+"""Single-process fast path of the train step (train.py:98-201, object branch): every hot op is one of
+the HIP kernels, all parameters of all classes live in ONE flat fp32 buffer (one AdamW launch, one
+gradient all-reduce), the ray pool is device-resident, and the whole step -- sample -> latent rows ->
+fused field forward -> composite -> loss -> composite backward -> fused field backward -> latent backward ->
+AdamW -> advance -- is captured once into a hipGraph and replayed (its cursor, RNG and optimiser step
+counters live on the device, cnr_step_advance).
+
+Per class the flat parameter row is
+    [ trunk 13892 | latent W (4,32,L) | latent b (4,32) | B (21,3) | shape codes (n_obj,L) | texture codes (n_obj,L) ]
+with the latent slots ordered shape_latent_layer_1, cat_latent_layer, shape_latent_layer_2,
+texture_latent_layer_1 (include/cnr_hip.h).  ``state_dicts()`` exports reference-named tensors
+(src/scene_cateogries.py:548-571 checkpoint keys).
+"""
+import math
+
+import torch
+
+from . import _C, ops
+from .embedding import UNIDIRS
+from .ops import LATENT_LAYERS, TRUNK_LAYERS, TRUNK_PARAMS
+
+_LAT_FANIN_TARGET = ops._LATENT_TARGETS  # (w_off, b_off, ld) of the trunk layer each latent slot feeds
+
+
+class ParamLayout:
+    def __init__(self, L, n_obj):
+        self.L, self.n_obj = L, n_obj
+        o = 0
+        self.trunk = (o, o + TRUNK_PARAMS); o += TRUNK_PARAMS
+        self.latW = (o, o + 4 * 32 * L); o += 4 * 32 * L
+        self.latb = (o, o + 4 * 32); o += 4 * 32
+        self.B = (o, o + 63); o += 63
+        self.shape = (o, o + n_obj * L); o += n_obj * L
+        self.tex = (o, o + n_obj * L); o += n_obj * L
+        self.total = o
+
+    def views(self, flat):
+        """flat (C, total) -> dict of views (no copies)."""
+        C = flat.shape[0]
+        s = lambda r: flat[:, r[0]:r[1]]
+        return dict(trunk=s(self.trunk), latW=s(self.latW).view(C, 4, 32, self.L), latb=s(self.latb).view(C, 4, 32),
+                    B=s(self.B).view(C, 21, 3), shape=s(self.shape).view(C, self.n_obj, self.L),
+                    tex=s(self.tex).view(C, self.n_obj, self.L))
+
+
+def init_params(C, L, n_obj, generator=None, device="cpu"):
+    """Reference initialisation: xavier-normal weights + nn.Linear default biases (src/model.py:4-6,
+    src/trainer.py:40), codes randn/sqrt(L/2) (src/trainer.py:57-58), B = icosahedral directions."""
+    lay = ParamLayout(L, n_obj)
+    flat = torch.zeros(C, lay.total)
+    v = lay.views(flat)
+    g = generator
+
+    def linear(out_f, in_f):
+        w = torch.randn(C, out_f, in_f, generator=g) * math.sqrt(2.0 / (in_f + out_f))
+        b = (torch.rand(C, out_f, generator=g) * 2 - 1) / math.sqrt(in_f)
+        return w, b
+    off = 0
+    for _, o, i in TRUNK_LAYERS:
+        w, b = linear(o, i)
+        v["trunk"][:, off:off + o * i] = w.reshape(C, -1); off += o * i
+        v["trunk"][:, off:off + o] = b; off += o
+    for k in range(4):
+        w, b = linear(32, L)
+        v["latW"][:, k] = w
+        v["latb"][:, k] = b
+    v["B"][:] = torch.tensor(UNIDIRS, dtype=torch.float32)
+    v["shape"][:] = torch.randn(C, n_obj, L, generator=g) / math.sqrt(L / 2)
+    v["tex"][:] = torch.randn(C, n_obj, L, generator=g) / math.sqrt(L / 2)
+    return flat.to(device), lay
+
+
+class FusedCategoryTrainer:
+    """C classes x n_obj objects, R rays per class per step, S = n1 + n2 samples per ray."""
+
+    def __init__(self, cfg, n_cls, n_obj, pools, rays_per_step, device, seed=0, generator=None,
+                 grad_scale=None, bwd_blocks=0, process_group=None, use_graph=True):
+        self.cfg, self.C, self.n_obj, self.R = cfg, n_cls, n_obj, rays_per_step
+        self.device = torch.device(device)
+        self.n1, self.n2 = cfg.n_bins_cam2surface, cfg.n_bins
+        self.S = self.n1 + self.n2
+        self.L = cfg.net_hyperparams["latent_dim"]
+        self.scale = float(cfg.obj_scale)
+        self.lr, self.wd = cfg.learning_rate, cfg.weight_decay
+        assert cfg.code_learning_rate == cfg.learning_rate and cfg.code_weight_decay == cfg.weight_decay, \\
+            "one flat AdamW group: the shipped configs use identical lr / weight decay for codes and networks"
+        self.theta, self.lay = init_params(n_cls, self.L, n_obj, generator, self.device)
+        self.grad = torch.zeros_like(self.theta)
+        self.exp_avg = torch.zeros_like(self.theta)
+        self.exp_avg_sq = torch.zeros_like(self.theta)
+        self.pg = process_group
+        self.world = 1 if process_group is None else torch.distributed.get_world_size(process_group)
+        # device-resident pools stacked over classes: (C, Npool, ...)
+        st = lambda k: torch.stack([p[k] for p in pools]).to(self.device).contiguous()
+        self.pool = dict(rgbs=st("rgbs"), depth=st("depth"), dirs=st("dirs"), T=st("T_co"), indices=st("indices"))
+        self.pool_rows = self.pool["depth"].shape[1]
+        assert self.pool_rows >= 2 * self.R
+        self.d_state = torch.zeros(3, device=self.device, dtype=torch.int64)   # cursor, rng step, opt step
+        self.cursor = 0
+        self.seed = int(seed) + 1
+        self.grad_scale = float(grad_scale) if grad_scale else float(2 ** round(math.log2(max(self.R, 2))))
+        self.bwd_blocks = int(bwd_blocks)
+        self.bufs = {}
+        self.losses = torch.zeros(3, n_cls, device=self.device)
+        self.flags = torch.zeros(n_cls, device=self.device, dtype=torch.int32)
+        self.dbias = torch.zeros(n_cls * n_obj, 4, 32, device=self.device)
+        self.use_graph = use_graph
+        self.graph = None
+        self.steps_done = 0
+        self._row_base = (torch.arange(n_cls, device=self.device, dtype=torch.int64) * n_obj)[:, None]
+
+    # ---- one step, eager (also the body that gets captured) ------------------------------------------
+    def _step_body(self):
+        C, R, S, n_obj, L = self.C, self.R, self.S, self.n_obj, self.L
+        cfg, v = self.cfg, self.lay.views(self.theta)
+        gv = self.lay.views(self.grad)
+        self.grad.zero_()
+        self.dbias.zero_()
+        # a2-a6: slice the device pool at the device cursor, transform, sample
+        b = ops.sample_rays(self.pool["rgbs"], self.pool["depth"], self.pool["dirs"], self.pool["T"], self.n1,
+                            self.n2, cfg.surface_eps, cfg.stop_eps, min_bound=cfg.min_depth, world_frame=False,
+                            seed=self.seed, d_state=self.d_state, rays=R, out=self.bufs)
+        cur = self.d_state[0]
+        # object row of every ray: pool indices at [cursor, cursor + R) -- gathered on the device
+        ar = self.bufs.setdefault("_arange", torch.arange(R, device=self.device))
+        ray_row = (torch.gather(self.pool["indices"], 1, (ar + cur).expand(C, R)) + self._row_base).to(torch.int32)
+        # a7 + latent layers (per-object work, plain batched GEMMs): zlat = relu(code Wl^T + bl); bias rows
+        codes4 = torch.stack([v["shape"], v["shape"], v["shape"], v["tex"]], dim=1).reshape(C * 4, n_obj, L)
+        Wl4 = v["latW"].reshape(C * 4, 32, L)
+        pre = torch.baddbmm(v["latb"].reshape(C * 4, 1, 32), codes4, Wl4.transpose(1, 2))      # (C*4,n_obj,32)
+        zl = torch.relu(pre)
+        Wt4 = torch.stack([v["trunk"][:, wo:wo + 32 * ld].reshape(C, 32, ld)[:, :, :32] for wo, _, ld in _LAT_FANIN_TARGET],
+                          dim=1).reshape(C * 4, 32, 32)
+        bt4 = torch.stack([v["trunk"][:, bo:bo + 32] for _, bo, _ in _LAT_FANIN_TARGET], dim=1).reshape(C * 4, 1, 32)
+        brows = torch.baddbmm(bt4, zl, Wt4.transpose(1, 2)).reshape(C, 4, n_obj, 32).transpose(1, 2).contiguous()
+        brows = brows.reshape(C * n_obj, 4, 32)
+        # a8 + a9 fused forward, a11-a13 composite, a14-a15 loss (+ its gradient), composite backward
+        packed = ops.pack_weights(v["trunk"])
+        sig, rgb = ops.field_fwd(b["pts"], v["B"], packed, brows, ray_row, self.scale)
+        kw = dict(device=self.device, dtype=torch.float32)
+        o = self.bufs
+        for name, shape in (("depth", (C, R)), ("var", (C, R)), ("rgb", (C, R, 3)), ("opa", (C, R)),
+                            ("dd", (C, R)), ("dr", (C, R, 3)), ("do", (C, R)), ("dsig", (C, R, S)),
+                            ("drgb", (C, R, S, 3))):
+            if name not in o:
+                o[name] = torch.empty(*shape, **kw)
+        _C.call("cnr_composite_fwd", sig, rgb, b["z"], None, o["depth"], o["var"], o["rgb"], o["opa"], C * R, S, 0)
+        inv_w = 1.0 / self.world
+        _C.call("cnr_loss_fwd_bwd", o["depth"], o["var"], o["rgb"], o["opa"], b["gt_depth"], b["gt_rgb"], b["labels"],
+                b["depth_mask"], 5.0, 10.0, inv_w, self.losses, self.flags, o["dd"], o["dr"], o["do"], C, R)
+        _C.call("cnr_composite_bwd", sig, rgb, b["z"], o["dd"], o["dr"], o["do"], None, o["dsig"], o["drgb"], C * R, S, 0)
+        # fused backward: dtrunk, dB, dbiasrows straight into the flat gradient buffer views
+        dtrunk = torch.zeros(C, TRUNK_PARAMS, **kw)
+        dB = torch.zeros(C, 21, 3, **kw)
+        _C.call("cnr_field_bwd", b["pts"], v["B"], packed, brows, ray_row, self.scale, o["dsig"], o["drgb"],
+                self.grad_scale, dtrunk, dB, self.dbias, C, R, S, n_obj, self.bwd_blocks)
+        gv["trunk"].copy_(dtrunk)
+        gv["B"].copy_(dB)
+        # latent backward (hand-written chain of the tiny batched GEMMs above)
+        dbr = self.dbias.reshape(C, n_obj, 4, 32).transpose(1, 2).reshape(C * 4, n_obj, 32)
+        dbt4 = dbr.sum(dim=1).reshape(C, 4, 32)
+        dWt4 = torch.bmm(dbr.transpose(1, 2), zl).reshape(C, 4, 32, 32)
+        for k, (wo, bo, ld) in enumerate(_LAT_FANIN_TARGET):
+            gv["trunk"][:, wo:wo + 32 * ld].view(C, 32, ld)[:, :, :32].add_(dWt4[:, k])
+            gv["trunk"][:, bo:bo + 32].add_(dbt4[:, k])
+        dpre = torch.bmm(dbr, Wt4) * (pre > 0)
+        gv["latW"].copy_(torch.bmm(dpre.transpose(1, 2), codes4).reshape(C, 4, 32, L))
+        gv["latb"].copy_(dpre.sum(dim=1).reshape(C, 4, 32))
+        dcodes = torch.bmm(dpre, Wl4).reshape(C, 4, n_obj, L)
+        reg = 0.0005 * inv_w if n_obj > 1 else 0.0     # loss.py:5-15, train.py:165-167
+        gv["shape"].copy_(dcodes[:, :3].sum(dim=1) + reg * v["shape"] / v["shape"].norm(dim=-1, keepdim=True))
+        gv["tex"].copy_(dcodes[:, 3] + reg * v["tex"] / v["tex"].norm(dim=-1, keepdim=True))
+        if self.pg is not None:
+            torch.distributed.all_reduce(self.grad, group=self.pg)   # one flat buffer, one collective
+        ops.adamw_step(self.theta, self.grad, self.exp_avg, self.exp_avg_sq, self.lr, (0.9, 0.999), 1e-8, self.wd,
+                       0, d_state=self.d_state)
+        ops.step_advance(self.d_state, R)
+
+    def step(self):
+        """One train step.  Returns nothing; ``self.losses`` (3,C) / ``self.flags`` (C,) hold the device-side
+        loss terms (depth, colour, opacity) and flags of the step just run."""
+        if self.cursor + 2 * self.R > self.pool_rows:   # epoch end: reshuffle (scene_cateogries.py:439-449)
+            self._reshuffle()
+        if not self.use_graph or self.pg is not None:
+            self._step_body()
+        elif self.graph is None and self.steps_done >= 2:
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self._step_body()
+        elif self.graph is None:
+            self._step_body()
+        else:
+            self.graph.replay()
+        self.cursor += self.R
+        self.steps_done += 1
+
+    def _reshuffle(self):
+        perm = torch.randperm(self.pool_rows, device=self.device)
+        for k in self.pool:
+            self.pool[k].copy_(self.pool[k][:, perm])
+        self.cursor = 0
+        self.d_state[0] = 0
+
+    # ---- reference-named export ------------------------------------------------------------------------
+    def state_dicts(self, c=0):
+        v = self.lay.views(self.theta)
+        fc, off = {}, 0
+        for n, o, i in TRUNK_LAYERS:
+            fc[n + ".weight"] = v["trunk"][c, off:off + o * i].reshape(o, i).clone(); off += o * i
+            fc[n + ".bias"] = v["trunk"][c, off:off + o].clone(); off += o
+        for k, n in enumerate(LATENT_LAYERS):
+            fc[n + ".weight"] = v["latW"][c, k].clone()
+            fc[n + ".bias"] = v["latb"][c, k].clone()
+        return dict(FC_state_dict=fc, PE_state_dict={"B_layer.weight": v["B"][c].clone(), "scale": torch.tensor(self.scale)},
+                    shape_code_state_dict={"weight": v["shape"][c].clone()},
+                    texture_code_state_dict={"weight": v["tex"][c].clone()}, obj_scale=self.scale)

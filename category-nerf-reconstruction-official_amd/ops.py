@@ -230,34 +230,44 @@ class RenderLossFn(Function):
 # a2-a5  sampling (no gradient: poses are not optimised)
 # ------------------------------------------------------------------------------------------------
 def sample_rays(rgbs, depth, dirs_c, T, n1, n2, eps, stop_eps, min_bound=0.0, world_frame=False,
-                u=None, g=None, seed=0, offset=0, want_rays=False):
-    """Class-batched pool slice (C,R,...) -> dict(z, pts, gt_rgb, depth_mask, labels[, origins, dirs_o]).
-    u/g given -> parity mode (identical draws); else in-kernel Philox(seed, offset)."""
-    C, R = depth.shape
+                u=None, g=None, seed=0, offset=0, want_rays=False, d_state=None, rays=None, out=None):
+    """Class-batched pool slice (C,R,...) -> dict(z, pts, gt_rgb, gt_depth, depth_mask, labels[, origins, dirs_o]).
+    u/g given -> parity mode (identical draws); else in-kernel Philox(seed, offset).
+    d_state (int64[3] device) + rays=R: the inputs are whole (C,pool_rows,...) pools and the slice starts at
+    the device-side cursor d_state[0] (see cnr_step_advance).  out: dict of preallocated outputs to reuse."""
+    C = depth.shape[0]
+    pool_rows = 0 if d_state is None else depth.shape[1]
+    R = depth.shape[1] if d_state is None else int(rays)
     S = n1 + n2
     dev = depth.device
     kw = dict(device=dev, dtype=torch.float32)
-    mb = torch.empty(C, **kw)
-    _C.call("cnr_sample_maxdepth", depth.contiguous(), mb, C, R)
-    z, pts = torch.empty(C, R, S, **kw), torch.empty(C, R, S, 3, **kw)
-    gt = torch.empty(C, R, 3, **kw)
-    dm = torch.empty(C, R, device=dev, dtype=torch.uint8)
-    lab = torch.empty(C, R, device=dev, dtype=torch.uint8)
-    org = torch.empty(C, R, 3, **kw) if want_rays else None
-    dro = torch.empty(C, R, 3, **kw) if want_rays else None
+    o = out if out is not None else {}
+    def buf(name, shape, dtype=torch.float32):
+        if name not in o:
+            o[name] = torch.empty(*shape, device=dev, dtype=dtype)
+        return o[name]
+    mb = buf("max_bound", (C,))
+    _C.call("cnr_sample_maxdepth", depth, mb, d_state, pool_rows, C, R)
+    z, pts = buf("z", (C, R, S)), buf("pts", (C, R, S, 3))
+    gt, gd = buf("gt_rgb", (C, R, 3)), buf("gt_depth", (C, R))
+    dm, lab = buf("depth_mask", (C, R), torch.uint8), buf("labels", (C, R), torch.uint8)
+    org = buf("origins", (C, R, 3)) if want_rays else None
+    dro = buf("dirs_o", (C, R, 3)) if want_rays else None
     cont = lambda t: None if t is None else t.contiguous()
     _C.call("cnr_sample_rays", rgbs.contiguous(), depth.contiguous(), dirs_c.contiguous(), T.contiguous(),
-            cont(u), cont(g), int(seed), int(offset), mb, int(bool(world_frame)), C, R, n1, n2,
-            float(eps), float(stop_eps), float(min_bound), z, pts, org, dro, gt, dm, lab)
-    out = dict(z=z, pts=pts, gt_rgb=gt, depth_mask=dm, labels=lab, gt_depth=depth)
-    if want_rays:
-        out.update(origins=org, dirs_o=dro)
-    return out
+            cont(u), cont(g), int(seed), int(offset), d_state, pool_rows, mb, int(bool(world_frame)), C, R, n1, n2,
+            float(eps), float(stop_eps), float(min_bound), z, pts, org, dro, gt, gd, dm, lab)
+    return o
 
 
-def adamw_step(param, grad, exp_avg, exp_avg_sq, lr, betas, eps, weight_decay, step, grad_unscale=1.0):
+def adamw_step(param, grad, exp_avg, exp_avg_sq, lr, betas, eps, weight_decay, step, grad_unscale=1.0,
+               d_state=None):
     _C.call("cnr_adamw_step", param, grad, exp_avg, exp_avg_sq, param.numel(), float(lr), float(betas[0]),
-            float(betas[1]), float(eps), float(weight_decay), int(step), float(grad_unscale))
+            float(betas[1]), float(eps), float(weight_decay), int(step), float(grad_unscale), d_state)
+
+
+def step_advance(d_state, add_rows):
+    _C.call("cnr_step_advance", d_state, int(add_rows))
 
 
 # ================================================================================================

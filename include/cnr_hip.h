@@ -60,14 +60,22 @@ int cnr_device_info(int* n_cu, int* lds_bytes, int* gcn_arch_is_gfx950);
  *   max_bound (C,) : per-class max(depth) over the slice (reference :486); computed by
  *         cnr_sample_maxdepth below so that no host sync is needed.
  * Outputs: z (C,R,S) with S = n1+n2, pts (C,R,S,3), origins (C,R,3) and dirs_o (C,R,3) (may be NULL),
- *   gt_rgb (C,R,3) f32 already /255 (train.py:144), depth_mask (C,R) u8, labels (C,R) u8. */
-int cnr_sample_maxdepth(const float* depth, float* max_bound, int C, int R, void* stream);
+ *   gt_rgb (C,R,3) f32 already /255 (train.py:144), gt_depth (C,R) copy of the slice's depth (may be
+ *   NULL), depth_mask (C,R) u8, labels (C,R) u8. */
+int cnr_sample_maxdepth(const float* depth, float* max_bound, const int64_t* d_state, int64_t pool_rows,
+                        int C, int R, void* stream);
 int cnr_sample_rays(const uint8_t* rgbs, const float* depth, const float* dirs_c, const float* T,
                     const float* u, const float* g, uint64_t seed, uint64_t offset,
+                    const int64_t* d_state, int64_t pool_rows,
                     const float* max_bound, int world_frame, int C, int R, int n1, int n2,
                     float eps, float stop_eps, float min_bound,
                     float* z, float* pts, float* origins, float* dirs_o,
-                    float* gt_rgb, uint8_t* depth_mask, uint8_t* labels, void* stream);
+                    float* gt_rgb, float* gt_depth, uint8_t* depth_mask, uint8_t* labels, void* stream);
+/* Device-resident step state int64[3] = {pool cursor (rows), rng step, optimiser step}.  With pool_rows > 0
+ * the four pool pointers above are the BASES of (C, pool_rows, ...) pools and the slice starts at row
+ * d_state[0] (src/scene_cateogries.py:422-431's i_batch); the Philox offset advances by d_state[1].
+ * cnr_step_advance adds (add_rows, 1, 1): a captured hipGraph of the train step replays unchanged. */
+int cnr_step_advance(int64_t* d_state, int64_t add_rows, void* stream);
 
 /* ---- a8: UniDirsEmbed (src/embedding.py:82-92).  x (C,N,3), B (C,21,3) -> e (C,N,129).
  * e[0:3] = x/scale ; e[3+21k+j] = sin(pi * 2^k * (B_j . x/scale)), k = 0..5.
@@ -119,10 +127,11 @@ int cnr_loss_fwd_bwd(const float* depth, const float* var, const float* rgb, con
                      float* d_depth, float* d_rgb, float* d_opacity, int C, int R, void* stream);
 
 /* ---- a18: AdamW on one flat fp32 buffer (train.py:40,183; torch.optim.AdamW semantics,
- * amsgrad=False, maximize=False).  step_count is the 1-based step number held on the host. */
+ * amsgrad=False, maximize=False).  step_count is the 1-based step number held on the host, or, when
+ * d_state != NULL, the step is d_state[2] + 1 read on the device. */
 int cnr_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                    float lr, float beta1, float beta2, float eps, float weight_decay,
-                   int64_t step_count, float grad_unscale, void* stream);
+                   int64_t step_count, float grad_unscale, const int64_t* d_state, void* stream);
 
 /* ================= fused f16-MFMA field path (a8 + a9 in one launch) ================================
  * Packed operand image per class, produced on device from the fp32 trunk blob: forward A fragments,

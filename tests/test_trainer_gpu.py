@@ -1,0 +1,100 @@
+"""GPU: the fused single-launch-per-op train step (cnr_amd.fused) against the oracle's train step."""
+import pytest
+import torch
+
+from conftest import rel_l2
+from oracle import ref_cpu as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cnr(dev):
+    import cnr_amd
+    return cnr_amd
+
+
+def _oracle_params(cnr, tr, theta):
+    v = tr.lay.views(theta.cpu())
+    mlp, off = {}, 0
+    for n, o, i in cnr.ops.TRUNK_LAYERS:
+        mlp[n + ".weight"] = v["trunk"][:, off:off + o * i].reshape(tr.C, o, i).clone(); off += o * i
+        mlp[n + ".bias"] = v["trunk"][:, off:off + o].clone(); off += o
+    for k, n in enumerate(cnr.ops.LATENT_LAYERS):
+        mlp[n + ".weight"] = v["latW"][:, k].clone()
+        mlp[n + ".bias"] = v["latb"][:, k].clone()
+    return mlp, v["B"].clone(), v["shape"].clone(), v["tex"].clone()
+
+
+@pytest.mark.parametrize("C,R,n1,n2,L", [(1, 256, 4, 28, 256), (2, 128, 8, 56, 32)])
+def test_fused_train_step_against_oracle(cnr, dev, C, R, n1, n2, L):
+    cfg = cnr.cfg.synthetic_config(device=str(dev), latent_dim=L, n_bins_cam2surface=n1, n_bins=n2)
+    gen = torch.Generator().manual_seed(7)
+    pools = [cnr.scene_cateogries.synthetic_pool(8 * R, 4, gen, "cpu") for _ in range(C)]
+    tr = cnr.fused.FusedCategoryTrainer(cfg, C, 4, pools, R, dev, seed=3, generator=gen, use_graph=False)
+    theta0 = tr.theta.clone()
+    tr.step()
+    b = {k: v.cpu() for k, v in tr.bufs.items() if torch.is_tensor(v)}
+    losses = tr.losses.cpu()
+    # ---- oracle on exactly the batch the kernels sampled -------------------------------------------------
+    mlp, B, shape, tex = _oracle_params(cnr, tr, theta0)
+    mlp = {k: v.requires_grad_() for k, v in mlp.items()}
+    B.requires_grad_()
+    sh = [shape[c].clone().requires_grad_() for c in range(C)]
+    tx = [tex[c].clone().requires_grad_() for c in range(C)]
+    idx = torch.stack([p["indices"][:R] for p in pools])
+    batch = dict(pts=b["pts"], z=b["z"], gt_depth=b["gt_depth"], gt_rgb=b["gt_rgb"], labels=b["labels"],
+                 depth_mask=b["depth_mask"].bool(), indices=idx)
+    loss, aux = O.forward_loss(mlp, B, cfg.obj_scale, sh, tx, batch)
+    loss.backward()
+    for k, name in enumerate(("loss_depth", "loss_color", "loss_opacity")):
+        assert rel_l2(losses[k], aux[name]) < 2e-3, name
+    # the sampled z must be a valid depth-guided sample set of the pool slice (a5 invariants)
+    d = torch.stack([p["depth"][:R] for p in pools])
+    valid = d > 0
+    assert torch.equal(batch["depth_mask"], valid)
+    zc = b["z"]
+    assert bool((zc[..., :n1][valid] <= (d[valid] - cfg.surface_eps)[:, None] + 1e-5).all())
+    # ---- gradient direction + AdamW step -------------------------------------------------------------------
+    gk = tr.lay.views(tr.grad.cpu())
+    off, dot, n_a, n_b = 0, 0.0, 0.0, 0.0
+    for n, o, i in cnr.ops.TRUNK_LAYERS:
+        for kind, cnt in (("weight", o * i), ("bias", o)):
+            got = gk["trunk"][:, off:off + cnt].reshape(-1).double()
+            ref = mlp[n + "." + kind].grad.reshape(-1).double()
+            dot += float(got @ ref); n_a += float(got @ got); n_b += float(ref @ ref)
+            off += cnt
+    assert dot / (n_a * n_b) ** 0.5 > 0.99
+    for k, n in enumerate(cnr.ops.LATENT_LAYERS):
+        assert rel_l2(gk["latW"][:, k], mlp[n + ".weight"].grad) < 0.15, n
+    assert rel_l2(gk["B"], B.grad) < 0.15
+    assert rel_l2(gk["shape"], torch.stack([s.grad for s in sh])) < 0.15
+    assert rel_l2(gk["tex"], torch.stack([s.grad for s in tx])) < 0.15
+    # one AdamW step (first step = lr * sign(g) where g is not noise): compare the signs of the updates
+    params = list(mlp.values()) + [B] + sh + tx
+    opt = torch.optim.AdamW(params, lr=cfg.learning_rate, weight_decay=cfg.weight_decay)
+    opt.step()
+    new = tr.lay.views(tr.theta.cpu())
+    old = tr.lay.views(theta0.cpu())
+    upd_ref = (B.detach() - old["B"]).reshape(-1)
+    upd_got = (new["B"] - old["B"]).reshape(-1)
+    assert float((torch.sign(upd_ref) == torch.sign(upd_got)).float().mean()) > 0.97
+
+
+def test_graph_replay_trains(cnr, dev):
+    """hipGraph-captured step: losses stay finite and the colour loss goes down over 60 replays."""
+    cfg = cnr.cfg.synthetic_config(device=str(dev), latent_dim=256, n_bins_cam2surface=4, n_bins=28)
+    gen = torch.Generator().manual_seed(11)
+    pools = [cnr.scene_cateogries.synthetic_pool(64 * 512, 4, gen, "cpu")]
+    tr = cnr.fused.FusedCategoryTrainer(cfg, 1, 4, pools, 512, dev, seed=5, generator=gen, use_graph=True)
+    hist = []
+    for it in range(60):
+        tr.step()
+        hist.append(tr.losses.clone())
+    torch.cuda.synchronize()
+    assert tr.graph is not None
+    h = torch.stack(hist).cpu()
+    assert torch.isfinite(h).all()
+    assert int(tr.d_state[2]) == 60 and int(tr.d_state[0]) == tr.cursor
+    assert h[-10:, 1].mean() < h[:10, 1].mean()   # colour L1 decreases
+    assert not bool((tr.flags.cpu() & 1).any())
