@@ -37,7 +37,6 @@ def cpu_baseline(cfg_shape, seconds=12.0):
     opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=0.013)
     import cnr_amd
     pool = cnr_amd.scene_cateogries.synthetic_pool(4 * R, n_obj, gen, "cpu")
-    cores = torch.get_num_threads()
 
     def step(i):
         sl = slice((i % 3) * R, (i % 3) * R + R)
@@ -54,8 +53,21 @@ def cpu_baseline(cfg_shape, seconds=12.0):
         loss.backward()
         opt.step()
 
-    for i in range(2):
-        step(i)
+    # pick the thread count that is fastest for THIS workload (a 128-thread box is slower with all threads on
+    # these small GEMMs than with 16-32): the baseline is the CPU's best, not its default
+    best = None
+    for nt in sorted({8, 16, 32, 64, torch.get_num_threads()}):
+        if nt > (os.cpu_count() or 1):
+            continue
+        torch.set_num_threads(nt)
+        step(0)
+        t0 = time.perf_counter()
+        step(1)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[0]:
+            best = (dt, nt)
+    cores = best[1]
+    torch.set_num_threads(cores)
     times, t_end, i = [], time.perf_counter() + seconds, 0
     while time.perf_counter() < t_end or len(times) < 3:
         t0 = time.perf_counter()
@@ -139,7 +151,9 @@ def main():
     tr.graph, tr.use_graph = saved_graph, not args.no_graph
     avg = {k: (sum(v) / len(v) if v else 0.0) for k, v in tms.items()}
     dom = max(("cnr_field_bwd", "cnr_field_fwd"), key=lambda k: avg[k])
-    # algorithmic FLOP of that launch: fwd = 27 422 / sample, bwd (recompute fwd + dX + dW) = 82 140
+    # cnr_field_bwd = one memset node + the texture and geometry launches of field_bwd_kernel + reduce_records:
+    # its duration is the sum of those (rocprof lists them separately, profiles/).
+    # algorithmic FLOP of that call: fwd = 27 422 / sample, bwd (recompute fwd + dX + dW) = 82 140
     flop_per_sample = 82140 if dom == "cnr_field_bwd" else 27422
     achieved = C * R * S * flop_per_sample / (avg[dom] * 1e-3) / 1e12 if avg[dom] > 0 else 0.0
     roofline = {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s",

@@ -34,9 +34,10 @@ SIGNATURES = {
     "cnr_pack_bytes": [],
     "cnr_pack_weights": [_vp, _vp, _i, _vp],
     "cnr_field_fwd": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _vp],
-    "cnr_field_bwd": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "cnr_field_bwd": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i64, _vp],
+    "cnr_field_bwd_workspace_bytes": [_i, _i],
 }
-_RESTYPE64 = {"cnr_pack_bytes"}
+_RESTYPE64 = {"cnr_pack_bytes", "cnr_field_bwd_workspace_bytes"}
 
 _lib = None
 _double = None
@@ -111,6 +112,10 @@ def version():
 
 def pack_bytes():
     return int(load().cnr_pack_bytes())
+
+
+def field_bwd_workspace_bytes(C, max_blocks):
+    return int(load().cnr_field_bwd_workspace_bytes(int(C), int(max_blocks)))
 
 
 def device_info():

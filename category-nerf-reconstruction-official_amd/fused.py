@@ -82,7 +82,7 @@ class FusedCategoryTrainer:
         self.L = cfg.net_hyperparams["latent_dim"]
         self.scale = float(cfg.obj_scale)
         self.lr, self.wd = cfg.learning_rate, cfg.weight_decay
-        assert cfg.code_learning_rate == cfg.learning_rate and cfg.code_weight_decay == cfg.weight_decay, \\
+        assert cfg.code_learning_rate == cfg.learning_rate and cfg.code_weight_decay == cfg.weight_decay, \
             "one flat AdamW group: the shipped configs use identical lr / weight decay for codes and networks"
         self.theta, self.lay = init_params(n_cls, self.L, n_obj, generator, self.device)
         self.grad = torch.zeros_like(self.theta)
@@ -136,7 +136,8 @@ class FusedCategoryTrainer:
         brows = brows.reshape(C * n_obj, 4, 32)
         # a8 + a9 fused forward, a11-a13 composite, a14-a15 loss (+ its gradient), composite backward
         packed = ops.pack_weights(v["trunk"])
-        sig, rgb = ops.field_fwd(b["pts"], v["B"], packed, brows, ray_row, self.scale)
+        Bc = v["B"].contiguous()
+        sig, rgb = ops.field_fwd(b["pts"], Bc, packed, brows, ray_row, self.scale)
         kw = dict(device=self.device, dtype=torch.float32)
         o = self.bufs
         for name, shape in (("depth", (C, R)), ("var", (C, R)), ("rgb", (C, R, 3)), ("opa", (C, R)),
@@ -152,8 +153,12 @@ class FusedCategoryTrainer:
         # fused backward: dtrunk, dB, dbiasrows straight into the flat gradient buffer views
         dtrunk = torch.zeros(C, TRUNK_PARAMS, **kw)
         dB = torch.zeros(C, 21, 3, **kw)
-        _C.call("cnr_field_bwd", b["pts"], v["B"], packed, brows, ray_row, self.scale, o["dsig"], o["drgb"],
-                self.grad_scale, dtrunk, dB, self.dbias, C, R, S, n_obj, self.bwd_blocks)
+        if "bwd_ws" not in o:
+            o["bwd_ws"] = torch.empty(_C.field_bwd_workspace_bytes(C, self.bwd_blocks), device=self.device,
+                                      dtype=torch.uint8)
+        _C.call("cnr_field_bwd", b["pts"], Bc, packed, brows, ray_row, self.scale, o["dsig"], o["drgb"],
+                self.grad_scale, dtrunk, dB, self.dbias, C, R, S, n_obj, self.bwd_blocks, o["bwd_ws"],
+                o["bwd_ws"].numel())
         gv["trunk"].copy_(dtrunk)
         gv["B"].copy_(dB)
         # latent backward (hand-written chain of the tiny batched GEMMs above)
@@ -187,6 +192,7 @@ class FusedCategoryTrainer:
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self._step_body()
+            self.graph.replay()          # capture only records: run the step it stands for
         elif self.graph is None:
             self._step_body()
         else:

@@ -334,6 +334,9 @@ class FusedFieldFn(Function):
         dtrunk = torch.zeros(ctx.trunk_shape, device=pts.device, dtype=torch.float32)
         dB = torch.zeros_like(B, memory_format=torch.contiguous_format)
         dbr = torch.zeros_like(biasrows, memory_format=torch.contiguous_format)
+        wsb = _C.field_bwd_workspace_bytes(C, ctx.mb)
+        wsp = torch.empty(wsb, device=pts.device, dtype=torch.uint8)
         _C.call("cnr_field_bwd", pts.contiguous(), B.contiguous(), packed, biasrows.contiguous(), ctx.ray_row,
-                ctx.scale, d_sig.contiguous(), d_rgb.contiguous(), ctx.gs, dtrunk, dB, dbr, C, R, S, ctx.rpc, ctx.mb)
+                ctx.scale, d_sig.contiguous(), d_rgb.contiguous(), ctx.gs, dtrunk, dB, dbr, C, R, S, ctx.rpc, ctx.mb,
+                wsp, wsb)
         return None, dB, dtrunk, dbr, None, None, None, None, None

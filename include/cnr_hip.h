@@ -158,12 +158,18 @@ int cnr_field_fwd(const float* pts, const float* B, const void* packed, const fl
  * grad_scale: power-of-two loss scale applied to d_sigma / d_rgb on load and removed on store (the
  * data-gradient chain runs on f16 MFMA operands); scaled d_sigma is clamped to +-8192.
  * rows_per_class: rows of biasrows per class when rows are laid out class-major and ray_row != NULL
- * (<= 32 enables the in-LDS row accumulation); pass R when ray_row == NULL.  S <= 240.
- * max_blocks: workgroups per class (0 = 256); fewer, longer workgroups amortise the dW flush. */
+ * (<= 4 enables the in-LDS row accumulation); pass R when ray_row == NULL.  S <= 240.
+ * max_blocks: workgroups per class (0 = 256).
+ * workspace: caller-allocated, 16-B aligned, >= cnr_field_bwd_workspace_bytes(C, max_blocks) bytes; the call
+ * zeroes it (hipMemsetAsync on `stream`), every workgroup stores one record of partial sums into it with plain
+ * stores and a last small kernel sums the records in a fixed order: no float atomics on shared addresses, the
+ * gradient is bitwise reproducible (the per-ray dbiasrows path, rows_per_class > 4, still uses atomics).
+ * Three kernel launches + one memset node on `stream`; capturable into a hipGraph. */
+int64_t cnr_field_bwd_workspace_bytes(int C, int max_blocks);
 int cnr_field_bwd(const float* pts, const float* B, const void* packed, const float* biasrows,
                   const int* ray_row, float scale, const float* d_sigma, const float* d_rgb,
                   float grad_scale, float* dtrunk, float* dB, float* dbiasrows, int C, int R, int S,
-                  int rows_per_class, int max_blocks, void* stream);
+                  int rows_per_class, int max_blocks, void* workspace, int64_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }
