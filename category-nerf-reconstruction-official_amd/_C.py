@@ -18,10 +18,12 @@ _vp, _i, _i64, _u64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.
 SIGNATURES = {
     "cnr_version": [],
     "cnr_device_info": [_vp, _vp, _vp],
-    "cnr_sample_maxdepth": [_vp, _vp, _vp, _i64, _i, _i, _vp],
+    "cnr_sample_maxdepth": [_vp, _vp, _vp, _i64, _vp, _i, _i, _vp],
     "cnr_step_advance": [_vp, _i64, _vp],
     "cnr_sample_rays": [_vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64, _vp, _i64, _vp, _i, _i, _i, _i, _i, _f, _f, _f,
-                        _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+                        _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp],
+    "cnr_latent_fwd": [_vp, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _vp, _vp, _vp],
+    "cnr_latent_bwd": [_vp, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _vp, _vp, _f, _vp, _vp],
     "cnr_pe_fwd": [_vp, _vp, _vp, _i, _i64, _f, _vp],
     "cnr_pe_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i64, _f, _vp],
     "cnr_mlp_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],

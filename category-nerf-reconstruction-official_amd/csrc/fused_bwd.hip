@@ -172,27 +172,49 @@ __global__ void fill_param_src_kernel() {
   }
 }
 
-// fixed-order sum of the per-workgroup records into the (accumulated) outputs
+// Fixed-order sum of the per-workgroup records into the (accumulated) outputs.  256 threads = 64 record entries x
+// 4 quarters of the workgroup range; each quarter keeps 8 loads in flight, the quarters are combined through LDS in
+// a fixed order.  Entries no launch writes (latent-layer biases, padding, unused row sums) are skipped, so the
+// workspace needs no clearing.
+__device__ __forceinline__ bool rec_entry_written(int i, int rows_per_class) {
+  if (i < TRUNK)
+    return !((i >= OFF_S1_B && i < OFF_S1_B + 32) || (i >= OFF_CAT_B && i < OFF_CAT_B + 32) ||
+             (i >= OFF_S2_B && i < OFF_S2_B + 32) || (i >= OFF_T1_B && i < OFF_T1_B + 32));
+  if (i < TRUNK + 126) return true;
+  return rows_per_class <= ROWS_LDS && (i - (TRUNK + 126)) < rows_per_class * 128;
+}
 __global__ __launch_bounds__(256) void reduce_records_kernel(const float* __restrict__ records, int nwg,
                                                              float* __restrict__ dtrunk, float* __restrict__ dB,
                                                              float* __restrict__ dbiasrows, int rows_per_class) {
+  __shared__ float part[4][64];
   const int c = blockIdx.y;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= REC_FLOATS) return;
-  const float* r = records + (size_t)c * nwg * REC_FLOATS + i;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int w = 0;
-  for (; w + 3 < nwg; w += 4) {
-    s0 += r[(size_t)(w + 0) * REC_FLOATS]; s1 += r[(size_t)(w + 1) * REC_FLOATS];
-    s2 += r[(size_t)(w + 2) * REC_FLOATS]; s3 += r[(size_t)(w + 3) * REC_FLOATS];
+  const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + e;
+  const bool live = i < REC_FLOATS && rec_entry_written(i, rows_per_class);
+  float s = 0.0f;
+  if (live) {
+    const int per = (nwg + 3) / 4, w0 = q * per, w1 = min(nwg, w0 + per);
+    const float* r = records + (size_t)c * nwg * REC_FLOATS + i;
+    float a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] = 0.0f;
+    int w = w0;
+    for (; w + 7 < w1; w += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += r[(size_t)(w + u) * REC_FLOATS];
+    }
+    for (; w < w1; ++w) a[0] += r[(size_t)w * REC_FLOATS];
+    s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   }
-  for (; w < nwg; ++w) s0 += r[(size_t)w * REC_FLOATS];
-  const float v = (s0 + s1) + (s2 + s3);
-  if (i < TRUNK) dtrunk[(size_t)c * TRUNK + i] += v;
-  else if (i < TRUNK + 63) atomicAdd(&dB[(size_t)c * 63 + (i - TRUNK)], v);          // two addends per element
-  else if (i < TRUNK + 126) atomicAdd(&dB[(size_t)c * 63 + (i - TRUNK - 63)], v);
-  else if (i - (TRUNK + 126) < rows_per_class * 128 && rows_per_class <= ROWS_LDS)
-    dbiasrows[(size_t)c * rows_per_class * 128 + (i - (TRUNK + 126))] += v;
+  part[q][e] = s;
+  __syncthreads();
+  if (q == 0 && live) {
+    const float v = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
+    if (i < TRUNK) dtrunk[(size_t)c * TRUNK + i] += v;
+    else if (i < TRUNK + 63) atomicAdd(&dB[(size_t)c * 63 + (i - TRUNK)], v);        // two addends per element
+    else if (i < TRUNK + 126) atomicAdd(&dB[(size_t)c * 63 + (i - TRUNK - 63)], v);
+    else dbiasrows[(size_t)c * rows_per_class * 128 + (i - (TRUNK + 126))] += v;
+  }
 }
 
 template <bool BIG_S, int PART>
@@ -601,9 +623,9 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(
   // No global float atomics on shared addresses either: hundreds of workgroups adding into the same 55 KB
   // serialise at the memory side (measured: +2.6 us per extra workgroup).  Every workgroup writes ONE record
   //   rec = [ trunk 13892 | dB geometry 63 | dB texture 63 | row sums ROWS_LDS x 128 ]  (floats, REC_FLOATS)
-  // with plain stores (the two PART launches fill disjoint entries of the same record; the launcher zeroes the
-  // workspace first) and reduce_records_kernel sums the records in a fixed order: the gradient is bitwise
-  // reproducible run to run.
+  // with plain stores (the two PART launches fill disjoint entries of the same record, every entry the reduction
+  // reads is rewritten by every call) and reduce_records_kernel sums the records in a fixed order: the gradient is
+  // bitwise reproducible run to run.
   float* rec = records + ((size_t)c * gridDim.x + blockIdx.x) * REC_FLOATS;
   // (1) per-wave small sums -> wave slots in LDS (plain), then one pass over the four waves
   wave_lds_sync();
@@ -719,8 +741,6 @@ extern "C" int cnr_field_bwd(const float* pts, const float* B, const void* packe
     hipLaunchKernelGGL(fill_param_src_kernel, dim3(16), dim3(256), 0, (hipStream_t)stream);
     attr_set = true;
   }
-  hipError_t me = hipMemsetAsync(workspace, 0, (size_t)need, (hipStream_t)stream);
-  if (me != hipSuccess) return (int)me;
   dim3 grid((unsigned)blocks, (unsigned)C);
 #define CNR_LAUNCH_BWD(BIG, PART)                                                                               \
   hipLaunchKernelGGL((field_bwd_kernel<BIG, PART>), grid, dim3(256), LDS_TOTAL, (hipStream_t)stream, pts, B,    \
@@ -730,7 +750,7 @@ extern "C" int cnr_field_bwd(const float* pts, const float* B, const void* packe
   else { CNR_LAUNCH_BWD(false, 1); CNR_LAUNCH_BWD(false, 0); }
 #undef CNR_LAUNCH_BWD
   CNR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(reduce_records_kernel, dim3(REC_FLOATS / 256, (unsigned)C), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(reduce_records_kernel, dim3(REC_FLOATS / 64, (unsigned)C), dim3(256), 0, (hipStream_t)stream,
                      (const float*)workspace, (int)blocks, dtrunk, dB, dbiasrows, rows_per_class);
   CNR_LAUNCH_CHECK();
   return CNR_OK;

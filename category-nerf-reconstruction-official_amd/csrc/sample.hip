@@ -34,11 +34,13 @@ __device__ __forceinline__ float linspace01(int i, int n) {
 }
 
 __global__ void maxdepth_kernel(const float* __restrict__ depth, float* __restrict__ max_bound, int R,
-                                const int64_t* __restrict__ d_state, int64_t pool_rows) {
+                                const int64_t* __restrict__ d_state, int64_t pool_rows,
+                                const int* __restrict__ perm) {
   const int c = blockIdx.x;
   float m = -INFINITY;
   const int64_t base = pool_rows > 0 ? (int64_t)c * pool_rows + d_state[0] : (int64_t)c * R;
-  for (int r = threadIdx.x; r < R; r += blockDim.x) m = fmaxf(m, depth[base + r]);
+  for (int r = threadIdx.x; r < R; r += blockDim.x)
+    m = fmaxf(m, depth[perm ? (int64_t)c * pool_rows + perm[base + r] : base + r]);
   __shared__ float sm[16];
   m = cnr::wave_max(m);
   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
@@ -81,7 +83,9 @@ __global__ __launch_bounds__(256) void sample_kernel(
     int C, int R, int n1, int n2, float eps, float stop_eps, float min_bound,
     float* __restrict__ z, float* __restrict__ pts, float* __restrict__ origins,
     float* __restrict__ dirs_o, float* __restrict__ gt_rgb, float* __restrict__ gt_depth,
-    uint8_t* __restrict__ depth_mask, uint8_t* __restrict__ labels) {
+    uint8_t* __restrict__ depth_mask, uint8_t* __restrict__ labels,
+    const int64_t* __restrict__ pool_indices, int n_obj, int* __restrict__ ray_row,
+    const int* __restrict__ perm) {
   const int lane = threadIdx.x & 63;
   const int64_t ray = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (ray >= (int64_t)C * R) return;
@@ -92,6 +96,7 @@ __global__ __launch_bounds__(256) void sample_kernel(
   int64_t prow = ray;
   if (pool_rows > 0) {
     prow = (int64_t)c * pool_rows + d_state[0] + (ray - (int64_t)c * R);
+    if (perm) prow = (int64_t)c * pool_rows + perm[prow];   // epoch shuffle = a new permutation, the pool stays put
     offset += (uint64_t)d_state[1] * 4;
   }
 
@@ -134,6 +139,7 @@ __global__ __launch_bounds__(256) void sample_kernel(
     if (dirs_o) { dirs_o[ray * 3 + 0] = ex; dirs_o[ray * 3 + 1] = ey; dirs_o[ray * 3 + 2] = ez; }
     depth_mask[ray] = invalid ? 0 : 1;
     labels[ray] = state;
+    if (ray_row) ray_row[ray] = (int)pool_indices[prow] + c * n_obj;   // row of the class-major code tables
   }
   if (lane < 3) gt_rgb[ray * 3 + lane] = (float)rgbs[prow * 4 + lane] / 255.0f;
   if (lane == 3 && gt_depth) gt_depth[ray] = d;
@@ -211,10 +217,10 @@ extern "C" int cnr_step_advance(int64_t* d_state, int64_t add_rows, void* stream
 }
 
 extern "C" int cnr_sample_maxdepth(const float* depth, float* max_bound, const int64_t* d_state,
-                                   int64_t pool_rows, int C, int R, void* stream) {
+                                   int64_t pool_rows, const int* perm, int C, int R, void* stream) {
   if (!depth || !max_bound || C <= 0 || R <= 0 || pool_rows < 0 || (pool_rows > 0 && !d_state)) return CNR_E_ARG;
   hipLaunchKernelGGL(maxdepth_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, depth, max_bound, R, d_state,
-                     pool_rows);
+                     pool_rows, perm);
   CNR_LAUNCH_CHECK();
   return CNR_OK;
 }
@@ -225,20 +231,23 @@ extern "C" int cnr_sample_rays(const uint8_t* rgbs, const float* depth, const fl
                                const float* max_bound, int world_frame, int C, int R, int n1, int n2,
                                float eps, float stop_eps, float min_bound, float* z, float* pts,
                                float* origins, float* dirs_o, float* gt_rgb, float* gt_depth,
-                               uint8_t* depth_mask, uint8_t* labels, void* stream) {
+                               uint8_t* depth_mask, uint8_t* labels, const int64_t* pool_indices, int n_obj,
+                               int* ray_row, const int* perm, void* stream) {
   if (!rgbs || !depth || !dirs_c || !T || !max_bound || !z || !pts || !gt_rgb || !depth_mask || !labels)
     return CNR_E_ARG;
   if (C <= 0 || R <= 0 || n1 < 0 || n2 <= 0) return CNR_E_ARG;
   if (n2 > 128) return CNR_E_SHAPE;
   if ((u == nullptr) != (g == nullptr)) return CNR_E_ARG;
   if (pool_rows < 0 || (pool_rows > 0 && (!d_state || pool_rows < R))) return CNR_E_ARG;
+  if (ray_row && (!pool_indices || n_obj <= 0)) return CNR_E_ARG;
+  if (perm && pool_rows == 0) return CNR_E_ARG;
   const int64_t rays = (int64_t)C * R;
   const int waves_per_block = 4;
   const int64_t blocks = (rays + waves_per_block - 1) / waves_per_block;
   hipLaunchKernelGGL(sample_kernel, dim3((unsigned)blocks), dim3(64 * waves_per_block), 0,
                      (hipStream_t)stream, rgbs, depth, dirs_c, T, u, g, seed, offset, d_state, pool_rows,
                      max_bound, world_frame, C, R, n1, n2, eps, stop_eps, min_bound, z, pts, origins, dirs_o,
-                     gt_rgb, gt_depth, depth_mask, labels);
+                     gt_rgb, gt_depth, depth_mask, labels, pool_indices, n_obj, ray_row, perm);
   CNR_LAUNCH_CHECK();
   return CNR_OK;
 }

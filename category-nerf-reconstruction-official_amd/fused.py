@@ -96,6 +96,9 @@ class FusedCategoryTrainer:
         self.pool_rows = self.pool["depth"].shape[1]
         assert self.pool_rows >= 2 * self.R
         self.d_state = torch.zeros(3, device=self.device, dtype=torch.int64)   # cursor, rng step, opt step
+        # epoch shuffle as an index permutation (C, pool_rows): the pool itself never moves
+        self.perm = torch.empty(n_cls, self.pool_rows, device=self.device, dtype=torch.int32)
+        self._zero64 = torch.zeros(1, device=self.device, dtype=torch.int64)
         self.cursor = 0
         self.seed = int(seed) + 1
         self.grad_scale = float(grad_scale) if grad_scale else float(2 ** round(math.log2(max(self.R, 2))))
@@ -107,7 +110,7 @@ class FusedCategoryTrainer:
         self.use_graph = use_graph
         self.graph = None
         self.steps_done = 0
-        self._row_base = (torch.arange(n_cls, device=self.device, dtype=torch.int64) * n_obj)[:, None]
+        self._reshuffle()
 
     # ---- one step, eager (also the body that gets captured) ------------------------------------------
     def _step_body(self):
@@ -119,21 +122,17 @@ class FusedCategoryTrainer:
         # a2-a6: slice the device pool at the device cursor, transform, sample
         b = ops.sample_rays(self.pool["rgbs"], self.pool["depth"], self.pool["dirs"], self.pool["T"], self.n1,
                             self.n2, cfg.surface_eps, cfg.stop_eps, min_bound=cfg.min_depth, world_frame=False,
-                            seed=self.seed, d_state=self.d_state, rays=R, out=self.bufs)
-        cur = self.d_state[0]
-        # object row of every ray: pool indices at [cursor, cursor + R) -- gathered on the device
-        ar = self.bufs.setdefault("_arange", torch.arange(R, device=self.device))
-        ray_row = (torch.gather(self.pool["indices"], 1, (ar + cur).expand(C, R)) + self._row_base).to(torch.int32)
-        # a7 + latent layers (per-object work, plain batched GEMMs): zlat = relu(code Wl^T + bl); bias rows
-        codes4 = torch.stack([v["shape"], v["shape"], v["shape"], v["tex"]], dim=1).reshape(C * 4, n_obj, L)
-        Wl4 = v["latW"].reshape(C * 4, 32, L)
-        pre = torch.baddbmm(v["latb"].reshape(C * 4, 1, 32), codes4, Wl4.transpose(1, 2))      # (C*4,n_obj,32)
-        zl = torch.relu(pre)
-        Wt4 = torch.stack([v["trunk"][:, wo:wo + 32 * ld].reshape(C, 32, ld)[:, :, :32] for wo, _, ld in _LAT_FANIN_TARGET],
-                          dim=1).reshape(C * 4, 32, 32)
-        bt4 = torch.stack([v["trunk"][:, bo:bo + 32] for _, bo, _ in _LAT_FANIN_TARGET], dim=1).reshape(C * 4, 1, 32)
-        brows = torch.baddbmm(bt4, zl, Wt4.transpose(1, 2)).reshape(C, 4, n_obj, 32).transpose(1, 2).contiguous()
-        brows = brows.reshape(C * n_obj, 4, 32)
+                            seed=self.seed, d_state=self.d_state, rays=R, out=self.bufs,
+                            pool_indices=self.pool["indices"], n_obj=n_obj, perm=self.perm)
+        ray_row = b["ray_row"]
+        # a7 + latent layers (per-object work): one small kernel -> zl (post-ReLU), effective bias rows
+        lay = self.lay
+        if "zl" not in self.bufs:
+            self.bufs["zl"] = torch.empty(C * n_obj, 4, 32, device=self.device)
+            self.bufs["brows"] = torch.empty(C * n_obj, 4, 32, device=self.device)
+        zl, brows = self.bufs["zl"], self.bufs["brows"]
+        lat_args = (lay.total, lay.latW[0], lay.latb[0], lay.shape[0], lay.tex[0], L, n_obj, C)
+        _C.call("cnr_latent_fwd", self.theta, *lat_args, zl, brows)
         # a8 + a9 fused forward, a11-a13 composite, a14-a15 loss (+ its gradient), composite backward
         packed = ops.pack_weights(v["trunk"])
         Bc = v["B"].contiguous()
@@ -151,30 +150,23 @@ class FusedCategoryTrainer:
                 b["depth_mask"], 5.0, 10.0, inv_w, self.losses, self.flags, o["dd"], o["dr"], o["do"], C, R)
         _C.call("cnr_composite_bwd", sig, rgb, b["z"], o["dd"], o["dr"], o["do"], None, o["dsig"], o["drgb"], C * R, S, 0)
         # fused backward: dtrunk, dB, dbiasrows straight into the flat gradient buffer views
-        dtrunk = torch.zeros(C, TRUNK_PARAMS, **kw)
-        dB = torch.zeros(C, 21, 3, **kw)
+        if C == 1:   # one class: the views of the flat gradient row are contiguous, accumulate in place
+            dtrunk, dB = gv["trunk"], gv["B"]
+        else:
+            dtrunk = torch.zeros(C, TRUNK_PARAMS, **kw)
+            dB = torch.zeros(C, 21, 3, **kw)
         if "bwd_ws" not in o:
             o["bwd_ws"] = torch.empty(_C.field_bwd_workspace_bytes(C, self.bwd_blocks), device=self.device,
                                       dtype=torch.uint8)
         _C.call("cnr_field_bwd", b["pts"], Bc, packed, brows, ray_row, self.scale, o["dsig"], o["drgb"],
                 self.grad_scale, dtrunk, dB, self.dbias, C, R, S, n_obj, self.bwd_blocks, o["bwd_ws"],
                 o["bwd_ws"].numel())
-        gv["trunk"].copy_(dtrunk)
-        gv["B"].copy_(dB)
-        # latent backward (hand-written chain of the tiny batched GEMMs above)
-        dbr = self.dbias.reshape(C, n_obj, 4, 32).transpose(1, 2).reshape(C * 4, n_obj, 32)
-        dbt4 = dbr.sum(dim=1).reshape(C, 4, 32)
-        dWt4 = torch.bmm(dbr.transpose(1, 2), zl).reshape(C, 4, 32, 32)
-        for k, (wo, bo, ld) in enumerate(_LAT_FANIN_TARGET):
-            gv["trunk"][:, wo:wo + 32 * ld].view(C, 32, ld)[:, :, :32].add_(dWt4[:, k])
-            gv["trunk"][:, bo:bo + 32].add_(dbt4[:, k])
-        dpre = torch.bmm(dbr, Wt4) * (pre > 0)
-        gv["latW"].copy_(torch.bmm(dpre.transpose(1, 2), codes4).reshape(C, 4, 32, L))
-        gv["latb"].copy_(dpre.sum(dim=1).reshape(C, 4, 32))
-        dcodes = torch.bmm(dpre, Wl4).reshape(C, 4, n_obj, L)
-        reg = 0.0005 * inv_w if n_obj > 1 else 0.0     # loss.py:5-15, train.py:165-167
-        gv["shape"].copy_(dcodes[:, :3].sum(dim=1) + reg * v["shape"] / v["shape"].norm(dim=-1, keepdim=True))
-        gv["tex"].copy_(dcodes[:, 3] + reg * v["tex"] / v["tex"].norm(dim=-1, keepdim=True))
+        if C > 1:
+            gv["trunk"].copy_(dtrunk)
+            gv["B"].copy_(dB)
+        # latent backward + code regulariser: one kernel over the flat rows
+        reg = 0.0005 * inv_w                     # loss.py:5-15, train.py:165-167
+        _C.call("cnr_latent_bwd", self.theta, *lat_args, zl, self.dbias, reg, self.grad)
         if self.pg is not None:
             torch.distributed.all_reduce(self.grad, group=self.pg)   # one flat buffer, one collective
         ops.adamw_step(self.theta, self.grad, self.exp_avg, self.exp_avg_sq, self.lr, (0.9, 0.999), 1e-8, self.wd,
@@ -201,11 +193,11 @@ class FusedCategoryTrainer:
         self.steps_done += 1
 
     def _reshuffle(self):
-        perm = torch.randperm(self.pool_rows, device=self.device)
-        for k in self.pool:
-            self.pool[k].copy_(self.pool[k][:, perm])
+        """New permutation, cursor back to 0 (scene_cateogries.py:439-449); all on the device, no host sync."""
+        for c in range(self.C):
+            self.perm[c].copy_(torch.randperm(self.pool_rows, device=self.device))
         self.cursor = 0
-        self.d_state[0] = 0
+        self.d_state[0:1].copy_(self._zero64)
 
     # ---- reference-named export ------------------------------------------------------------------------
     def state_dicts(self, c=0):

@@ -230,7 +230,8 @@ class RenderLossFn(Function):
 # a2-a5  sampling (no gradient: poses are not optimised)
 # ------------------------------------------------------------------------------------------------
 def sample_rays(rgbs, depth, dirs_c, T, n1, n2, eps, stop_eps, min_bound=0.0, world_frame=False,
-                u=None, g=None, seed=0, offset=0, want_rays=False, d_state=None, rays=None, out=None):
+                u=None, g=None, seed=0, offset=0, want_rays=False, d_state=None, rays=None, out=None,
+                pool_indices=None, n_obj=0, perm=None):
     """Class-batched pool slice (C,R,...) -> dict(z, pts, gt_rgb, gt_depth, depth_mask, labels[, origins, dirs_o]).
     u/g given -> parity mode (identical draws); else in-kernel Philox(seed, offset).
     d_state (int64[3] device) + rays=R: the inputs are whole (C,pool_rows,...) pools and the slice starts at
@@ -247,16 +248,18 @@ def sample_rays(rgbs, depth, dirs_c, T, n1, n2, eps, stop_eps, min_bound=0.0, wo
             o[name] = torch.empty(*shape, device=dev, dtype=dtype)
         return o[name]
     mb = buf("max_bound", (C,))
-    _C.call("cnr_sample_maxdepth", depth, mb, d_state, pool_rows, C, R)
+    _C.call("cnr_sample_maxdepth", depth, mb, d_state, pool_rows, perm, C, R)
     z, pts = buf("z", (C, R, S)), buf("pts", (C, R, S, 3))
     gt, gd = buf("gt_rgb", (C, R, 3)), buf("gt_depth", (C, R))
     dm, lab = buf("depth_mask", (C, R), torch.uint8), buf("labels", (C, R), torch.uint8)
     org = buf("origins", (C, R, 3)) if want_rays else None
     dro = buf("dirs_o", (C, R, 3)) if want_rays else None
+    rr = buf("ray_row", (C, R), torch.int32) if pool_indices is not None else None
     cont = lambda t: None if t is None else t.contiguous()
     _C.call("cnr_sample_rays", rgbs.contiguous(), depth.contiguous(), dirs_c.contiguous(), T.contiguous(),
             cont(u), cont(g), int(seed), int(offset), d_state, pool_rows, mb, int(bool(world_frame)), C, R, n1, n2,
-            float(eps), float(stop_eps), float(min_bound), z, pts, org, dro, gt, gd, dm, lab)
+            float(eps), float(stop_eps), float(min_bound), z, pts, org, dro, gt, gd, dm, lab,
+            pool_indices, int(n_obj), rr, perm)
     return o
 
 

@@ -61,20 +61,25 @@ int cnr_device_info(int* n_cu, int* lds_bytes, int* gcn_arch_is_gfx950);
  *         cnr_sample_maxdepth below so that no host sync is needed.
  * Outputs: z (C,R,S) with S = n1+n2, pts (C,R,S,3), origins (C,R,3) and dirs_o (C,R,3) (may be NULL),
  *   gt_rgb (C,R,3) f32 already /255 (train.py:144), gt_depth (C,R) copy of the slice's depth (may be
- *   NULL), depth_mask (C,R) u8, labels (C,R) u8. */
+ *   NULL), depth_mask (C,R) u8, labels (C,R) u8; ray_row (C,R) i32 = pool_indices[slice] + c * n_obj, the row of
+ *   each ray in class-major (C*n_obj, ...) code / bias-row tables (NULL to skip; pool_indices is (C,R) or,
+ *   with pool_rows > 0, the (C,pool_rows) int64 base). */
 int cnr_sample_maxdepth(const float* depth, float* max_bound, const int64_t* d_state, int64_t pool_rows,
-                        int C, int R, void* stream);
+                        const int* perm, int C, int R, void* stream);
 int cnr_sample_rays(const uint8_t* rgbs, const float* depth, const float* dirs_c, const float* T,
                     const float* u, const float* g, uint64_t seed, uint64_t offset,
                     const int64_t* d_state, int64_t pool_rows,
                     const float* max_bound, int world_frame, int C, int R, int n1, int n2,
                     float eps, float stop_eps, float min_bound,
                     float* z, float* pts, float* origins, float* dirs_o,
-                    float* gt_rgb, float* gt_depth, uint8_t* depth_mask, uint8_t* labels, void* stream);
+                    float* gt_rgb, float* gt_depth, uint8_t* depth_mask, uint8_t* labels,
+                    const int64_t* pool_indices, int n_obj, int* ray_row, const int* perm, void* stream);
 /* Device-resident step state int64[3] = {pool cursor (rows), rng step, optimiser step}.  With pool_rows > 0
  * the four pool pointers above are the BASES of (C, pool_rows, ...) pools and the slice starts at row
  * d_state[0] (src/scene_cateogries.py:422-431's i_batch); the Philox offset advances by d_state[1].
- * cnr_step_advance adds (add_rows, 1, 1): a captured hipGraph of the train step replays unchanged. */
+ * cnr_step_advance adds (add_rows, 1, 1): a captured hipGraph of the train step replays unchanged.
+ * perm (C,pool_rows) i32, optional with pool_rows > 0: row r of the slice is pool row perm[c][cursor + r] -- the
+ * per-epoch reshuffle (src/scene_cateogries.py:439-449) becomes a new permutation instead of moving the pool. */
 int cnr_step_advance(int64_t* d_state, int64_t add_rows, void* stream);
 
 /* ---- a8: UniDirsEmbed (src/embedding.py:82-92).  x (C,N,3), B (C,21,3) -> e (C,N,129).
@@ -133,6 +138,19 @@ int cnr_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_a
                    float lr, float beta1, float beta2, float eps, float weight_decay,
                    int64_t step_count, float grad_unscale, const int64_t* d_state, void* stream);
 
+/* ---- a7 + latent layers over the fused trainer's flat parameter rows (csrc/latent.hip).  theta / grad: (C,
+ * class_stride) floats, each row [trunk 13892 | ...]; off_* = float offsets of latent W (4,32,L), latent b (4,32),
+ * shape codes (n_obj,L), texture codes (n_obj,L) inside a row.  fwd -> zl (C*n_obj,4,32) post-ReLU latent outputs,
+ * biasrows (C*n_obj,4,32).  bwd: dbiasrows -> grad rows: latent W/b and code entries are WRITTEN, the trunk's
+ * Wt_k[:, :32] / bt_k entries are ADDED (cnr_field_bwd's dtrunk must already be there); the code-norm regulariser
+ * reg_scale * code / ||code|| (src/loss.py:5-15, train.py:165-167) is included when n_obj > 1. */
+int cnr_latent_fwd(const float* theta, int64_t class_stride, int64_t off_latW, int64_t off_latb,
+                   int64_t off_shape, int64_t off_tex, int L, int n_obj, int C, float* zl, float* biasrows,
+                   void* stream);
+int cnr_latent_bwd(const float* theta, int64_t class_stride, int64_t off_latW, int64_t off_latb,
+                   int64_t off_shape, int64_t off_tex, int L, int n_obj, int C, const float* zl,
+                   const float* dbiasrows, float reg_scale, float* grad, void* stream);
+
 /* ================= fused f16-MFMA field path (a8 + a9 in one launch) ================================
  * Packed operand image per class, produced on device from the fp32 trunk blob: forward A fragments,
  * fp32 constants, transposed (backward) A fragments -- layout contract in csrc/fused_common.h.
@@ -160,11 +178,11 @@ int cnr_field_fwd(const float* pts, const float* B, const void* packed, const fl
  * rows_per_class: rows of biasrows per class when rows are laid out class-major and ray_row != NULL
  * (<= 4 enables the in-LDS row accumulation); pass R when ray_row == NULL.  S <= 240.
  * max_blocks: workgroups per class (0 = 256).
- * workspace: caller-allocated, 16-B aligned, >= cnr_field_bwd_workspace_bytes(C, max_blocks) bytes; the call
- * zeroes it (hipMemsetAsync on `stream`), every workgroup stores one record of partial sums into it with plain
- * stores and a last small kernel sums the records in a fixed order: no float atomics on shared addresses, the
- * gradient is bitwise reproducible (the per-ray dbiasrows path, rows_per_class > 4, still uses atomics).
- * Three kernel launches + one memset node on `stream`; capturable into a hipGraph. */
+ * workspace: caller-allocated, 16-B aligned, >= cnr_field_bwd_workspace_bytes(C, max_blocks) bytes, contents
+ * irrelevant: every workgroup stores one record of partial sums into it with plain stores and a last small
+ * kernel sums the records in a fixed order -- no float atomics on shared addresses, the gradient is bitwise
+ * reproducible (the per-ray dbiasrows path, rows_per_class > 4, still uses atomics).
+ * Three kernel launches on `stream`; capturable into a hipGraph. */
 int64_t cnr_field_bwd_workspace_bytes(int C, int max_blocks);
 int cnr_field_bwd(const float* pts, const float* B, const void* packed, const float* biasrows,
                   const int* ray_row, float scale, const float* d_sigma, const float* d_rgb,

@@ -33,6 +33,7 @@ def test_fused_train_step_against_oracle(cnr, dev, C, R, n1, n2, L):
     pools = [cnr.scene_cateogries.synthetic_pool(8 * R, 4, gen, "cpu") for _ in range(C)]
     tr = cnr.fused.FusedCategoryTrainer(cfg, C, 4, pools, R, dev, seed=3, generator=gen, use_graph=False)
     theta0 = tr.theta.clone()
+    rows = tr.perm[:, :R].long().cpu()          # pool rows of the first slice (epoch permutation)
     tr.step()
     b = {k: v.cpu() for k, v in tr.bufs.items() if torch.is_tensor(v)}
     losses = tr.losses.cpu()
@@ -42,7 +43,7 @@ def test_fused_train_step_against_oracle(cnr, dev, C, R, n1, n2, L):
     B.requires_grad_()
     sh = [shape[c].clone().requires_grad_() for c in range(C)]
     tx = [tex[c].clone().requires_grad_() for c in range(C)]
-    idx = torch.stack([p["indices"][:R] for p in pools])
+    idx = torch.stack([pools[c]["indices"][rows[c]] for c in range(C)])
     batch = dict(pts=b["pts"], z=b["z"], gt_depth=b["gt_depth"], gt_rgb=b["gt_rgb"], labels=b["labels"],
                  depth_mask=b["depth_mask"].bool(), indices=idx)
     loss, aux = O.forward_loss(mlp, B, cfg.obj_scale, sh, tx, batch)
@@ -50,7 +51,7 @@ def test_fused_train_step_against_oracle(cnr, dev, C, R, n1, n2, L):
     for k, name in enumerate(("loss_depth", "loss_color", "loss_opacity")):
         assert rel_l2(losses[k], aux[name]) < 2e-3, name
     # the sampled z must be a valid depth-guided sample set of the pool slice (a5 invariants)
-    d = torch.stack([p["depth"][:R] for p in pools])
+    d = torch.stack([pools[c]["depth"][rows[c]] for c in range(C)])
     valid = d > 0
     assert torch.equal(batch["depth_mask"], valid)
     zc = b["z"]
