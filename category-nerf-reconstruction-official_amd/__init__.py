@@ -7,6 +7,6 @@ single-launch fast path and ``parallel`` the multi-GPU sharding.  Import as ``cn
 cnr_amd.py at the repo root; the directory name carries a hyphen).
 """
 from . import _C, ops  # noqa: F401
-from . import cfg, embedding, model, render_rays, loss, trainer, utils, scene_cateogries, fused  # noqa: F401
+from . import cfg, embedding, model, render_rays, loss, trainer, utils, scene_cateogries, fused, parallel  # noqa: F401
 
 __version__ = "0.1.0"

@@ -15,7 +15,7 @@ import math
 
 import torch
 
-from . import _C, ops
+from . import _C, ops, parallel
 from .embedding import UNIDIRS
 from .ops import LATENT_LAYERS, TRUNK_LAYERS, TRUNK_PARAMS
 
@@ -168,7 +168,7 @@ class FusedCategoryTrainer:
         reg = 0.0005 * inv_w                     # loss.py:5-15, train.py:165-167
         _C.call("cnr_latent_bwd", self.theta, *lat_args, zl, self.dbias, reg, self.grad)
         if self.pg is not None:
-            torch.distributed.all_reduce(self.grad, group=self.pg)   # one flat buffer, one collective
+            parallel.allreduce_mean_(self.grad, self.pg, prescaled=True)   # one flat buffer, one collective
         ops.adamw_step(self.theta, self.grad, self.exp_avg, self.exp_avg_sq, self.lr, (0.9, 0.999), 1e-8, self.wd,
                        0, d_state=self.d_state)
         ops.step_advance(self.d_state, R)

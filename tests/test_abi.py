@@ -1,0 +1,93 @@
+"""CPU: the C-ABI library loads without a GPU, exports every symbol include/cnr_hip.h declares, the ctypes
+signature table mirrors the header, and argument errors come back as codes (never exit(), never a crash)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, "include", "cnr_hip.h")
+LIB = os.path.join(ROOT, "category-nerf-reconstruction-official_amd", "libcnr_hip.so")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(int64_t|int)\s+(cnr_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+        args = [a.strip() for a in m.group(3).split(",")]
+        out[m.group(2)] = [a for a in args if a and a != "void"]
+    return out
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(LIB):
+        import __graft_entry__
+        __graft_entry__.build()
+    return ctypes.CDLL(LIB)
+
+
+def test_header_declares_the_hot_path():
+    fns = declared_functions()
+    for name in ("cnr_sample_rays", "cnr_pe_fwd", "cnr_pe_bwd", "cnr_mlp_fwd_f32", "cnr_mlp_bwd_f32",
+                 "cnr_composite_fwd", "cnr_composite_bwd", "cnr_loss_fwd_bwd", "cnr_adamw_step", "cnr_pack_weights",
+                 "cnr_field_fwd", "cnr_field_bwd", "cnr_latent_fwd", "cnr_latent_bwd", "cnr_step_advance"):
+        assert name in fns, name
+
+
+def test_every_declared_symbol_is_exported(lib):
+    for name in declared_functions():
+        assert hasattr(lib, name), f"{name} declared in cnr_hip.h but not exported by libcnr_hip.so"
+
+
+def test_ctypes_table_matches_header():
+    import cnr_amd
+    fns = declared_functions()
+    sig = cnr_amd._C.SIGNATURES
+    assert set(sig) == set(fns), (set(sig) ^ set(fns))
+    for name, args in fns.items():
+        assert len(sig[name]) == len(args), (name, len(sig[name]), len(args))
+        for ct, decl in zip(sig[name], args):
+            if "*" in decl:
+                assert ct is ctypes.c_void_p, (name, decl)
+            elif decl.startswith("float"):
+                assert ct is ctypes.c_float, (name, decl)
+            elif decl.startswith(("int64_t", "uint64_t")):
+                assert ct in (ctypes.c_int64, ctypes.c_uint64), (name, decl)
+            elif decl.startswith("int"):
+                assert ct is ctypes.c_int, (name, decl)
+
+
+def test_argument_errors_are_return_codes(lib):
+    """NULL pointers / bad sizes -> CNR_E_ARG (-1) before anything touches the device."""
+    import cnr_amd
+    for name, argtypes in cnr_amd._C.SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int64 if name in cnr_amd._C._RESTYPE64 else ctypes.c_int
+    assert lib.cnr_version() >= 100
+    assert lib.cnr_pack_bytes() == 62464
+    assert lib.cnr_pe_fwd(None, None, None, 1, 10, 2.0, None) == -1
+    assert lib.cnr_composite_fwd(None, None, None, None, None, None, None, None, 4, 8, 0, None) == -1
+    assert lib.cnr_adamw_step(None, None, None, None, 10, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, 1.0, None, None) == -1
+    assert lib.cnr_step_advance(None, 1, None) == -1
+    assert lib.cnr_field_bwd_workspace_bytes(2, 0) == 2 * 256 * 14592 * 4
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    import cnr_amd
+    monkeypatch.setattr(cnr_amd._C, "_lib", None)
+    monkeypatch.setattr(cnr_amd._C, "LIB_PATH", "/nonexistent/libcnr_hip.so")
+    with pytest.raises(cnr_amd._C.CnrError):
+        cnr_amd._C.load()
+
+
+def test_cpu_tensors_are_rejected():
+    """No CPU fallback: handing a host tensor to a kernel wrapper raises."""
+    import torch
+    import cnr_amd
+    with pytest.raises(cnr_amd._C.CnrError):
+        cnr_amd.ops.UniDirsEmbedFn.apply(torch.zeros(4, 3), torch.zeros(21, 3), 2.0)

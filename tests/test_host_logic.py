@@ -1,0 +1,87 @@
+"""CPU: host logic (autograd Functions, functorch vmap rules, modules, loss assembly, trainer bookkeeping) with the
+kernels replaced by the oracle-backed test double -- the reference's train.py:49-64,88-89,136-184 flow on our
+modules must reproduce the reference's golden losses and gradients."""
+import pytest
+import torch
+
+from conftest import Golden, rel_l2
+
+
+@pytest.fixture()
+def cnr():
+    import cnr_amd
+    from cpu_double import Double
+    cnr_amd._C.install_test_double(Double())
+    yield cnr_amd
+    cnr_amd._C.install_test_double(None)
+
+
+@pytest.mark.parametrize("name", ["s0_c2_r64_s16_l32", "edge_empty_mask", "s0_c1_r120_s10_l256"])
+def test_reference_flow_under_vmap(cnr, name):
+    from test_parity_gpu import _build_reference_style_step
+    g = Golden(name, "cpu")
+    trainers, opt, names, fc_param, pe_param, alpha, color, loss, ld = _build_reference_style_step(cnr, g, torch.device("cpu"))
+    assert alpha.shape == (g.C, g.R, g.S, 1) and color.shape == (g.C, g.R, g.S, 3)
+    assert rel_l2(alpha, g.t("sigmas")) < 1e-5 and rel_l2(color, g.t("rgbs")) < 1e-5
+    assert rel_l2(loss, g.t("loss")) < 1e-5
+    for k in ("depth", "color", "opacity"):
+        assert rel_l2(ld[k], g.t("loss_" + k)) < 1e-5
+    loss.backward()
+    for n, p in zip(names, fc_param):
+        ref = g.t("grad." + n)
+        got = torch.zeros_like(ref) if p.grad is None else p.grad
+        assert rel_l2(got, ref) < 1e-4, n
+    assert rel_l2(pe_param[0].grad, g.t("grad_B")) < 1e-4
+    assert rel_l2(torch.stack([t.shape_codes.weight.grad for t in trainers]), g.t("grad_shape_codes")) < 1e-4
+
+
+def test_state_dict_names_match_reference_checkpoints(cnr):
+    """FC_state_dict / PE_state_dict keys (src/scene_cateogries.py:548-571; names listed in SURVEY section 8(a))."""
+    cfg = cnr.cfg.synthetic_config(device="cpu", latent_dim=32)
+    t = cnr.trainer.Trainer(cfg, 1, [3, 7])
+    keys = list(t.fc_occ_map.state_dict().keys())
+    assert keys[:2] == ["encoding_xyz.0.weight", "encoding_xyz.0.bias"]
+    assert "shape_latent_layer_2.0.weight" in keys and "rgb.2.bias" in keys and len(keys) == 28
+    assert sum(p.numel() for p in t.fc_occ_map.parameters()) == 13892 + 4 * (32 * 32 + 32)
+    assert list(t.pe.state_dict().keys()) == ["scale", "B_layer.weight"]
+    assert t.inst_id_to_index == {3: 0, 7: 1} and t.n_obj == 2 and (t.emb_size1, t.emb_size2) == (87, 42)
+    assert t.shape_codes.weight.shape == (2, 32)
+
+
+def test_flat_layout_and_export(cnr):
+    lay = cnr.fused.ParamLayout(256, 4)
+    assert lay.total == 13892 + 4 * 32 * 256 + 128 + 63 + 2 * 4 * 256
+    flat, _ = cnr.fused.init_params(2, 256, 4, torch.Generator().manual_seed(0))
+    v = lay.views(flat)
+    assert v["trunk"].shape == (2, 13892) and v["latW"].shape == (2, 4, 32, 256) and v["B"].shape == (2, 21, 3)
+    v["B"][1, 0, 0] = 123.0
+    assert flat[1, lay.B[0]] == 123.0          # views alias the flat buffer
+
+
+def test_bias_rows_fold(cnr):
+    """W (a + z) + b == W a + (W z + b): the identity the fused kernels rely on, checked on the fp32 oracle."""
+    from oracle import ref_cpu as O
+    gen = torch.Generator().manual_seed(0)
+    p = O.init_codenerf_params(1, 32, 32, gen)
+    parts = []
+    for n, _, _ in cnr.ops.TRUNK_LAYERS:
+        parts += [p[n + ".weight"].reshape(1, -1), p[n + ".bias"].reshape(1, -1)]
+    trunk = torch.cat(parts, 1)
+    zlat = torch.rand(1, 5, 4, 32, generator=gen)
+    br = cnr.ops.bias_rows(trunk, zlat)
+    W, b = p["shape_layer_2.0.weight"][0], p["shape_layer_2.0.bias"][0]
+    assert torch.allclose(br[0, :, 2], zlat[0, :, 2] @ W.T + b, atol=1e-6)
+    Wc, bc = p["cat_layer.0.weight"][0], p["cat_layer.0.bias"][0]
+    assert torch.allclose(br[0, :, 1], zlat[0, :, 1] @ Wc[:, :32].T + bc, atol=1e-6)
+
+
+def test_synthetic_pool_and_shards(cnr):
+    gen = torch.Generator().manual_seed(3)
+    pool = cnr.scene_cateogries.synthetic_pool(1000, 4, gen, "cpu")
+    assert pool["rgbs"].dtype == torch.uint8 and pool["T_co"].shape == (1000, 4, 4)
+    frac_invalid = float((pool["depth"] == 0).float().mean())
+    assert 0.01 < frac_invalid < 0.12
+    lo, hi = zip(*[cnr.parallel.shard_rows(1000, r, 3) for r in range(3)])
+    assert lo[0] == 0 and hi[-1] == 1000 and all(h == l2 for h, l2 in zip(hi[:-1], lo[1:]))
+    sh = cnr.parallel.shard_pool(pool, 1, 3)
+    assert torch.equal(sh["depth"], pool["depth"][lo[1]:hi[1]])
