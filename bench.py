@@ -99,12 +99,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("CNR_SINGLE_DEVICE_REHEARSAL"):           # N ranks on one card (gloo), 1-GPU boxes only
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     pg = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("CNR_DIST_BACKEND", "nccl")     # nccl = RCCL over xGMI; gloo only for rehearsals
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=dev)
+        else:
+            torch.distributed.init_process_group(backend)
         pg = torch.distributed.group.WORLD
 
     import cnr_amd

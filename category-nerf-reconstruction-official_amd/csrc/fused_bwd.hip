@@ -60,7 +60,7 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   // also a scheduling fence: without it the pre-RA scheduler hoists the next layers' LDS loads across layer
   // boundaries and the live set outgrows the register file (hundreds of scratch spills)
-  __builtin_amdgcn_sched_barrier(0);
+  // __builtin_amdgcn_sched_barrier(0);
 }
 
 // [sample][feature] image of an accumulator-layout tile held as two f16 fragments
