@@ -113,6 +113,9 @@ def main():
             torch.distributed.init_process_group(backend)
         pg = torch.distributed.group.WORLD
 
+    dbg = (lambda *a: print(f"[bench rank {rank}]", *a, file=sys.stderr, flush=True)) if os.environ.get("CNR_BENCH_DEBUG") \
+        else (lambda *a: None)
+    dbg("process group up")
     import cnr_amd
     info = cnr_amd._C.device_info()
     C, R, S, L, n_obj = args.classes, args.rays, args.samples, args.latent, 4
@@ -131,18 +134,25 @@ def main():
             torch.distributed.barrier()
             torch.cuda.synchronize()
 
+    dbg("trainer built")
     for _ in range(max(args.warmup, 4)):
         tr.step()
+    dbg("warmup issued")
     sync()
+    dbg("warmup done")
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i_step in range(args.steps):
         tr.step()
+        if i_step % 8 == 0:
+            dbg("timed step", i_step)
+    dbg("timed loop issued")
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+    dbg("timed region done")
     ms_per_step = dt / args.steps * 1e3
     rays_per_s = world * C * R * args.steps / dt
 
@@ -162,8 +172,14 @@ def main():
     # algorithmic FLOP of that call: fwd = 27 422 / sample, bwd (recompute fwd + dX + dW) = 82 140
     flop_per_sample = 82140 if dom == "cnr_field_bwd" else 27422
     achieved = C * R * S * flop_per_sample / (avg[dom] * 1e-3) / 1e12 if avg[dom] > 0 else 0.0
+    # HBM bytes of that call from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc passes,
+    # gfx950 corrections per MI355X_MICROARCH.md): measured offline on this shape, kept in profiles/
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if dom == "cnr_field_bwd" and (C, R, S) == (1, 2048, 64) and os.path.exists(tpath):
+        traffic = json.load(open(tpath)).get("cnr_field_bwd_call_hbm_bytes")
     roofline = {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_MFMA_F16_TFLOPS, "traffic": None,
+                "frac": achieved / PEAK_MFMA_F16_TFLOPS, "traffic": traffic,
                 "kernel_ms": {k: round(v, 5) for k, v in avg.items()},
                 "step_tflops": world * C * R * S * FLOP_PER_SAMPLE_STEP / (dt / args.steps) / 1e12}
 
