@@ -37,6 +37,8 @@ SIGNATURES = {
     "cnr_pack_weights": [_vp, _vp, _i, _vp],
     "cnr_field_fwd": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _vp],
     "cnr_field_bwd": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i64, _vp],
+    "cnr_field_bwd_pipe": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i64,
+                           _vp],
     "cnr_field_bwd_workspace_bytes": [_i, _i],
 }
 _RESTYPE64 = {"cnr_pack_bytes", "cnr_field_bwd_workspace_bytes"}

@@ -27,22 +27,8 @@
 // the longest-lived activations (a0, a1, a2 and the PE features) are parked in per-wave LDS images already
 // during the forward sweep; those images double as the X operands of the weight-gradient products.
 // One wave per SIMD (512-register budget), 4 waves per workgroup, no workgroup barrier inside the tile loop.
-#include "fused_common.h"
-
+#include "fused_bwd_common.h"
 namespace {
-using namespace fz;
-typedef short s4v __attribute__((ext_vector_type(4)));
-
-enum BlockKind { BK_R2, BK_R0, BK_T1, BK_VD_Y, BK_VD_E0, BK_VD_E1, BK_ES, BK_S2, BK_CAT_Y, BK_CAT_E0, BK_CAT_E1,
-                 BK_CAT_E2, BK_S1, BK_XYZ_E0, BK_XYZ_E1, BK_XYZ_E2, NBLOCKS };
-
-constexpr int ST_H = 72;    // [32 samples][32 features] f16, 64 B + 8 B pad per row
-constexpr int ST_E1 = 208;  // [32][half0: 48 slots | half1: 48 slots] = 192 B + 16 B pad
-constexpr int ST_E2 = 112;  // [32][half0: 24 | half1: 24] = 96 B + 16 B pad
-constexpr int E1IMG_BYTES = 32 * ST_E1 + 128;
-constexpr int E2IMG_BYTES = 32 * ST_E2 + 128;
-constexpr int HIMG_BYTES = 32 * ST_H + 64;
-constexpr int ROWS_LDS = 4;  // rows_per_class <= 4: dbiasrows accumulate in wave-private LDS
 constexpr int WS_E1 = 0, WS_E2 = WS_E1 + E1IMG_BYTES, WS_X = WS_E2 + E2IMG_BYTES, WS_D = WS_X + HIMG_BYTES,
               WS_A0 = WS_D + HIMG_BYTES, WS_A1 = WS_A0 + HIMG_BYTES, WS_A2 = WS_A1 + HIMG_BYTES,
               WS_ROWTAB = WS_A2 + HIMG_BYTES,             // [ROWS_LDS][4][32] f32
@@ -54,168 +40,6 @@ constexpr int LDS_TOTAL = LDS_SCRATCH + 4 * WAVE_SCRATCH;
 static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget");
 static_assert(2 * NBLOCKS * 4096 <= LDS_TOTAL, "the two flush regions alias the whole allocation");
 
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  // also a scheduling fence: without it the pre-RA scheduler hoists the next layers' LDS loads across layer
-  // boundaries and the live set outgrows the register file (hundreds of scratch spills)
-  // __builtin_amdgcn_sched_barrier(0);
-}
-
-// [sample][feature] image of an accumulator-layout tile held as two f16 fragments
-__device__ __forceinline__ void stage_h(unsigned char* img, const h8& f0, const h8& f1, int col, int h) {
-  unsigned char* base = img + col * ST_H + h * 8;
-  *reinterpret_cast<h4*>(base + 0) = f0.lo;
-  *reinterpret_cast<h4*>(base + 16) = f0.hi;
-  *reinterpret_cast<h4*>(base + 32) = f1.lo;
-  *reinterpret_cast<h4*>(base + 48) = f1.hi;
-}
-// this lane's own two fragments back from such an image
-__device__ __forceinline__ void load_h(const unsigned char* img, h8& f0, h8& f1, int col, int h) {
-  const unsigned char* base = img + col * ST_H + h * 8;
-  f0.lo = *reinterpret_cast<const h4*>(base + 0);
-  f0.hi = *reinterpret_cast<const h4*>(base + 16);
-  f1.lo = *reinterpret_cast<const h4*>(base + 32);
-  f1.hi = *reinterpret_cast<const h4*>(base + 48);
-}
-// transposing read: operand fragment (feature = col0 + (lane & 31), k = sample 16 s + 8 h + j)
-__device__ __forceinline__ h8 tr_frag(const unsigned char* img, int stride, int col0, int s, int lane) {
-  const int i = lane & 15, g16 = lane >> 4, q = i >> 2, p = i & 3, hh = g16 >> 1;
-  const unsigned char* a = img + (16 * s + 8 * hh + q) * stride + (col0 + 16 * (g16 & 1) + 4 * p) * 2;
-  typedef __attribute__((address_space(3))) s4v* lds_s4;
-  const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(a));
-  const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(a + 4 * stride));
-  h8 r;
-  r.lo = __builtin_bit_cast(h4, lo);
-  r.hi = __builtin_bit_cast(h4, hi);
-  return r;
-}
-__device__ __forceinline__ f16v zero16() {
-  f16v z;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) z[i] = 0.0f;
-  return z;
-}
-__device__ __forceinline__ h8 zero8() {
-  h8 z;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) z[i] = (_Float16)0;
-  return z;
-}
-// dpre = upstream * (activation > 0) for the 8 accumulator registers of k-step s
-__device__ __forceinline__ void mask8(f16v& a, int s, const h8& act) {
-#pragma unroll
-  for (int j = 0; j < 8; ++j) a[8 * s + j] = (act[j] > (_Float16)0) ? a[8 * s + j] : 0.0f;
-}
-
-// trunk-blob index of element (out row o, image column c) of a dW block ; -1 = not a parameter
-__device__ __forceinline__ int block_index(int kind, int o, int c) {
-  int f;
-  switch (kind) {
-    case BK_R2: if (o >= 3) return -1; return c < 16 ? OFF_R2_W + o * 16 + c : (c == 16 ? OFF_R2_B + o : -1);
-    case BK_R0: return o < 16 ? OFF_R0_W + o * 32 + c : -1;
-    case BK_T1: return OFF_T1_W + o * 32 + c;
-    case BK_VD_Y: return OFF_VD_W + o * (32 + E2) + c;
-    case BK_VD_E0: case BK_VD_E1: {
-      const int cc = c + (kind == BK_VD_E1 ? 32 : 0);
-      if (cc >= 48) return -1;
-      const int hh = cc / 24, q = cc % 24;
-      if (hh == 0 && q == 22) return OFF_VD_B + o;
-      f = slot_feature(1, hh, q);
-      return f < 0 ? -1 : OFF_VD_W + o * (32 + E2) + 32 + (f - E1); }
-    case BK_ES: return OFF_ES_W + o * 32 + c;
-    case BK_S2: return OFF_S2_W + o * 32 + c;
-    case BK_CAT_Y: return OFF_CAT_W + o * (32 + E1) + c;
-    case BK_CAT_E0: case BK_CAT_E1: case BK_CAT_E2: {
-      const int cc = c + 32 * (kind - BK_CAT_E0);
-      f = slot_feature(0, cc / 48, cc % 48);
-      return f < 0 ? -1 : OFF_CAT_W + o * (32 + E1) + 32 + f; }
-    case BK_S1: return OFF_S1_W + o * 32 + c;
-    default: {
-      const int cc = c + 32 * (kind - BK_XYZ_E0);
-      const int hh = cc / 48, q = cc % 48;
-      if (hh == 0 && q == 47) return OFF_XYZ_B + o;
-      f = slot_feature(0, hh, q);
-      return f < 0 ? -1 : OFF_XYZ_W + o * E1 + f; }
-  }
-}
-
-constexpr int REC_FLOATS = ((TRUNK + 126 + ROWS_LDS * 128 + 255) / 256) * 256;  // one workgroup's record
-
-// sum over the 32 lanes of each wave half with DPP row operations (6 VALU ops; __shfl_xor lowers to
-// ds_bpermute, ~80 dependent cycles each): afterwards lane 31 holds the sum of lanes 0..31, lane 63 of 32..63
-__device__ __forceinline__ float half_sum_dpp(float v) {
-  int x = __builtin_bit_cast(int, v);
-#define CNR_DPP_ADD(CTRL, ROWMASK)                                                                     \
-  x = __builtin_bit_cast(int, __builtin_bit_cast(float, x) +                                           \
-                                  __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, CTRL, ROWMASK, 0xf, true)))
-  CNR_DPP_ADD(0x111, 0xf);  // row_shr:1
-  CNR_DPP_ADD(0x112, 0xf);  // row_shr:2
-  CNR_DPP_ADD(0x114, 0xf);  // row_shr:4
-  CNR_DPP_ADD(0x118, 0xf);  // row_shr:8   -> lane 15 of every 16-lane row holds the row sum
-  CNR_DPP_ADD(0x142, 0xa);  // row_bcast:15 into rows 1 and 3 -> lanes 31 / 63 hold the half sums
-#undef CNR_DPP_ADD
-  return __builtin_bit_cast(float, x);
-}
-
-// For every trunk parameter: where its gradient sits in the two-region LDS image of the 16 dW blocks
-// ((kind << 10) | (row << 5) | col), or -1 when it does not come from a block.  Built once per process.
-__device__ int g_param_src[TRUNK];
-__global__ void build_param_src_kernel() {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < TRUNK; i += gridDim.x * blockDim.x) g_param_src[i] = -1;
-}
-__global__ void fill_param_src_kernel() {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < NBLOCKS * 1024; i += gridDim.x * blockDim.x) {
-    const int idx = block_index(i >> 10, (i >> 5) & 31, i & 31);
-    if (idx >= 0) g_param_src[idx] = i;
-  }
-}
-
-// Fixed-order sum of the per-workgroup records into the (accumulated) outputs.  256 threads = 64 record entries x
-// 4 quarters of the workgroup range; each quarter keeps 8 loads in flight, the quarters are combined through LDS in
-// a fixed order.  Entries no launch writes (latent-layer biases, padding, unused row sums) are skipped, so the
-// workspace needs no clearing.
-__device__ __forceinline__ bool rec_entry_written(int i, int rows_per_class) {
-  if (i < TRUNK)
-    return !((i >= OFF_S1_B && i < OFF_S1_B + 32) || (i >= OFF_CAT_B && i < OFF_CAT_B + 32) ||
-             (i >= OFF_S2_B && i < OFF_S2_B + 32) || (i >= OFF_T1_B && i < OFF_T1_B + 32));
-  if (i < TRUNK + 126) return true;
-  return rows_per_class <= ROWS_LDS && (i - (TRUNK + 126)) < rows_per_class * 128;
-}
-__global__ __launch_bounds__(256) void reduce_records_kernel(const float* __restrict__ records, int nwg,
-                                                             float* __restrict__ dtrunk, float* __restrict__ dB,
-                                                             float* __restrict__ dbiasrows, int rows_per_class) {
-  __shared__ float part[4][64];
-  const int c = blockIdx.y;
-  const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
-  const int i = blockIdx.x * 64 + e;
-  const bool live = i < REC_FLOATS && rec_entry_written(i, rows_per_class);
-  float s = 0.0f;
-  if (live) {
-    const int per = (nwg + 3) / 4, w0 = q * per, w1 = min(nwg, w0 + per);
-    const float* r = records + (size_t)c * nwg * REC_FLOATS + i;
-    float a[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) a[u] = 0.0f;
-    int w = w0;
-    for (; w + 7 < w1; w += 8) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) a[u] += r[(size_t)(w + u) * REC_FLOATS];
-    }
-    for (; w < w1; ++w) a[0] += r[(size_t)w * REC_FLOATS];
-    s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-  }
-  part[q][e] = s;
-  __syncthreads();
-  if (q == 0 && live) {
-    const float v = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
-    if (i < TRUNK) dtrunk[(size_t)c * TRUNK + i] += v;
-    else if (i < TRUNK + 63) atomicAdd(&dB[(size_t)c * 63 + (i - TRUNK)], v);        // two addends per element
-    else if (i < TRUNK + 126) atomicAdd(&dB[(size_t)c * 63 + (i - TRUNK - 63)], v);
-    else dbiasrows[(size_t)c * rows_per_class * 128 + (i - (TRUNK + 126))] += v;
-  }
-}
 
 template <bool BIG_S, int PART>
 __global__ __launch_bounds__(256, 1) void field_bwd_kernel(

@@ -158,9 +158,8 @@ class FusedCategoryTrainer:
         if "bwd_ws" not in o:
             o["bwd_ws"] = torch.empty(_C.field_bwd_workspace_bytes(C, self.bwd_blocks), device=self.device,
                                       dtype=torch.uint8)
-        _C.call("cnr_field_bwd", b["pts"], Bc, packed, brows, ray_row, self.scale, o["dsig"], o["drgb"],
-                self.grad_scale, dtrunk, dB, self.dbias, C, R, S, n_obj, self.bwd_blocks, o["bwd_ws"],
-                o["bwd_ws"].numel())
+        ops.field_bwd(b["pts"], Bc, packed, brows, ray_row, self.scale, o["dsig"], o["drgb"],
+                      self.grad_scale, dtrunk, dB, self.dbias, C, R, S, n_obj, self.bwd_blocks, o["bwd_ws"])
         if C > 1:
             gv["trunk"].copy_(dtrunk)
             gv["B"].copy_(dB)

@@ -5,6 +5,8 @@ parameter rank) and carries a ``vmap`` rule, so the reference's own
 ``functorch.combine_state_for_ensemble`` + ``vmap(fmodel)(params, buffers, *stacked_inputs)``
 (src/utils.py:24-28, train.py:154-155) dispatches straight into the class-batched kernels.
 """
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -301,6 +303,24 @@ def pack_weights(trunk):
     return packed
 
 
+# cnr_field_bwd variants: "split" = two block-split launches (csrc/fused_bwd.hip), "pipe2"/"pipe3" = the single
+# pipelined launch with 2 / 3 chain waves per workgroup (csrc/fused_bwd_pipe.hip).  Same results contract.
+FIELD_BWD_VARIANT = os.environ.get("CNR_FIELD_BWD", "split")
+
+
+def field_bwd(pts, B, packed, biasrows, ray_row, scale, d_sig, d_rgb, grad_scale, dtrunk, dB, dbiasrows, C, R, S,
+              rows_per_class, max_blocks, workspace, variant=None):
+    v = variant or FIELD_BWD_VARIANT
+    if v == "split":
+        _C.call("cnr_field_bwd", pts, B, packed, biasrows, ray_row, scale, d_sig, d_rgb, grad_scale, dtrunk, dB,
+                dbiasrows, C, R, S, rows_per_class, max_blocks, workspace, workspace.numel())
+    elif v in ("pipe2", "pipe3"):
+        _C.call("cnr_field_bwd_pipe", pts, B, packed, biasrows, ray_row, scale, d_sig, d_rgb, grad_scale, dtrunk,
+                dB, dbiasrows, C, R, S, rows_per_class, max_blocks, int(v[-1]), workspace, workspace.numel())
+    else:
+        raise ValueError(f"unknown cnr_field_bwd variant {v!r}")
+
+
 def field_fwd(pts, B, packed, biasrows, ray_row, scale):
     """pts (C,R,S,3) -> sigmas (C,R,S), rgbs (C,R,S,3); biasrows (rows,4,32) flat over classes."""
     C, R, S, _ = pts.shape
@@ -339,7 +359,7 @@ class FusedFieldFn(Function):
         dbr = torch.zeros_like(biasrows, memory_format=torch.contiguous_format)
         wsb = _C.field_bwd_workspace_bytes(C, ctx.mb)
         wsp = torch.empty(wsb, device=pts.device, dtype=torch.uint8)
-        _C.call("cnr_field_bwd", pts.contiguous(), B.contiguous(), packed, biasrows.contiguous(), ctx.ray_row,
-                ctx.scale, d_sig.contiguous(), d_rgb.contiguous(), ctx.gs, dtrunk, dB, dbr, C, R, S, ctx.rpc, ctx.mb,
-                wsp, wsb)
+        field_bwd(pts.contiguous(), B.contiguous(), packed, biasrows.contiguous(), ctx.ray_row,
+                  ctx.scale, d_sig.contiguous(), d_rgb.contiguous(), ctx.gs, dtrunk, dB, dbr, C, R, S, ctx.rpc, ctx.mb,
+                  wsp)
         return None, dB, dtrunk, dbr, None, None, None, None, None

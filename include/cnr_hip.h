@@ -189,6 +189,16 @@ int cnr_field_bwd(const float* pts, const float* B, const void* packed, const fl
                   float grad_scale, float* dtrunk, float* dB, float* dbiasrows, int C, int R, int S,
                   int rows_per_class, int max_blocks, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Same contract and results as cnr_field_bwd, ONE field kernel + the record reduction: each workgroup is
+ * `chain_waves` (2 or 3) waves that run forward recompute + data-gradient chain + PE backward for one 32-sample
+ * tile each, plus 4 - chain_waves waves that own the weight-gradient accumulators and consume the chain waves'
+ * per-layer images one workgroup barrier behind (csrc/fused_bwd_pipe.hip).  max_blocks / workspace as above. */
+int cnr_field_bwd_pipe(const float* pts, const float* B, const void* packed, const float* biasrows,
+                       const int* ray_row, float scale, const float* d_sigma, const float* d_rgb,
+                       float grad_scale, float* dtrunk, float* dB, float* dbiasrows, int C, int R, int S,
+                       int rows_per_class, int max_blocks, int chain_waves, void* workspace,
+                       int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -93,6 +93,13 @@ def test_fused_forward_full_size(cnr, dev, C, R, S, L, wscale):
 
 
 # ---- fused backward ----------------------------------------------------------------------------------
+@pytest.fixture(params=["split", "pipe2", "pipe3"])
+def bwd_variant(request, cnr, monkeypatch):
+    """every cnr_field_bwd implementation must meet the same bars (ops.field_bwd dispatches on this)."""
+    monkeypatch.setattr(cnr.ops, "FIELD_BWD_VARIANT", request.param)
+    return request.param
+
+
 def _fused_step(cnr, g, dev, grad_scale, max_blocks=0):
     """Full train-step graph on the fused kernels: torch holds the flat trunk, latent layers and codes."""
     mlp = g.mlp()
@@ -200,7 +207,7 @@ def _torch_loss(sig, rgb, g):
 
 
 @pytest.mark.parametrize("name", golden_names())
-def test_fused_backward_vs_emulated_f16(cnr, dev, name):
+def test_fused_backward_vs_emulated_f16(cnr, dev, name, bwd_variant):
     """Kernel gradients == autograd of the torch emulation of the same f16 pipeline (same ReLU masks up to
     fp32 summation order): 5e-3 relative L2 on the whole trunk gradient, 2e-2 per tensor (one unit whose
     pre-activation is ~1e-6 can still flip between MFMA and torch.matmul summation order: 1.5e-2 on the
@@ -233,7 +240,7 @@ def test_fused_backward_vs_emulated_f16(cnr, dev, name):
 
 
 @pytest.mark.parametrize("name", golden_names())
-def test_fused_backward_vs_fp32_reference(cnr, dev, name):
+def test_fused_backward_vs_fp32_reference(cnr, dev, name, bwd_variant):
     """Against the reference's fp32 autograd gradients.  The f16 forward (1e-3) flips the ReLU mask of the
     ~0.1 % of units whose pre-activation is within 1e-3 of zero; each flip toggles a whole contribution, so the
     gradient differs by ~sqrt(1e-3) = 3 % in relative L2 while pointing the same way.  Bars: 0.15 relative L2

@@ -34,10 +34,20 @@ def run(C, R, S, blocks, iters=50):
         b.record(); torch.cuda.synchronize()
         return a.elapsed_time(b) / iters * 1e3
     fwd = t(lambda: _C.call("cnr_field_fwd", pts, B, packed, brows, ray_row, 2.0, sig, rgb, C, R, S))
-    bwd = t(lambda: _C.call("cnr_field_bwd", pts, B, packed, brows, ray_row, 2.0, dsig, drgb, 2048.0, dtrunk, dB, dbr,
-                            C, R, S, n_obj, blocks, wsp, wsp.numel()))
     n = C * R * S
-    print(f"C{C} R{R} S{S} blocks{blocks}: fwd {fwd:8.1f} us ({n*27422/fwd/1e6:7.1f} TF)   bwd {bwd:8.1f} us ({n*82140/bwd/1e6:7.1f} TF)")
+    line = f"C{C} R{R} S{S} blocks{blocks}: fwd {fwd:8.1f} us ({n*27422/fwd/1e6:7.1f} TF)"
+    ref = None
+    for variant in ("split", "pipe2", "pipe3"):
+        dtrunk.zero_(); dB.zero_(); dbr.zero_()
+        ops.field_bwd(pts, B, packed, brows, ray_row, 2.0, dsig, drgb, 2048.0, dtrunk, dB, dbr, C, R, S, n_obj, blocks,
+                      wsp, variant=variant)
+        got = torch.cat([dtrunk.flatten(), dB.flatten(), dbr.flatten()]).clone()
+        if ref is None: ref = got
+        err = ((got - ref).norm() / ref.norm()).item()
+        bwd = t(lambda: ops.field_bwd(pts, B, packed, brows, ray_row, 2.0, dsig, drgb, 2048.0, dtrunk, dB, dbr, C, R, S,
+                                      n_obj, blocks, wsp, variant=variant))
+        line += f" | {variant} {bwd:8.1f} us ({n*82140/bwd/1e6:6.1f} TF) d={err:.1e}"
+    print(line, flush=True)
 
 
 for (C, R, S, blocks) in [(1, 2048, 64, 0), (1, 2048, 64, 128), (1, 2048, 64, 64), (1, 8192, 128, 0), (1, 8192, 128, 128), (1, 64, 32, 0), (1, 64, 32, 1)]:

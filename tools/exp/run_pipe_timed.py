@@ -1,0 +1,41 @@
+"""Cycle stamps of the pipelined field backward (build: see tools/exp/build_pipe_timed.sh)."""
+import sys, os, ctypes
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import torch
+import cnr_amd
+from cnr_amd import ops, _C
+lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libpipetimed.so"))
+dev = torch.device("cuda:0")
+L, n_obj = 256, 4
+C, R, S, NCH = 1, int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+gen = torch.Generator().manual_seed(0)
+theta, lay = cnr_amd.fused.init_params(C, L, n_obj, gen, dev)
+v = lay.views(theta)
+packed = ops.pack_weights(v["trunk"].contiguous())
+pts = (torch.rand(C, R, S, 3, device=dev) * 2 - 1)
+B = v["B"].contiguous()
+brows = torch.randn(C * n_obj, 4, 32, device=dev) * 0.1
+ray_row = (torch.randint(0, n_obj, (C, R), device=dev)).to(torch.int32)
+dsig = torch.randn(C, R, S, device=dev) * 1e-3
+drgb = torch.randn(C, R, S, 3, device=dev) * 1e-3
+dtrunk = torch.zeros(C, 13892, device=dev); dB = torch.zeros(C, 21, 3, device=dev); dbr = torch.zeros_like(brows)
+vp = ctypes.c_void_p
+fn = lib.cnr_field_bwd_pipe
+fn.argtypes = [vp, vp, vp, vp, vp, ctypes.c_float, vp, vp, ctypes.c_float, vp, vp, vp] + [ctypes.c_int] * 6 + [vp, ctypes.c_int64, vp]
+wsp = torch.empty(_C.field_bwd_workspace_bytes(C, 0), device=dev, dtype=torch.uint8)
+for it in range(3):
+    rc = fn(pts.data_ptr(), B.data_ptr(), packed.data_ptr(), brows.data_ptr(), ray_row.data_ptr(), 2.0, dsig.data_ptr(), drgb.data_ptr(),
+            2048.0, dtrunk.data_ptr(), dB.data_ptr(), dbr.data_ptr(), C, R, S, n_obj, 0, NCH, wsp.data_ptr(), wsp.numel(), None)
+    torch.cuda.synchronize()
+    buf = (ctypes.c_longlong * 128)()
+    lib.cnr_pipe_read_stamps(buf)
+    for role, name in ((0, "chain"), (1, "dW   ")):
+        st = list(buf)[role * 64: role * 64 + 21]
+        # stamps: 0 = iteration start, then (before barrier, after barrier) x 10
+        work = [st[1] - st[0]] + [st[2 * k + 1] - st[2 * k] for k in range(1, 10)]
+        wait = [st[2 * k + 2] - st[2 * k + 1] for k in range(10)]
+        print(rc, name, "work", work, "wait", wait, "total", st[20] - st[0])
+    f = list(buf)[40:46]
+    print("   fwd: start->loads/pe", f[0] - buf[0], "pe+imgs", f[1] - f[0], "xyz", f[2] - f[1], "s1,cat,s2", f[3] - f[2],
+          "es", f[4] - f[3], "vd,t1,r0,r2", f[5] - f[4], "to barrier", buf[1] - f[5])
