@@ -157,7 +157,8 @@ def main():
     rays_per_s = world * C * R * args.steps / dt
 
     # ---- roofline leg: the dominant kernel (fused backward) timed with HIP events on its launch stream ----
-    names = ["cnr_field_bwd", "cnr_field_fwd", "cnr_composite_fwd", "cnr_composite_bwd", "cnr_loss_fwd_bwd",
+    bwd_name = "cnr_field_bwd" if cnr_amd.ops.FIELD_BWD_VARIANT == "split" else "cnr_field_bwd_pipe"
+    names = [bwd_name, "cnr_field_fwd", "cnr_composite_fwd", "cnr_composite_bwd", "cnr_loss_fwd_bwd",
              "cnr_sample_rays", "cnr_adamw_step", "cnr_pack_weights"]
     saved_graph, tr.graph, tr.use_graph = tr.graph, None, False   # eager so that events bracket single launches
     cnr_amd._C.enable_kernel_timing(names)
@@ -166,20 +167,21 @@ def main():
     tms = cnr_amd._C.kernel_timings_ms()
     tr.graph, tr.use_graph = saved_graph, not args.no_graph
     avg = {k: (sum(v) / len(v) if v else 0.0) for k, v in tms.items()}
-    dom = max(("cnr_field_bwd", "cnr_field_fwd"), key=lambda k: avg[k])
-    # cnr_field_bwd = one memset node + the texture and geometry launches of field_bwd_kernel + reduce_records:
+    dom = max((bwd_name, "cnr_field_fwd"), key=lambda k: avg[k])
+    # the backward call = the field kernel(s) (pipe: one launch; split: texture + geometry launches) + reduce_records:
     # its duration is the sum of those (rocprof lists them separately, profiles/).
     # algorithmic FLOP of that call: fwd = 27 422 / sample, bwd (recompute fwd + dX + dW) = 82 140
-    flop_per_sample = 82140 if dom == "cnr_field_bwd" else 27422
+    flop_per_sample = 82140 if dom == bwd_name else 27422
     achieved = C * R * S * flop_per_sample / (avg[dom] * 1e-3) / 1e12 if avg[dom] > 0 else 0.0
     # HBM bytes of that call from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc passes,
     # gfx950 corrections per MI355X_MICROARCH.md): measured offline on this shape, kept in profiles/
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if dom == "cnr_field_bwd" and (C, R, S) == (1, 2048, 64) and os.path.exists(tpath):
-        traffic = json.load(open(tpath)).get("cnr_field_bwd_call_hbm_bytes")
+    if dom == bwd_name and (C, R, S) == (1, 2048, 64) and os.path.exists(tpath):
+        traffic = json.load(open(tpath)).get(bwd_name + "_call_hbm_bytes")
     roofline = {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_MFMA_F16_TFLOPS, "traffic": traffic,
+                "variant": cnr_amd.ops.FIELD_BWD_VARIANT,
                 "kernel_ms": {k: round(v, 5) for k, v in avg.items()},
                 "step_tflops": world * C * R * S * FLOP_PER_SAMPLE_STEP / (dt / args.steps) / 1e12}
 

@@ -31,12 +31,12 @@ static_assert(p_lds_total<3>() <= 160 * 1024 && p_lds_total<2>() <= 160 * 1024, 
 
 // backward layer steps, in order
 #ifdef CNR_PIPE_STAMPS  // tools/exp only: cycle stamps of one chain wave and one dW wave of workgroup 0
-__device__ long long g_pipe_stamps[128];
-#define PSTAMP() do { if (blockIdx.x == 0 && lane == 0 && (wv == 0 || wv == 3)) \
-    g_pipe_stamps[(wv == 3) * 64 + (pstamp_i++)] = (long long)__builtin_readcyclecounter(); } while (0)
+__device__ long long g_pipe_stamps[160];
+#define PSTAMP() do { if (blockIdx.x == 0 && lane == 0) \
+    g_pipe_stamps[wv * 32 + (pstamp_i++)] = (long long)__builtin_readcyclecounter(); } while (0)
 #define PSTAMP_RESET() int pstamp_i = 0
 #define FSTAMP(k) do { if (blockIdx.x == 0 && lane == 0 && wv == 0) \
-    g_pipe_stamps[40 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
+    g_pipe_stamps[128 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
 #define FSTAMP(k) do {} while (0)
 #define PSTAMP() do {} while (0)
@@ -115,7 +115,8 @@ __global__ __launch_bounds__(256, 1) void field_bwd_pipe_kernel(
     unsigned char* A0img = cw + CW_A0;
     unsigned char* A1img = cw + CW_A1;
     unsigned char* A2img = cw + CW_A2;
-    int* rowidx = reinterpret_cast<int*>(cw + CW_SMALL);
+    // [5][32 samples] f16: rows 0..3 = (object row of sample k == r), row 4 = ones: the dW wave's row-sum operand
+    _Float16* rowoh = reinterpret_cast<_Float16*>(cw + CW_SMALL);
     const float* Bl_h = reinterpret_cast<const float*>(smem + P_LDS_BL) + 33 * h;
     auto slot_D = [&](int step) { return cw + CW_SLOT + (step & 1) * SLOT_BYTES; };
 
@@ -144,6 +145,15 @@ __global__ __launch_bounds__(256, 1) void field_bwd_pipe_kernel(
     auto clamp_tile = [&](int t) { return t < ntiles ? t : ntiles - 1; };  // past the end: a dead tile (all zero)
     int tile = blockIdx.x * NCH + wv;
     load_inputs(clamp_tile(tile));
+    // PE features of the tile, computed one tile ahead (under the dW wave's last products of the previous tile)
+    h8 E1f[6], E2f[3];
+    auto pe_features = [&]() {
+      float Bh[33];
+#pragma unroll
+      for (int i = 0; i < 33; ++i) Bh[i] = Bl_h[i];
+      pe_slots<true>(Bh, in_p0 * inv_scale, in_p1 * inv_scale, in_p2 * inv_scale, h, E1f, E2f);
+    };
+    pe_features();
 
     for (int t0 = blockIdx.x * NCH; t0 < ntiles; t0 += tile_step, tile += tile_step) {
       asm volatile("" ::: "memory");
@@ -156,9 +166,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_pipe_kernel(
       const float dr0 = tile_ok ? in_r0 * gscale : 0.0f, dr1 = tile_ok ? in_r1 * gscale : 0.0f,
                   dr2 = tile_ok ? in_r2 * gscale : 0.0f;
       const int row = in_row;
-      if (h == 0) rowidx[col] = row;
       const float* brow_l = reinterpret_cast<const float*>(smem + P_LDS_BR) + (row - c * rows_per_class) * 128;
-      auto bias_init = [&](int k) { return acc_init(brow_l + k * 32, h); };
 
       auto pe_backward = [&](const f16v (&de)[3], int nblk, int band0, int nq) {
         float pd[11], gpa[11];
@@ -189,13 +197,19 @@ __global__ __launch_bounds__(256, 1) void field_bwd_pipe_kernel(
       };
 
       // ------------------------------- forward recompute --------------------------------------------
+      // Every layer's weight fragments and bias are fetched while the previous layer's MFMAs are in flight, in
+      // source order BEFORE that layer's image stores (LDS reads cannot be hoisted over the stores by the compiler).
       FSTAMP(0);
-      h8 E1f[6], E2f[3];
-      {
-        float Bh[33];
+      h8 wq[8];
+      f16v acc, bq;
 #pragma unroll
-        for (int i = 0; i < 33; ++i) Bh[i] = Bl_h[i];
-        pe_slots<true>(Bh, t0x, t1x, t2x, h, E1f, E2f);
+      for (int s = 0; s < 6; ++s) wq[s] = lds_frag(smem, KK_XYZ + s, lane);
+      acc = acc_init(cf + CF_B_XYZ, h);
+      {
+        const int rl = row - c * rows_per_class;
+        rowoh[(2 * h + 0) * 32 + col] = rl == 2 * h + 0 ? (_Float16)1 : (_Float16)0;
+        rowoh[(2 * h + 1) * 32 + col] = rl == 2 * h + 1 ? (_Float16)1 : (_Float16)0;
+        if (h == 0) rowoh[4 * 32 + col] = (_Float16)1;
       }
       {
         unsigned char* b1 = E1img + col * ST_E1 + h * 96;
@@ -206,59 +220,70 @@ __global__ __launch_bounds__(256, 1) void field_bwd_pipe_kernel(
         for (int s = 0; s < 3; ++s) *reinterpret_cast<h8*>(b2 + 16 * s) = E2f[s];
       }
       FSTAMP(1);
-      f16v acc = acc_init(cf + CF_B_XYZ, h);
 #pragma unroll
-      for (int s = 0; s < 6; ++s) acc = MFMA(lds_frag(smem, KK_XYZ + s, lane), E1f[s], acc);
+      for (int s = 0; s < 6; ++s) acc = MFMA(wq[s], E1f[s], acc);
+      wq[0] = lds_frag(smem, KK_S1 + 0, lane); wq[1] = lds_frag(smem, KK_S1 + 1, lane);
+      bq = acc_init(brow_l + 0 * 32, h);
       FSTAMP(2);
       {
         const h8 a = pack8(acc, 0, true), b = pack8(acc, 1, true);  // a0
+        acc = MFMA(wq[0], a, bq);
+        acc = MFMA(wq[1], b, acc);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) wq[s] = lds_frag(smem, KK_CAT + s, lane);
+        bq = acc_init(brow_l + 1 * 32, h);
         stage_h(A0img, a, b, col, h);
-        acc = bias_init(0);
-        acc = MFMA(lds_frag(smem, KK_S1 + 0, lane), a, acc);
-        acc = MFMA(lds_frag(smem, KK_S1 + 1, lane), b, acc);
       }
       {
         const h8 a = pack8(acc, 0, true), b = pack8(acc, 1, true);  // a1
-        stage_h(A1img, a, b, col, h);
-        acc = bias_init(1);
-        acc = MFMA(lds_frag(smem, KK_CAT + 0, lane), a, acc);
-        acc = MFMA(lds_frag(smem, KK_CAT + 1, lane), b, acc);
+        acc = MFMA(wq[0], a, bq);
+        acc = MFMA(wq[1], b, acc);
 #pragma unroll
-        for (int s = 0; s < 6; ++s) acc = MFMA(lds_frag(smem, KK_CAT + 2 + s, lane), E1f[s], acc);
+        for (int s = 0; s < 6; ++s) acc = MFMA(wq[2 + s], E1f[s], acc);
+        wq[0] = lds_frag(smem, KK_S2 + 0, lane); wq[1] = lds_frag(smem, KK_S2 + 1, lane);
+        bq = acc_init(brow_l + 2 * 32, h);
+        stage_h(A1img, a, b, col, h);
       }
       {
         const h8 a = pack8(acc, 0, true), b = pack8(acc, 1, true);  // a2
+        acc = MFMA(wq[0], a, bq);
+        acc = MFMA(wq[1], b, acc);
+        wq[0] = lds_frag(smem, KK_ES + 0, lane); wq[1] = lds_frag(smem, KK_ES + 1, lane);
+        bq = acc_init(cf + CF_B_ES, h);
         stage_h(A2img, a, b, col, h);
-        acc = bias_init(2);
-        acc = MFMA(lds_frag(smem, KK_S2 + 0, lane), a, acc);
-        acc = MFMA(lds_frag(smem, KK_S2 + 1, lane), b, acc);
       }
       FSTAMP(3);
       const h8 A3a = pack8(acc, 0, true), A3b = pack8(acc, 1, true);
-      acc = acc_init(cf + CF_B_ES, h);
-      acc = MFMA(lds_frag(smem, KK_ES + 0, lane), A3a, acc);
-      acc = MFMA(lds_frag(smem, KK_ES + 1, lane), A3b, acc);
+      acc = MFMA(wq[0], A3a, bq);
+      acc = MFMA(wq[1], A3b, acc);
+#pragma unroll
+      for (int s = 0; s < 5; ++s) wq[s] = lds_frag(smem, KK_VD + s, lane);
+      bq = acc_init(cf + CF_B_VD, h);
 #pragma unroll
       for (int i = 0; i < 16; ++i) DWS(i) = fmaf(draw, acc[i], DWS(i));  // d w_sigma += draw * y4
       DBS += (h == 0) ? draw : 0.0f;
       FSTAMP(4);
       const h8 Y4a = pack8(acc, 0, false), Y4b = pack8(acc, 1, false);
-      acc = acc_init(cf + CF_B_VD, h);
-      acc = MFMA(lds_frag(smem, KK_VD + 0, lane), Y4a, acc);
-      acc = MFMA(lds_frag(smem, KK_VD + 1, lane), Y4b, acc);
+      acc = MFMA(wq[0], Y4a, bq);
+      acc = MFMA(wq[1], Y4b, acc);
 #pragma unroll
-      for (int s = 0; s < 3; ++s) acc = MFMA(lds_frag(smem, KK_VD + 2 + s, lane), E2f[s], acc);
+      for (int s = 0; s < 3; ++s) acc = MFMA(wq[2 + s], E2f[s], acc);
+      wq[0] = lds_frag(smem, KK_T1 + 0, lane); wq[1] = lds_frag(smem, KK_T1 + 1, lane);
+      bq = acc_init(brow_l + 3 * 32, h);
       const h8 A5a = pack8(acc, 0, true), A5b = pack8(acc, 1, true);
-      acc = bias_init(3);
-      acc = MFMA(lds_frag(smem, KK_T1 + 0, lane), A5a, acc);
-      acc = MFMA(lds_frag(smem, KK_T1 + 1, lane), A5b, acc);
+      acc = MFMA(wq[0], A5a, bq);
+      acc = MFMA(wq[1], A5b, acc);
+      wq[0] = lds_frag(smem, KK_R0 + 0, lane); wq[1] = lds_frag(smem, KK_R0 + 1, lane);
+      bq = acc_init(cf + CF_B_R0, h);
       const h8 A6a = pack8(acc, 0, true), A6b = pack8(acc, 1, true);
-      acc = acc_init(cf + CF_B_R0, h);
-      acc = MFMA(lds_frag(smem, KK_R0 + 0, lane), A6a, acc);
-      acc = MFMA(lds_frag(smem, KK_R0 + 1, lane), A6b, acc);
+      acc = MFMA(wq[0], A6a, bq);
+      acc = MFMA(wq[1], A6b, acc);
+      wq[0] = lds_frag(smem, KK_R2, lane);
+      wq[1] = lds_frag(bwf, KT_R2, lane);
+      bq = acc_init(cf + CF_B_R2, h);
       const h8 A7a = pack8(acc, 0, true);
-      acc = acc_init(cf + CF_B_R2, h);
-      acc = MFMA(lds_frag(smem, KK_R2, lane), A7a, acc);
+      acc = MFMA(wq[0], A7a, bq);
+      h8 Wn0 = lds_frag(bwf, KT_R0, lane), Wn1;
       FSTAMP(5);
 
       // ---- step ST_R2: dPre9 = drgb * rgb (1 - rgb) in rows 0..2 (registers 0..2 of half 0)
@@ -272,6 +297,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_pipe_kernel(
           D0[2] = (_Float16)(dr2 * r2 * (1.0f - r2));
         }
       }
+      acc = MFMA(wq[1], D0, zero16());  // d a7 (rows 0..15)
       // staged into feature columns 16..18: the dW wave accumulates rgb.2 into rows 16..18 of rgb.0's block
       // (rgb.0 has 16 outputs), which frees one accumulator block for the row sums
       stage_h(slot_D(ST_R2), D1, D0, col, h);
@@ -280,108 +306,110 @@ __global__ __launch_bounds__(256, 1) void field_bwd_pipe_kernel(
         if (h == 0) one[0] = (_Float16)1;  // feature 16 of the a7 image := 1 -> d b(rgb.2)
         stage_h(slot_D(ST_R2) + HIMG_BYTES, A7a, one, col, h);
       }
-      acc = MFMA(lds_frag(bwf, KT_R2, lane), D0, zero16());  // d a7 (rows 0..15)
       D0 = pack8_masked(acc, 0, A7a); D1 = zero8();
-      // the weight fragments of the next step are fetched before each barrier (the barrier's fence would
-      // otherwise pin their LDS reads behind it, in front of the MFMA that needs them)
-      h8 Wn0 = lds_frag(bwf, KT_R0, lane), Wn1;
+      // (the weight fragments of the next step are fetched before each barrier: its fence would otherwise pin
+      //  their LDS reads behind it, in front of the MFMA that needs them)
       PSYNC();
       // ---- step ST_R0 ------------------------------------------------------------------------------
+      acc = MFMA(Wn0, D0, zero16());  // d a6
+      Wn0 = lds_frag(bwf, KT_T1 + 0, lane); Wn1 = lds_frag(bwf, KT_T1 + 1, lane);
       stage_h(slot_D(ST_R0), D0, D1, col, h);
       stage_h(slot_D(ST_R0) + HIMG_BYTES, A6a, A6b, col, h);
-      acc = MFMA(Wn0, D0, zero16());  // d a6
       D0 = pack8_masked(acc, 0, A6a); D1 = pack8_masked(acc, 1, A6b);
-      Wn0 = lds_frag(bwf, KT_T1 + 0, lane); Wn1 = lds_frag(bwf, KT_T1 + 1, lane);
       PSYNC();
       // ---- step ST_T1 ------------------------------------------------------------------------------
-      stage_h(slot_D(ST_T1), D0, D1, col, h);
-      stage_h(slot_D(ST_T1) + HIMG_BYTES, A5a, A5b, col, h);
       acc = MFMA(Wn0, D0, zero16());
       acc = MFMA(Wn1, D1, acc);  // d a5
-      D0 = pack8_masked(acc, 0, A5a); D1 = pack8_masked(acc, 1, A5b);
       Wn0 = lds_frag(bwf, KT_VD_Y + 0, lane); Wn1 = lds_frag(bwf, KT_VD_Y + 1, lane);
+      stage_h(slot_D(ST_T1), D0, D1, col, h);
+      stage_h(slot_D(ST_T1) + HIMG_BYTES, A5a, A5b, col, h);
+      D0 = pack8_masked(acc, 0, A5a); D1 = pack8_masked(acc, 1, A5b);
       PSYNC();
       // ---- step ST_VD : inputs [y4 | e2] -----------------------------------------------------------
-      stage_h(slot_D(ST_VD), D0, D1, col, h);
-      stage_h(slot_D(ST_VD) + HIMG_BYTES, Y4a, Y4b, col, h);
       acc = MFMA(Wn0, D0, zero16());
       acc = MFMA(Wn1, D1, acc);  // d y4 from the colour branch
-      {  // d e2 (two 16-slot blocks) -> dB, bands 4 and 5
-        f16v de[3];
+      f16v de2[3];  // d e2 (two 16-slot blocks); its PE backward runs in the next step, under the dW wave's 3 blocks
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          de[b] = MFMA(lds_frag(bwf, KT_VD_E + 2 * b + 0, lane), D0, zero16());
-          de[b] = MFMA(lds_frag(bwf, KT_VD_E + 2 * b + 1, lane), D1, de[b]);
-        }
-        de[2] = de[1];
-        {  // + sigma head: d y4 += w_sigma * draw  (first: the next barrier only needs D0 / D1)
-          const f16v wsg = acc_init(cf + CF_W_SG, h);
-#pragma unroll
-          for (int i = 0; i < 16; ++i) acc[i] = fmaf(wsg[i], draw, acc[i]);
-        }
-        D0 = pack8(acc, 0, false); D1 = pack8(acc, 1, false);
-        pe_backward(de, 2, 4, 22);
+      for (int b = 0; b < 2; ++b) {
+        de2[b] = MFMA(lds_frag(bwf, KT_VD_E + 2 * b + 0, lane), D0, zero16());
+        de2[b] = MFMA(lds_frag(bwf, KT_VD_E + 2 * b + 1, lane), D1, de2[b]);
       }
+      de2[2] = de2[1];
       Wn0 = lds_frag(bwf, KT_ES + 0, lane); Wn1 = lds_frag(bwf, KT_ES + 1, lane);
+      stage_h(slot_D(ST_VD), D0, D1, col, h);
+      stage_h(slot_D(ST_VD) + HIMG_BYTES, Y4a, Y4b, col, h);
+      {  // + sigma head: d y4 += w_sigma * draw
+        const f16v wsg = acc_init(cf + CF_W_SG, h);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = fmaf(wsg[i], draw, acc[i]);
+      }
+      D0 = pack8(acc, 0, false); D1 = pack8(acc, 1, false);
       PSYNC();
       // ---- step ST_ES (no activation) --------------------------------------------------------------
-      stage_h(slot_D(ST_ES), D0, D1, col, h);
-      stage_h(slot_D(ST_ES) + HIMG_BYTES, A3a, A3b, col, h);
       acc = MFMA(Wn0, D0, zero16());
       acc = MFMA(Wn1, D1, acc);  // d a3
-      D0 = pack8_masked(acc, 0, A3a); D1 = pack8_masked(acc, 1, A3b);
       Wn0 = lds_frag(bwf, KT_S2 + 0, lane); Wn1 = lds_frag(bwf, KT_S2 + 1, lane);
+      stage_h(slot_D(ST_ES), D0, D1, col, h);
+      stage_h(slot_D(ST_ES) + HIMG_BYTES, A3a, A3b, col, h);
+      D0 = pack8_masked(acc, 0, A3a); D1 = pack8_masked(acc, 1, A3b);
+      pe_backward(de2, 2, 4, 22);  // bands 4 and 5 -> dB
       PSYNC();
       // ---- step ST_S2 : input a2 (parked) ------------------------------------------------------------
-      stage_h(slot_D(ST_S2), D0, D1, col, h);
       acc = MFMA(Wn0, D0, zero16());
       acc = MFMA(Wn1, D1, acc);  // d a2
+      Wn0 = lds_frag(bwf, KT_CAT_Y + 0, lane); Wn1 = lds_frag(bwf, KT_CAT_Y + 1, lane);
       {
         h8 a, b;
         load_h(A2img, a, b, col, h);
+        stage_h(slot_D(ST_S2), D0, D1, col, h);
         D0 = pack8_masked(acc, 0, a); D1 = pack8_masked(acc, 1, b);
       }
-      Wn0 = lds_frag(bwf, KT_CAT_Y + 0, lane); Wn1 = lds_frag(bwf, KT_CAT_Y + 1, lane);
       PSYNC();
       // ---- step ST_CAT : inputs [a1 | e1] (both parked) ----------------------------------------------
-      stage_h(slot_D(ST_CAT), D0, D1, col, h);
-      const h8 Dc0 = D0, Dc1 = D1;  // its d e1 part is formed together with encoding_xyz's
       acc = MFMA(Wn0, D0, zero16());
       acc = MFMA(Wn1, D1, acc);  // d a1
+      Wn0 = lds_frag(bwf, KT_S1 + 0, lane); Wn1 = lds_frag(bwf, KT_S1 + 1, lane);
+      const h8 Dc0 = D0, Dc1 = D1;  // its d e1 part is formed together with encoding_xyz's
       {
         h8 a, b;
         load_h(A1img, a, b, col, h);
+        stage_h(slot_D(ST_CAT), D0, D1, col, h);
         D0 = pack8_masked(acc, 0, a); D1 = pack8_masked(acc, 1, b);
       }
-      Wn0 = lds_frag(bwf, KT_S1 + 0, lane); Wn1 = lds_frag(bwf, KT_S1 + 1, lane);
       PSYNC();
       // ---- step ST_S1 : input a0 (parked) --------------------------------------------------------------
-      stage_h(slot_D(ST_S1), D0, D1, col, h);
       acc = MFMA(Wn0, D0, zero16());
       acc = MFMA(Wn1, D1, acc);  // d a0
-      {
-        h8 a, b;
-        load_h(A0img, a, b, col, h);
-        D0 = pack8_masked(acc, 0, a); D1 = pack8_masked(acc, 1, b);
-      }
-      f16v de[3];  // the cat part of d e1 does not depend on this step's result: issue it before the barrier
+      f16v de[3];  // the cat part of d e1 does not depend on this step's result: under the dW wave's 4 cat blocks
 #pragma unroll
       for (int b = 0; b < 3; ++b) {
         de[b] = MFMA(lds_frag(bwf, KT_CAT_E + 2 * b + 0, lane), Dc0, zero16());
         de[b] = MFMA(lds_frag(bwf, KT_CAT_E + 2 * b + 1, lane), Dc1, de[b]);
       }
+      {
+        h8 a, b;
+        load_h(A0img, a, b, col, h);
+        stage_h(slot_D(ST_S1), D0, D1, col, h);
+        D0 = pack8_masked(acc, 0, a); D1 = pack8_masked(acc, 1, b);
+      }
+      load_inputs(clamp_tile(tile + tile_step));  // next tile's sample: in flight across the next two steps
       PSYNC();
       // ---- step ST_XYZ : input e1 (parked) ------------------------------------------------------------------
       stage_h(slot_D(ST_XYZ), D0, D1, col, h);
-      PSYNC();  // D0 is all the dW wave needs; the PE backward below overlaps its encoding_xyz products
       // d e1 = Wc_e^T dPre(cat) + Wx^T dPre(xyz) (three 16-slot blocks) -> dB, bands 0..3
 #pragma unroll
       for (int b = 0; b < 3; ++b) {
         de[b] = MFMA(lds_frag(bwf, KT_XYZ_E + 2 * b + 0, lane), D0, de[b]);
         de[b] = MFMA(lds_frag(bwf, KT_XYZ_E + 2 * b + 1, lane), D1, de[b]);
       }
-      load_inputs(clamp_tile(tile + tile_step));  // next tile's sample; its latency hides under the PE backward
       pe_backward(de, 3, 0, 44);
+      PSYNC();
+      // ---- the dW wave finishes encoding_xyz; this wave computes the next tile's PE features meanwhile ---------
+      pe_features();
+#pragma unroll
+      for (int s = 0; s < 6; ++s) asm volatile("" : "+v"(E1f[s]));  // materialise here, not below the barrier
+#pragma unroll
+      for (int s = 0; s < 3; ++s) asm volatile("" : "+v"(E2f[s]));
       PSYNC();  // the dW wave is done with this tile's images
     }
   } else {
@@ -394,64 +422,72 @@ __global__ __launch_bounds__(256, 1) void field_bwd_pipe_kernel(
     const bool owns_rs = NDW == 1 || dwid == 0;
     constexpr int LI_RS = 0;  // BK_R2's local index
     // row-sum block RS[m][feature]: m = 4 * latent slot + object row (m < 16), m = 16: enc_shape bias, m = 17: rgb.0 bias
-    const int m_row = col & 3, m_grp = col < 16 ? (col >> 2) : (col - 12);  // groups 0..3 latent, 4 / 5 the two biases
+    const int m_row = col < 16 ? (col & 3) : 4, m_grp = col < 16 ? (col >> 2) : (col - 12);  // groups 0..3 latent, 4 / 5 the biases
 
     for (int t0 = blockIdx.x * NCH; t0 < ntiles; t0 += tile_step) {
       asm volatile("" ::: "memory");
       PSTAMP_RESET();
       PSTAMP();
-      h8 RF[NCH][2];  // A operand of the row sums before the layer mask: [m][sample k] = (object row of k == m_row)
+      h8 RF[NCH][2];  // A operand of the row sums before the layer mask: [m][sample k] = (object row of k == m_row), or 1
 
+      // One layer step for every chain wave's tile.  The transposing LDS reads are convergent operations, which the
+      // scheduler keeps in source order: all operand fragments of the step are therefore read first (they are in
+      // flight together), then the MFMAs run back to back.
       auto consume = [&](auto step_c) {
         constexpr int step = decltype(step_c)::value;
+        constexpr int NX = step == ST_VD ? 3 : step == ST_CAT ? 4 : step == ST_XYZ ? 3 : 1;  // dW blocks of the layer
+        constexpr int KIND0 = step == ST_R2 ? BK_R0     // rows 16..18 of rgb.0's block, see the chain role
+                            : step == ST_R0 ? BK_R0 : step == ST_T1 ? BK_T1 : step == ST_VD ? BK_VD_Y
+                            : step == ST_ES ? BK_ES : step == ST_S2 ? BK_S2 : step == ST_CAT ? BK_CAT_Y
+                            : step == ST_S1 ? BK_S1 : BK_XYZ_E0;
+        constexpr int RS_GRP = step == ST_R0 ? 5 : step == ST_T1 ? 3 : step == ST_ES ? 4 : step == ST_S2 ? 2
+                             : step == ST_CAT ? 1 : step == ST_S1 ? 0 : -1;
         const bool mine = owns(step);
-#pragma unroll
-        for (int w = 0; w < NCH; ++w) {
-          // (a tile past the end is not skipped: its chain wave staged all-zero dPre images, and straight-line code
-          //  lets the three tiles' LDS reads overlap)
+        if (!mine && !(owns_rs && RS_GRP >= 0)) return;
+        h8 fD[2][2], fX[2][NX][2];  // two tiles in flight
+        auto load_tile = [&](int w) {
           const unsigned char* cb = chain_base + w * CW_BYTES;
           const unsigned char* Dimg = cb + CW_SLOT + (step & 1) * SLOT_BYTES;
-          const unsigned char* Ximg = Dimg + HIMG_BYTES;
-          const h8 tD0 = tr_frag(Dimg, ST_H, 0, 0, lane), tD1 = tr_frag(Dimg, ST_H, 0, 1, lane);
-          auto dW = [&](auto kind_c, const unsigned char* ximg, int stride, int col0) {
-            constexpr int kind = decltype(kind_c)::value;
-            constexpr int li = NDW == 1 ? kind : (kind < BK_CAT_Y ? kind : kind - BK_CAT_Y);
-            if (!mine) return;
-            Wacc[li] = MFMA(tD0, tr_frag(ximg, stride, col0, 0, lane), Wacc[li]);
-            Wacc[li] = MFMA(tD1, tr_frag(ximg, stride, col0, 1, lane), Wacc[li]);
-          };
-          // RS[m][:] += sum over the tile's samples in m's group of dPre: no LDS, no result read-back
-          auto row_sums = [&](int grp) {
-            if (!owns_rs) return;
+          fD[w & 1][0] = tr_frag(Dimg, ST_H, 0, 0, lane);
+          fD[w & 1][1] = tr_frag(Dimg, ST_H, 0, 1, lane);
+          if (!mine) return;
+#pragma unroll
+          for (int b = 0; b < NX; ++b) {
+            // input image of block b: the slot's X image, or an image the chain wave parked at forward time
+            const unsigned char* ximg;
+            int stride = ST_H, col0 = 0;
+            if (step == ST_R2 || step == ST_R0 || step == ST_T1 || step == ST_ES || (step == ST_VD && b == 0))
+              ximg = Dimg + HIMG_BYTES;
+            else if (step == ST_VD) { ximg = cb + CW_E2; stride = ST_E2; col0 = 32 * (b - 1); }
+            else if (step == ST_S2) ximg = cb + CW_A2;
+            else if (step == ST_S1) ximg = cb + CW_A0;
+            else if (step == ST_CAT && b == 0) ximg = cb + CW_A1;
+            else { ximg = cb + CW_E1; stride = ST_E1; col0 = 32 * (step == ST_CAT ? b - 1 : b); }
+            fX[w & 1][b][0] = tr_frag(ximg, stride, col0, 0, lane);
+            fX[w & 1][b][1] = tr_frag(ximg, stride, col0, 1, lane);
+          }
+        };
+        load_tile(0);
+#pragma unroll
+        for (int w = 0; w < NCH; ++w) {
+          if (w + 1 < NCH) load_tile(w + 1);
+          if (mine) {
+#pragma unroll
+            for (int b = 0; b < NX; ++b) {
+              const int kind = KIND0 + b;  // compile-time after unrolling
+              const int li = NDW == 1 ? kind : (kind < BK_CAT_Y ? kind : kind - BK_CAT_Y);
+              Wacc[li] = MFMA(fD[w & 1][0], fX[w & 1][b][0], Wacc[li]);
+              Wacc[li] = MFMA(fD[w & 1][1], fX[w & 1][b][1], Wacc[li]);
+            }
+          }
+          if (owns_rs && RS_GRP >= 0) {
+            // RS[m][:] += sum over the tile's samples in m's group of dPre: no LDS, no result read-back
             typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-            const unsigned int lm = (m_grp == grp) ? 0xffffffffu : 0u;
+            const unsigned int lm = (m_grp == RS_GRP) ? 0xffffffffu : 0u;
             const h8 a0 = __builtin_bit_cast(h8, (u4)(__builtin_bit_cast(u4, RF[w][0]) & lm));
             const h8 a1 = __builtin_bit_cast(h8, (u4)(__builtin_bit_cast(u4, RF[w][1]) & lm));
-            Wacc[LI_RS] = MFMA(a0, tD0, Wacc[LI_RS]);
-            Wacc[LI_RS] = MFMA(a1, tD1, Wacc[LI_RS]);
-          };
-          if constexpr (step == ST_R2) { dW(IC<BK_R0>{}, Ximg, ST_H, 0); }  // rows 16..18, see the chain role
-          else if constexpr (step == ST_R0) { dW(IC<BK_R0>{}, Ximg, ST_H, 0); row_sums(5); }
-          else if constexpr (step == ST_T1) { dW(IC<BK_T1>{}, Ximg, ST_H, 0); row_sums(3); }
-          else if constexpr (step == ST_VD) {
-            dW(IC<BK_VD_Y>{}, Ximg, ST_H, 0);
-            dW(IC<BK_VD_E0>{}, cb + CW_E2, ST_E2, 0);
-            dW(IC<BK_VD_E1>{}, cb + CW_E2, ST_E2, 32);
-          }
-          else if constexpr (step == ST_ES) { dW(IC<BK_ES>{}, Ximg, ST_H, 0); row_sums(4); }
-          else if constexpr (step == ST_S2) { dW(IC<BK_S2>{}, cb + CW_A2, ST_H, 0); row_sums(2); }
-          else if constexpr (step == ST_CAT) {
-            dW(IC<BK_CAT_Y>{}, cb + CW_A1, ST_H, 0);
-            row_sums(1);
-            dW(IC<BK_CAT_E0>{}, cb + CW_E1, ST_E1, 0);
-            dW(IC<BK_CAT_E1>{}, cb + CW_E1, ST_E1, 32);
-            dW(IC<BK_CAT_E2>{}, cb + CW_E1, ST_E1, 64);
-          }
-          else if constexpr (step == ST_S1) { dW(IC<BK_S1>{}, cb + CW_A0, ST_H, 0); row_sums(0); }
-          else {
-            dW(IC<BK_XYZ_E0>{}, cb + CW_E1, ST_E1, 0);
-            dW(IC<BK_XYZ_E1>{}, cb + CW_E1, ST_E1, 32);
-            dW(IC<BK_XYZ_E2>{}, cb + CW_E1, ST_E1, 64);
+            Wacc[LI_RS] = MFMA(a0, fD[w & 1][0], Wacc[LI_RS]);
+            Wacc[LI_RS] = MFMA(a1, fD[w & 1][1], Wacc[LI_RS]);
           }
         }
       };
@@ -459,18 +495,9 @@ __global__ __launch_bounds__(256, 1) void field_bwd_pipe_kernel(
       if (owns_rs) {
 #pragma unroll
         for (int w = 0; w < NCH; ++w) {
-          const int* rowidx = reinterpret_cast<const int*>(chain_base + w * CW_BYTES + CW_SMALL);
+          const _Float16* rowoh = reinterpret_cast<const _Float16*>(chain_base + w * CW_BYTES + CW_SMALL);
 #pragma unroll
-          for (int s = 0; s < 2; ++s) {
-            typedef int i4 __attribute__((ext_vector_type(4)));
-            const i4 ra = *reinterpret_cast<const i4*>(rowidx + 16 * s + 8 * h);
-            const i4 rb = *reinterpret_cast<const i4*>(rowidx + 16 * s + 8 * h + 4);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              const int rk = (j < 4 ? ra[j & 3] : rb[j & 3]) - c * rows_per_class;
-              RF[w][s][j] = (col >= 16 || rk == m_row) ? (_Float16)1 : (_Float16)0;
-            }
-          }
+          for (int s = 0; s < 2; ++s) RF[w][s] = *reinterpret_cast<const h8*>(rowoh + m_row * 32 + 16 * s + 8 * h);
         }
       }
       consume(IC<ST_R2>{});
@@ -569,7 +596,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_pipe_kernel(
 
 #ifdef CNR_PIPE_STAMPS
 extern "C" int cnr_pipe_read_stamps(long long* host) {
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pipe_stamps), sizeof(long long) * 128);
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pipe_stamps), sizeof(long long) * 160);
 }
 #endif
 

@@ -305,7 +305,7 @@ def pack_weights(trunk):
 
 # cnr_field_bwd variants: "split" = two block-split launches (csrc/fused_bwd.hip), "pipe2"/"pipe3" = the single
 # pipelined launch with 2 / 3 chain waves per workgroup (csrc/fused_bwd_pipe.hip).  Same results contract.
-FIELD_BWD_VARIANT = os.environ.get("CNR_FIELD_BWD", "split")
+FIELD_BWD_VARIANT = os.environ.get("CNR_FIELD_BWD", "pipe3")
 
 
 def field_bwd(pts, B, packed, biasrows, ray_row, scale, d_sig, d_rgb, grad_scale, dtrunk, dB, dbiasrows, C, R, S,

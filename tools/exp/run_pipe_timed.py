@@ -28,14 +28,15 @@ for it in range(3):
     rc = fn(pts.data_ptr(), B.data_ptr(), packed.data_ptr(), brows.data_ptr(), ray_row.data_ptr(), 2.0, dsig.data_ptr(), drgb.data_ptr(),
             2048.0, dtrunk.data_ptr(), dB.data_ptr(), dbr.data_ptr(), C, R, S, n_obj, 0, NCH, wsp.data_ptr(), wsp.numel(), None)
     torch.cuda.synchronize()
-    buf = (ctypes.c_longlong * 128)()
+    buf = (ctypes.c_longlong * 160)()
     lib.cnr_pipe_read_stamps(buf)
-    for role, name in ((0, "chain"), (1, "dW   ")):
-        st = list(buf)[role * 64: role * 64 + 21]
+    base = min(buf[w * 32] for w in range(4))
+    for w in range(4):
+        st = list(buf)[w * 32: w * 32 + 21]
         # stamps: 0 = iteration start, then (before barrier, after barrier) x 10
         work = [st[1] - st[0]] + [st[2 * k + 1] - st[2 * k] for k in range(1, 10)]
         wait = [st[2 * k + 2] - st[2 * k + 1] for k in range(10)]
-        print(rc, name, "work", work, "wait", wait, "total", st[20] - st[0])
-    f = list(buf)[40:46]
-    print("   fwd: start->loads/pe", f[0] - buf[0], "pe+imgs", f[1] - f[0], "xyz", f[2] - f[1], "s1,cat,s2", f[3] - f[2],
+        print(rc, "wave", w, "t0", st[0] - base, "work", work, "wait", wait, "total", st[20] - st[0])
+    f = list(buf)[128:134]
+    print("   wave 0 fwd: start->loads/pe", f[0] - buf[0], "pe+imgs", f[1] - f[0], "xyz", f[2] - f[1], "s1,cat,s2", f[3] - f[2],
           "es", f[4] - f[3], "vd,t1,r0,r2", f[5] - f[4], "to barrier", buf[1] - f[5])
