@@ -40,8 +40,13 @@ SIGNATURES = {
     "cnr_field_bwd_pipe": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i64,
                            _vp],
     "cnr_field_bwd_workspace_bytes": [_i, _i],
+    "cnr_render_loss_workspace_bytes": [_i, _i],
+    "cnr_render_loss": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp,
+                        _i64, _vp],
+    "cnr_render_loss_finish": [_vp, _vp, _vp, _i, _i, _vp],
+    "cnr_step_epilogue": [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i, _i, _vp],
 }
-_RESTYPE64 = {"cnr_pack_bytes", "cnr_field_bwd_workspace_bytes"}
+_RESTYPE64 = {"cnr_pack_bytes", "cnr_field_bwd_workspace_bytes", "cnr_render_loss_workspace_bytes"}
 
 _lib = None
 _double = None
@@ -120,6 +125,10 @@ def pack_bytes():
 
 def field_bwd_workspace_bytes(C, max_blocks):
     return int(load().cnr_field_bwd_workspace_bytes(int(C), int(max_blocks)))
+
+
+def render_loss_workspace_bytes(C, R):
+    return int(load().cnr_render_loss_workspace_bytes(int(C), int(R)))
 
 
 def device_info():

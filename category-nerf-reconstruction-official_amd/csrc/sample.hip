@@ -165,7 +165,15 @@ __global__ __launch_bounds__(256) void sample_kernel(
   }
 
   // ---- a3/a5: per-column z -------------------------------------------------------------------
-  const float mb = max_bound[c];
+  float mb;
+  if (max_bound) mb = max_bound[c];
+  else {  // max depth of this step's slice of class c, by this wave (same value as cnr_sample_maxdepth: max is exact)
+    float m = -INFINITY;
+    const int64_t base = pool_rows > 0 ? (int64_t)c * pool_rows + d_state[0] : (int64_t)c * R;
+    for (int r = lane; r < R; r += 64)
+      m = fmaxf(m, depth[perm ? (int64_t)c * pool_rows + perm[base + r] : base + r]);
+    mb = cnr::wave_max(m);
+  }
   // (loop is wave-uniform: every lane takes part in the shuffles, only loads/stores are predicated)
   for (int s0 = 0; s0 < S; s0 += 64) {
     const int s = s0 + lane;
@@ -233,8 +241,7 @@ extern "C" int cnr_sample_rays(const uint8_t* rgbs, const float* depth, const fl
                                float* origins, float* dirs_o, float* gt_rgb, float* gt_depth,
                                uint8_t* depth_mask, uint8_t* labels, const int64_t* pool_indices, int n_obj,
                                int* ray_row, const int* perm, void* stream) {
-  if (!rgbs || !depth || !dirs_c || !T || !max_bound || !z || !pts || !gt_rgb || !depth_mask || !labels)
-    return CNR_E_ARG;
+  if (!rgbs || !depth || !dirs_c || !T || !z || !pts || !gt_rgb || !depth_mask || !labels) return CNR_E_ARG;
   if (C <= 0 || R <= 0 || n1 < 0 || n2 <= 0) return CNR_E_ARG;
   if (n2 > 128) return CNR_E_SHAPE;
   if ((u == nullptr) != (g == nullptr)) return CNR_E_ARG;

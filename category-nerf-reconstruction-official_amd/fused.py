@@ -85,7 +85,9 @@ class FusedCategoryTrainer:
         assert cfg.code_learning_rate == cfg.learning_rate and cfg.code_weight_decay == cfg.weight_decay, \
             "one flat AdamW group: the shipped configs use identical lr / weight decay for codes and networks"
         self.theta, self.lay = init_params(n_cls, self.L, n_obj, generator, self.device)
-        self.grad = torch.zeros_like(self.theta)
+        # gradient of the flat parameters and of the per-object bias rows in ONE allocation: one fill per step
+        self._gbuf = torch.zeros(self.theta.numel() + n_cls * n_obj * 128, device=self.device)
+        self.grad = self._gbuf[:self.theta.numel()].view_as(self.theta)
         self.exp_avg = torch.zeros_like(self.theta)
         self.exp_avg_sq = torch.zeros_like(self.theta)
         self.pg = process_group
@@ -99,6 +101,7 @@ class FusedCategoryTrainer:
         # epoch shuffle as an index permutation (C, pool_rows): the pool itself never moves
         self.perm = torch.empty(n_cls, self.pool_rows, device=self.device, dtype=torch.int32)
         self._zero64 = torch.zeros(1, device=self.device, dtype=torch.int64)
+        self.max_bound = torch.zeros(n_cls, device=self.device)
         self.cursor = 0
         self.seed = int(seed) + 1
         self.grad_scale = float(grad_scale) if grad_scale else float(2 ** round(math.log2(max(self.R, 2))))
@@ -106,7 +109,7 @@ class FusedCategoryTrainer:
         self.bufs = {}
         self.losses = torch.zeros(3, n_cls, device=self.device)
         self.flags = torch.zeros(n_cls, device=self.device, dtype=torch.int32)
-        self.dbias = torch.zeros(n_cls * n_obj, 4, 32, device=self.device)
+        self.dbias = self._gbuf[self.theta.numel():].view(n_cls * n_obj, 4, 32)
         self.use_graph = use_graph
         self.graph = None
         self.steps_done = 0
@@ -115,49 +118,54 @@ class FusedCategoryTrainer:
     # ---- one step, eager (also the body that gets captured) ------------------------------------------
     def _step_body(self):
         C, R, S, n_obj, L = self.C, self.R, self.S, self.n_obj, self.L
-        cfg, v = self.cfg, self.lay.views(self.theta)
+        cfg, v, lay = self.cfg, self.lay.views(self.theta), self.lay
         gv = self.lay.views(self.grad)
-        self.grad.zero_()
-        self.dbias.zero_()
-        # a2-a6: slice the device pool at the device cursor, transform, sample
+        o = self.bufs
+        if "zl" not in o:
+            kw = dict(device=self.device, dtype=torch.float32)
+            o["zl"] = torch.empty(C * n_obj, 4, 32, **kw)
+            o["brows"] = torch.empty(C * n_obj, 4, 32, **kw)
+            o["packed"] = torch.empty(C, _C.pack_bytes(), device=self.device, dtype=torch.uint8)
+            o["sig"] = torch.empty(C, R, S, **kw)
+            o["rgbs"] = torch.empty(C, R, S, 3, **kw)
+            for name, shape in (("depth", (C, R)), ("var", (C, R)), ("rgb", (C, R, 3)), ("opa", (C, R)),
+                                ("dsig", (C, R, S)), ("drgb", (C, R, S, 3))):
+                o[name] = torch.empty(*shape, **kw)
+            o["rl_ws"] = torch.zeros(_C.render_loss_workspace_bytes(C, R), device=self.device, dtype=torch.uint8)
+            o["bwd_ws"] = torch.empty(_C.field_bwd_workspace_bytes(C, self.bwd_blocks), device=self.device,
+                                      dtype=torch.uint8)
+            if C > 1:
+                o["dtrunk"] = torch.empty(C, TRUNK_PARAMS, **kw)
+                o["dB"] = torch.empty(C, 21, 3, **kw)
+        zl, brows, packed = o["zl"], o["brows"], o["packed"]
+        lat_args = (lay.total, lay.latW[0], lay.latb[0], lay.shape[0], lay.tex[0], L, n_obj, C)
+        Bc = v["B"] if C == 1 else v["B"].contiguous()
+        # One stream, one chain of kernels.  (Parallel hipGraph branches -- parameter prep beside sampling, the loss
+        # values beside the field backward -- were measured: every cross-queue edge costs more than the few
+        # microseconds of overlap it buys at this step size, 0.154 -> 0.170 ms per step.)
+        self._gbuf.zero_()
+        _C.call("cnr_latent_fwd", self.theta, *lat_args, zl, brows)   # a7 + latent layers: per-object work
+        _C.call("cnr_pack_weights", v["trunk"] if C == 1 else v["trunk"].contiguous(), packed, C)
+        # a2-a6: slice the device pool at the device cursor, transform, sample (the slice's max depth is already in
+        # self.max_bound: the previous step's epilogue, or _reshuffle, put it there)
         b = ops.sample_rays(self.pool["rgbs"], self.pool["depth"], self.pool["dirs"], self.pool["T"], self.n1,
                             self.n2, cfg.surface_eps, cfg.stop_eps, min_bound=cfg.min_depth, world_frame=False,
-                            seed=self.seed, d_state=self.d_state, rays=R, out=self.bufs,
+                            seed=self.seed, d_state=self.d_state, rays=R, out=self.bufs, max_bound=self.max_bound,
                             pool_indices=self.pool["indices"], n_obj=n_obj, perm=self.perm)
         ray_row = b["ray_row"]
-        # a7 + latent layers (per-object work): one small kernel -> zl (post-ReLU), effective bias rows
-        lay = self.lay
-        if "zl" not in self.bufs:
-            self.bufs["zl"] = torch.empty(C * n_obj, 4, 32, device=self.device)
-            self.bufs["brows"] = torch.empty(C * n_obj, 4, 32, device=self.device)
-        zl, brows = self.bufs["zl"], self.bufs["brows"]
-        lat_args = (lay.total, lay.latW[0], lay.latb[0], lay.shape[0], lay.tex[0], L, n_obj, C)
-        _C.call("cnr_latent_fwd", self.theta, *lat_args, zl, brows)
-        # a8 + a9 fused forward, a11-a13 composite, a14-a15 loss (+ its gradient), composite backward
-        packed = ops.pack_weights(v["trunk"])
-        Bc = v["B"].contiguous()
-        sig, rgb = ops.field_fwd(b["pts"], Bc, packed, brows, ray_row, self.scale)
-        kw = dict(device=self.device, dtype=torch.float32)
-        o = self.bufs
-        for name, shape in (("depth", (C, R)), ("var", (C, R)), ("rgb", (C, R, 3)), ("opa", (C, R)),
-                            ("dd", (C, R)), ("dr", (C, R, 3)), ("do", (C, R)), ("dsig", (C, R, S)),
-                            ("drgb", (C, R, S, 3))):
-            if name not in o:
-                o[name] = torch.empty(*shape, **kw)
-        _C.call("cnr_composite_fwd", sig, rgb, b["z"], None, o["depth"], o["var"], o["rgb"], o["opa"], C * R, S, 0)
+        # a8 + a9 fused forward
+        sig, rgb = o["sig"], o["rgbs"]
+        _C.call("cnr_field_fwd", b["pts"], Bc, packed, brows, ray_row, self.scale, sig, rgb, C, R, S)
+        # a11-a15 in one launch: composite, losses, their gradient, composite backward
         inv_w = 1.0 / self.world
-        _C.call("cnr_loss_fwd_bwd", o["depth"], o["var"], o["rgb"], o["opa"], b["gt_depth"], b["gt_rgb"], b["labels"],
-                b["depth_mask"], 5.0, 10.0, inv_w, self.losses, self.flags, o["dd"], o["dr"], o["do"], C, R)
-        _C.call("cnr_composite_bwd", sig, rgb, b["z"], o["dd"], o["dr"], o["do"], None, o["dsig"], o["drgb"], C * R, S, 0)
+        _C.call("cnr_render_loss", sig, rgb, b["z"], b["gt_depth"], b["gt_rgb"], b["labels"], b["depth_mask"],
+                5.0, 10.0, inv_w, o["dsig"], o["drgb"], o["depth"], o["var"], o["rgb"], o["opa"], C, R, S,
+                o["rl_ws"], o["rl_ws"].numel())
         # fused backward: dtrunk, dB, dbiasrows straight into the flat gradient buffer views
         if C == 1:   # one class: the views of the flat gradient row are contiguous, accumulate in place
             dtrunk, dB = gv["trunk"], gv["B"]
         else:
-            dtrunk = torch.zeros(C, TRUNK_PARAMS, **kw)
-            dB = torch.zeros(C, 21, 3, **kw)
-        if "bwd_ws" not in o:
-            o["bwd_ws"] = torch.empty(_C.field_bwd_workspace_bytes(C, self.bwd_blocks), device=self.device,
-                                      dtype=torch.uint8)
+            dtrunk, dB = o["dtrunk"].zero_(), o["dB"].zero_()
         ops.field_bwd(b["pts"], Bc, packed, brows, ray_row, self.scale, o["dsig"], o["drgb"],
                       self.grad_scale, dtrunk, dB, self.dbias, C, R, S, n_obj, self.bwd_blocks, o["bwd_ws"])
         if C > 1:
@@ -170,7 +178,10 @@ class FusedCategoryTrainer:
             parallel.allreduce_mean_(self.grad, self.pg, prescaled=True)   # one flat buffer, one collective
         ops.adamw_step(self.theta, self.grad, self.exp_avg, self.exp_avg_sq, self.lr, (0.9, 0.999), 1e-8, self.wd,
                        0, d_state=self.d_state)
-        ops.step_advance(self.d_state, R)
+        # last node: loss values + flags from the render kernel's partials, the next slice's max depth, device-side
+        # step state advanced
+        _C.call("cnr_step_epilogue", self.d_state, R, o["rl_ws"], self.losses, self.flags, self.pool["depth"],
+                self.pool_rows, self.perm, self.max_bound, C, R)
 
     def step(self):
         """One train step.  Returns nothing; ``self.losses`` (3,C) / ``self.flags`` (C,) hold the device-side
@@ -197,6 +208,8 @@ class FusedCategoryTrainer:
             self.perm[c].copy_(torch.randperm(self.pool_rows, device=self.device))
         self.cursor = 0
         self.d_state[0:1].copy_(self._zero64)
+        _C.call("cnr_sample_maxdepth", self.pool["depth"], self.max_bound, self.d_state, self.pool_rows, self.perm,
+                self.C, self.R)
 
     # ---- reference-named export ------------------------------------------------------------------------
     def state_dicts(self, c=0):

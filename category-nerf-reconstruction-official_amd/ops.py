@@ -233,6 +233,7 @@ class RenderLossFn(Function):
 # ------------------------------------------------------------------------------------------------
 def sample_rays(rgbs, depth, dirs_c, T, n1, n2, eps, stop_eps, min_bound=0.0, world_frame=False,
                 u=None, g=None, seed=0, offset=0, want_rays=False, d_state=None, rays=None, out=None,
+                max_bound=None,
                 pool_indices=None, n_obj=0, perm=None):
     """Class-batched pool slice (C,R,...) -> dict(z, pts, gt_rgb, gt_depth, depth_mask, labels[, origins, dirs_o]).
     u/g given -> parity mode (identical draws); else in-kernel Philox(seed, offset).
@@ -249,8 +250,11 @@ def sample_rays(rgbs, depth, dirs_c, T, n1, n2, eps, stop_eps, min_bound=0.0, wo
         if name not in o:
             o[name] = torch.empty(*shape, device=dev, dtype=dtype)
         return o[name]
-    mb = buf("max_bound", (C,))
-    _C.call("cnr_sample_maxdepth", depth, mb, d_state, pool_rows, perm, C, R)
+    if max_bound is not None:
+        mb = max_bound                # already there (cnr_step_epilogue of the previous step, or the caller)
+    else:
+        mb = buf("max_bound", (C,))
+        _C.call("cnr_sample_maxdepth", depth, mb, d_state, pool_rows, perm, C, R)
     z, pts = buf("z", (C, R, S)), buf("pts", (C, R, S, 3))
     gt, gd = buf("gt_rgb", (C, R, 3)), buf("gt_depth", (C, R))
     dm, lab = buf("depth_mask", (C, R), torch.uint8), buf("labels", (C, R), torch.uint8)

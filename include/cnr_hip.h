@@ -58,7 +58,8 @@ int cnr_device_info(int* n_cu, int* lds_bytes, int* gcn_arch_is_gfx950);
  *   world_frame: 0 -> origin_dirs_O (T is T_CO, inverted in-kernel, sim3 closed form is NOT assumed:
  *         a general 3x3 inverse is used), 1 -> origin_dirs_W (T is T_WC).
  *   max_bound (C,) : per-class max(depth) over the slice (reference :486); computed by
- *         cnr_sample_maxdepth below so that no host sync is needed.
+ *         cnr_sample_maxdepth below (or by the previous step's cnr_step_epilogue) so that no host sync is
+ *         needed; NULL: every wave takes the maximum itself (same value, R extra loads per ray).
  * Outputs: z (C,R,S) with S = n1+n2, pts (C,R,S,3), origins (C,R,3) and dirs_o (C,R,3) (may be NULL),
  *   gt_rgb (C,R,3) f32 already /255 (train.py:144), gt_depth (C,R) copy of the slice's depth (may be
  *   NULL), depth_mask (C,R) u8, labels (C,R) u8; ray_row (C,R) i32 = pool_indices[slice] + c * n_obj, the row of
@@ -188,6 +189,32 @@ int cnr_field_bwd(const float* pts, const float* B, const void* packed, const fl
                   const int* ray_row, float scale, const float* d_sigma, const float* d_rgb,
                   float grad_scale, float* dtrunk, float* dB, float* dbiasrows, int C, int R, int S,
                   int rows_per_class, int max_blocks, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* a11-a15 fused for the render + loss step of the fused trainer: cnr_composite_fwd -> cnr_loss_fwd_bwd ->
+ * cnr_composite_bwd in ONE kernel (src/render_rays.py:3-7,25-33,46-95; src/loss.py:18-74).  Possible because the
+ * gradient of the masked-mean losses w.r.t. one ray's renders needs that ray's values and the mask counts only.
+ * sigmas (C,R,S) are the pre-sigmoid occupancy logits (CodeNeRF's raw * 10), colors (C,R,S,3), z (C,R,S).
+ * Outputs: d_sigmas (C,R,S), d_colors (C,R,S,3) = dL/dsigmas, dL/dcolors of
+ *   sum_c depth + color_scaling * color + opacity_scaling * opacity,  times grad_scale,
+ * bit-identical to the three-call sequence; depth, var (C,R), rgb (C,R,3), opacity (C,R): the renders, each
+ * optional (NULL to skip); per-block partial sums of the three loss terms into `workspace`
+ * (>= cnr_render_loss_workspace_bytes(C, R) bytes).  S <= 512.
+ * cnr_render_loss_finish turns those partials into losses (3,C) and flags (C), exactly as cnr_loss_fwd_bwd
+ * defines them (fixed summation order, no float atomics).  It only needs the stream order after
+ * cnr_render_loss, so a trainer can run it on a side stream beside the field backward. */
+int64_t cnr_render_loss_workspace_bytes(int C, int R);
+int cnr_render_loss(const float* sigmas, const float* colors, const float* z, const float* gt_depth,
+                    const float* gt_rgb, const uint8_t* labels, const uint8_t* depth_mask, float color_scaling,
+                    float opacity_scaling, float grad_scale, float* d_sigmas, float* d_colors, float* depth,
+                    float* var, float* rgb, float* opacity, int C, int R, int S, void* workspace,
+                    int64_t workspace_bytes, void* stream);
+int cnr_render_loss_finish(const void* workspace, float* losses, int32_t* flags, int C, int R, void* stream);
+/* Last node of the fused trainer's captured step, one launch: cnr_render_loss_finish, then (next_max_bound !=
+ * NULL) cnr_sample_maxdepth for the NEXT step's slice [cursor + add_rows, + R) of the (C,pool_rows) depth pool,
+ * then cnr_step_advance(d_state, add_rows).  The next step's cnr_sample_rays reads next_max_bound. */
+int cnr_step_epilogue(int64_t* d_state, int64_t add_rows, const void* workspace, float* losses, int32_t* flags,
+                      const float* depth, int64_t pool_rows, const int* perm, float* next_max_bound, int C, int R,
+                      void* stream);
 
 /* Same contract and results as cnr_field_bwd, ONE field kernel + the record reduction: each workgroup is
  * `chain_waves` (2 or 3) waves that run forward recompute + data-gradient chain + PE backward for one 32-sample

@@ -235,3 +235,50 @@ def test_full_size_against_oracle_and_properties(cnr, dev, C, R, S, L):
     assert rel_l2(t_.sum(-1), opa_) < 1e-6
     _, _, _, rgb2, _ = cnr.ops.CompositeFn.apply(sig.squeeze(-1), col * 0.5, d(z))
     assert rel_l2(rgb2 * 2, rgb_) < 1e-6
+
+
+@pytest.mark.parametrize("C,R,S,empty", [(1, 2048, 64, False), (2, 300, 16, False), (3, 130, 200, False),
+                                        (2, 257, 64, True)])
+def test_render_loss_single_launch_equals_three_calls(cnr, dev, C, R, S, empty):
+    """cnr_render_loss == cnr_composite_fwd -> cnr_loss_fwd_bwd -> cnr_composite_bwd: gradients and renders
+    bit-identical (same expressions), loss values to fp32 summation order, flags equal; a second launch on
+    the same workspace reproduces the first bitwise."""
+    _C = cnr._C
+    gen = torch.Generator().manual_seed(C * 1000 + R + S)
+    rnd = lambda *s: torch.randn(*s, generator=gen).to(dev)
+    sig, col = rnd(C, R, S) * 3, torch.rand(C, R, S, 3, generator=gen).to(dev)
+    z = (torch.rand(C, R, S, generator=gen).sort(dim=-1).values * 4 + 0.1).to(dev)
+    gt_d, gt_c = (torch.rand(C, R, generator=gen) * 4).to(dev), torch.rand(C, R, 3, generator=gen).to(dev)
+    labels = torch.randint(0, 3, (C, R), generator=gen).to(torch.uint8).to(dev)
+    dmask = (torch.rand(C, R, generator=gen) > 0.2).to(torch.uint8).to(dev)
+    if empty:
+        labels[1] = 0                      # class 1 has no object ray: colour / depth terms vanish for ALL classes
+    f = lambda *s: torch.empty(*s, device=dev)
+    depth, var, rgb, opa = f(C, R), f(C, R), f(C, R, 3), f(C, R)
+    _C.call("cnr_composite_fwd", sig, col, z, None, depth, var, rgb, opa, C * R, S, 0)
+    losses, flags = f(3, C), torch.empty(C, device=dev, dtype=torch.int32)
+    dd, dr, do = f(C, R), f(C, R, 3), f(C, R)
+    _C.call("cnr_loss_fwd_bwd", depth, var, rgb, opa, gt_d, gt_c, labels, dmask, 5.0, 10.0, 0.5, losses, flags,
+            dd, dr, do, C, R)
+    dsig, dcol = f(C, R, S), f(C, R, S, 3)
+    _C.call("cnr_composite_bwd", sig, col, z, dd, dr, do, None, dsig, dcol, C * R, S, 0)
+
+    ws = torch.zeros(_C.render_loss_workspace_bytes(C, R), device=dev, dtype=torch.uint8)
+    outs = []
+    for _ in range(2):
+        l2, f2 = f(3, C), torch.empty(C, device=dev, dtype=torch.int32)
+        ds2, dc2 = f(C, R, S), f(C, R, S, 3)
+        d2, v2, r2, o2 = f(C, R), f(C, R), f(C, R, 3), f(C, R)
+        _C.call("cnr_render_loss", sig, col, z, gt_d, gt_c, labels, dmask, 5.0, 10.0, 0.5, ds2, dc2, d2, v2, r2, o2,
+                C, R, S, ws, ws.numel())
+        _C.call("cnr_render_loss_finish", ws, l2, f2, C, R)
+        outs.append((l2, f2, ds2, dc2, d2, v2, r2, o2))
+    l2, f2, ds2, dc2, d2, v2, r2, o2 = outs[0]
+    assert torch.equal(ds2, dsig) and torch.equal(dc2, dcol)
+    assert torch.equal(d2, depth) and torch.equal(v2, var) and torch.equal(r2, rgb) and torch.equal(o2, opa)
+    assert torch.equal(f2, flags)
+    assert rel_l2(l2, losses) < 1e-6
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    if empty:
+        assert int(flags[0]) & 4 and float(losses[1].abs().sum()) == 0.0
