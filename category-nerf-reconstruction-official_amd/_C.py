@@ -40,6 +40,7 @@ SIGNATURES = {
     "cnr_field_bwd_pipe": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i64,
                            _vp],
     "cnr_field_bwd_workspace_bytes": [_i, _i],
+    "cnr_param_prep": [_vp, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp],
     "cnr_render_loss_workspace_bytes": [_i, _i],
     "cnr_render_loss": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp,
                         _i64, _vp],

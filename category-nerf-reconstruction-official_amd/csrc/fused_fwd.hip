@@ -9,6 +9,7 @@
 // Latent conditioning arrives as per-row effective biases  bias'_l[row] = W_l z_l[row] + b_l  (row =
 // object, or ray for per-ray codes): W_l (a + z) + b = W_l a + bias'_l, so the latent add costs no VALU.
 #include "fused_common.h"
+#include "latent_common.h"
 
 namespace {
 using namespace fz;
@@ -62,11 +63,8 @@ __device__ __forceinline__ float bwd_elem(const float* __restrict__ Wt, int kt, 
   return Wt[w_off + o * ld + in_col];
 }
 
-__global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ trunk, unsigned char* __restrict__ packed) {
-  const int c = blockIdx.y;
-  const float* Wt = trunk + (size_t)c * TRUNK;
-  unsigned char* out = packed + (size_t)c * PK_BYTES;
-  const int kk = blockIdx.x;  // 0 .. NKK_FWD + NKK_BWD (+1 for constants)
+// one block = one 1 KB operand fragment (kk < NKK_FWD + NKK_BWD) or the constants block (kk == that)
+__device__ __forceinline__ void pack_block(const float* __restrict__ Wt, unsigned char* __restrict__ out, int kk) {
   if (kk < NKK_FWD + NKK_BWD) {
     for (int e = threadIdx.x; e < 64 * 8; e += 256) {
       const int lane = e >> 3, j = e & 7, r = lane & 31, h = lane >> 5;
@@ -90,6 +88,34 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ tru
       cf[i] = v;
     }
   }
+}
+__global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ trunk, unsigned char* __restrict__ packed) {
+  const int c = blockIdx.y;
+  pack_block(trunk + (size_t)c * TRUNK, packed + (size_t)c * PK_BYTES, blockIdx.x);
+}
+
+// Parameter-only work of one train step in ONE launch (three independent jobs side by side in the grid instead of
+// three launches in a row): operand image of the trunk (pack_block), per-object latent rows (latent_fwd_block),
+// and the zero fill of the gradient buffers.  grid (NPACK + 4 n_obj + nzero, C).
+__global__ __launch_bounds__(256) void param_prep_kernel(const float* __restrict__ theta, cnr::FlatLayout lay,
+                                                         int64_t off_trunk, unsigned char* __restrict__ packed,
+                                                         float* __restrict__ zl, float* __restrict__ biasrows,
+                                                         float* __restrict__ zero_buf, int64_t zero_count, int nzero) {
+  constexpr int NPACK = NKK_FWD + NKK_BWD + 1;
+  const int c = blockIdx.y, C = gridDim.y;
+  const float* th = theta + (int64_t)c * lay.stride;
+  int b = blockIdx.x;
+  if (b < NPACK) { pack_block(th + off_trunk, packed + (size_t)c * PK_BYTES, b); return; }
+  b -= NPACK;
+  if (b < 4 * lay.n_obj) { cnr::latent_fwd_block(th, th + off_trunk, lay, zl, biasrows, b >> 2, b & 3, c); return; }
+  b -= 4 * lay.n_obj;
+  // zero fill: block (b, c) of nzero * C takes a contiguous float4 range
+  const int64_t nvec = zero_count >> 2, nblk = (int64_t)nzero * C, me = (int64_t)c * nzero + b;
+  const int64_t per = (nvec + nblk - 1) / nblk;
+  const int64_t lo = me * per, hi = lo + per < nvec ? lo + per : nvec;
+  f4 z4 = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t i = lo + threadIdx.x; i < hi; i += 256) reinterpret_cast<f4*>(zero_buf)[i] = z4;
+  if (me == 0 && threadIdx.x < (zero_count & 3)) zero_buf[(nvec << 2) + threadIdx.x] = 0.0f;
 }
 
 }  // namespace
@@ -213,6 +239,25 @@ extern "C" int cnr_pack_weights(const float* trunk, void* packed, int C, void* s
   if (((uintptr_t)packed & 15) != 0) return CNR_E_ALIGN;
   dim3 grid(fz::NKK_FWD + fz::NKK_BWD + 1, (unsigned)C);
   hipLaunchKernelGGL(pack_kernel, grid, dim3(256), 0, (hipStream_t)stream, trunk, (unsigned char*)packed);
+  CNR_LAUNCH_CHECK();
+  return CNR_OK;
+}
+
+extern "C" int cnr_param_prep(const float* theta, int64_t class_stride, int64_t off_trunk, int64_t off_latW,
+                              int64_t off_latb, int64_t off_shape, int64_t off_tex, int L, int n_obj, int C,
+                              void* packed, float* zl, float* biasrows, float* zero_buf, int64_t zero_count,
+                              void* stream) {
+  if (!theta || !packed || !zl || !biasrows || L <= 0 || n_obj <= 0 || C <= 0 || zero_count < 0 ||
+      (zero_count > 0 && !zero_buf))
+    return CNR_E_ARG;
+  if (((uintptr_t)packed & 15) != 0 || ((uintptr_t)zero_buf & 15) != 0) return CNR_E_ALIGN;
+  cnr::FlatLayout lay{class_stride, off_latW, off_latb, off_shape, off_tex, L, n_obj};
+  int nzero = zero_count > 0 ? (int)((zero_count / 4 + 256 * 8 - 1) / (256 * 8) / C) : 0;  // ~8 float4 per thread
+  if (zero_count > 0 && nzero < 1) nzero = 1;
+  if (nzero > 256) nzero = 256;
+  dim3 grid(fz::NKK_FWD + fz::NKK_BWD + 1 + 4 * n_obj + nzero, (unsigned)C);
+  hipLaunchKernelGGL(param_prep_kernel, grid, dim3(256), 0, (hipStream_t)stream, theta, lay, off_trunk,
+                     (unsigned char*)packed, zl, biasrows, zero_buf, zero_count, nzero);
   CNR_LAUNCH_CHECK();
   return CNR_OK;
 }

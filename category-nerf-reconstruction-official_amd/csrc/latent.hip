@@ -7,51 +7,16 @@
 // and backward turns dbiasrows into the gradients of Wt_k[:, :32], bt_k (added into the trunk gradient), Wl_k, bl_k
 // and both code tables, plus the code-norm regulariser of src/loss.py:5-15 (reg_scale * code / ||code||).
 // Work is a few hundred kFLOP: one launch each instead of ~45 tiny PyTorch kernels is the whole point.
-#include "cnr_common.h"
+#include "latent_common.h"
 
 namespace {
 using namespace cnr;
 
-struct FlatLayout {
-  int64_t stride;  // floats per class row
-  int64_t latW, latb, shape, tex;
-  int L, n_obj;
-};
-__device__ __forceinline__ void latent_target(int k, int& w_off, int& b_off, int& ld) {
-  if (k == 0) { w_off = OFF_S1_W; b_off = OFF_S1_B; ld = 32; }
-  else if (k == 1) { w_off = OFF_CAT_W; b_off = OFF_CAT_B; ld = 32 + E1; }
-  else if (k == 2) { w_off = OFF_S2_W; b_off = OFF_S2_B; ld = 32; }
-  else { w_off = OFF_T1_W; b_off = OFF_T1_B; ld = 32; }
-}
-
-// grid (n_obj * 4, C), 256 threads: one block per (object, slot); a wave per output for the L-long dot product
-// (coalesced weight rows), then 32 threads finish the 32x32 product with the trunk layer.
+// grid (n_obj * 4, C), 256 threads: one block per (object, slot), see latent_fwd_block
 __global__ __launch_bounds__(256) void latent_fwd_kernel(const float* __restrict__ theta, FlatLayout lay,
                                                          float* __restrict__ zl, float* __restrict__ biasrows) {
-  const int obj = blockIdx.x >> 2, k = blockIdx.x & 3, c = blockIdx.y;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const float* th = theta + (int64_t)c * lay.stride;
-  const float* code = th + (k == 3 ? lay.tex : lay.shape) + (int64_t)obj * lay.L;
-  __shared__ float zs[32];
-  for (int o = wv; o < 32; o += 4) {
-    const float* w = th + lay.latW + ((int64_t)k * 32 + o) * lay.L;
-    float acc = 0.0f;
-    for (int l = lane; l < lay.L; l += 64) acc = fmaf(code[l], w[l], acc);
-    acc = wave_sum(acc);
-    if (lane == 0) zs[o] = fmaxf(acc + th[lay.latb + k * 32 + o], 0.0f);
-  }
-  __syncthreads();
-  if (threadIdx.x < 32) {
-    const int o = threadIdx.x;
-    const int64_t row = (int64_t)c * lay.n_obj + obj;
-    zl[(row * 4 + k) * 32 + o] = zs[o];
-    int w_off, b_off, ld;
-    latent_target(k, w_off, b_off, ld);
-    float br = th[b_off + o];
-#pragma unroll
-    for (int j = 0; j < 32; ++j) br = fmaf(th[w_off + o * ld + j], zs[j], br);
-    biasrows[(row * 4 + k) * 32 + o] = br;
-  }
+  const float* th = theta + (int64_t)blockIdx.y * lay.stride;
+  latent_fwd_block(th, th, lay, zl, biasrows, blockIdx.x >> 2, blockIdx.x & 3, blockIdx.y);
 }
 
 // grid (NB, C), 256 threads.  Every block recomputes the tiny d pre table (n_obj x 128 values) and the code

@@ -143,9 +143,10 @@ class FusedCategoryTrainer:
         # One stream, one chain of kernels.  (Parallel hipGraph branches -- parameter prep beside sampling, the loss
         # values beside the field backward -- were measured: every cross-queue edge costs more than the few
         # microseconds of overlap it buys at this step size, 0.154 -> 0.170 ms per step.)
-        self._gbuf.zero_()
-        _C.call("cnr_latent_fwd", self.theta, *lat_args, zl, brows)   # a7 + latent layers: per-object work
-        _C.call("cnr_pack_weights", v["trunk"] if C == 1 else v["trunk"].contiguous(), packed, C)
+        # parameter-only work, one launch: zero the gradient buffers | a7 + latent layers (per-object rows) | f16
+        # operand image of the trunk
+        _C.call("cnr_param_prep", self.theta, lay.total, lay.trunk[0], lay.latW[0], lay.latb[0], lay.shape[0],
+                lay.tex[0], L, n_obj, C, packed, zl, brows, self._gbuf, self._gbuf.numel())
         # a2-a6: slice the device pool at the device cursor, transform, sample (the slice's max depth is already in
         # self.max_bound: the previous step's epilogue, or _reshuffle, put it there)
         b = ops.sample_rays(self.pool["rgbs"], self.pool["depth"], self.pool["dirs"], self.pool["T"], self.n1,

@@ -190,6 +190,13 @@ int cnr_field_bwd(const float* pts, const float* B, const void* packed, const fl
                   float grad_scale, float* dtrunk, float* dB, float* dbiasrows, int C, int R, int S,
                   int rows_per_class, int max_blocks, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Parameter-only work of one fused-trainer step in ONE launch, three independent jobs side by side in the grid:
+ * cnr_pack_weights (trunk of class c at theta + c * class_stride + off_trunk), cnr_latent_fwd (same arguments), and
+ * a zero fill of zero_buf[0 .. zero_count) (the gradient buffers; 16-B aligned; zero_count 0 to skip). */
+int cnr_param_prep(const float* theta, int64_t class_stride, int64_t off_trunk, int64_t off_latW, int64_t off_latb,
+                   int64_t off_shape, int64_t off_tex, int L, int n_obj, int C, void* packed, float* zl,
+                   float* biasrows, float* zero_buf, int64_t zero_count, void* stream);
+
 /* a11-a15 fused for the render + loss step of the fused trainer: cnr_composite_fwd -> cnr_loss_fwd_bwd ->
  * cnr_composite_bwd in ONE kernel (src/render_rays.py:3-7,25-33,46-95; src/loss.py:18-74).  Possible because the
  * gradient of the masked-mean losses w.r.t. one ray's renders needs that ray's values and the mask counts only.

@@ -99,3 +99,32 @@ def test_graph_replay_trains(cnr, dev):
     assert int(tr.d_state[2]) == 60 and int(tr.d_state[0]) == tr.cursor
     assert h[-10:, 1].mean() < h[:10, 1].mean()   # colour L1 decreases
     assert not bool((tr.flags.cpu() & 1).any())
+
+
+@pytest.mark.parametrize("C,n_obj,L", [(1, 4, 256), (3, 2, 32), (2, 7, 64)])
+def test_param_prep_equals_separate_calls(cnr, dev, C, n_obj, L):
+    """cnr_param_prep (pack | latent rows | zero fill side by side in one grid) == cnr_pack_weights +
+    cnr_latent_fwd + a memset: operand image bit-identical, rows identical (same code path), buffer zero."""
+    _C = cnr._C
+    gen = torch.Generator().manual_seed(7 * C + n_obj)
+    theta, lay = cnr.fused.init_params(C, L, n_obj, gen, dev)
+    v = lay.views(theta)
+    args = (lay.total, lay.latW[0], lay.latb[0], lay.shape[0], lay.tex[0], L, n_obj, C)
+    zl0, br0 = torch.empty(C * n_obj, 4, 32, device=dev), torch.empty(C * n_obj, 4, 32, device=dev)
+    _C.call("cnr_latent_fwd", theta, *args, zl0, br0)
+    pk0 = cnr.ops.pack_weights(v["trunk"].contiguous())
+    zl1, br1 = torch.empty_like(zl0), torch.empty_like(br0)
+    pk1 = torch.empty_like(pk0)
+    zbuf = torch.full((lay.total * C + 131,), 3.0, device=dev)       # odd length: the scalar tail is covered too
+    _C.call("cnr_param_prep", theta, lay.total, lay.trunk[0], lay.latW[0], lay.latb[0], lay.shape[0], lay.tex[0],
+            L, n_obj, C, pk1, zl1, br1, zbuf, zbuf.numel())
+    assert torch.equal(pk0, pk1)
+    assert torch.equal(zl0, zl1) and torch.equal(br0, br1)
+    assert float(zbuf.abs().max()) == 0.0
+    # against torch: z = relu(Wl code + bl), rows = Wt[:, :32] z + bt
+    zref = []
+    for k in range(4):
+        code = v["tex"] if k == 3 else v["shape"]
+        zref.append(torch.relu(torch.einsum("col,cnl->cno", v["latW"][:, k], code) + v["latb"][:, k][:, None, :]))
+    zref = torch.stack(zref, dim=2).reshape(C * n_obj, 4, 32)
+    assert rel_l2(zl1, zref) < 1e-6
