@@ -158,8 +158,8 @@ def main():
 
     # ---- roofline leg: the dominant kernel (fused backward) timed with HIP events on its launch stream ----
     bwd_name = "cnr_field_bwd" if cnr_amd.ops.FIELD_BWD_VARIANT == "split" else "cnr_field_bwd_pipe"
-    names = [bwd_name, "cnr_field_fwd", "cnr_composite_fwd", "cnr_composite_bwd", "cnr_loss_fwd_bwd",
-             "cnr_sample_rays", "cnr_adamw_step", "cnr_pack_weights"]
+    names = [bwd_name, "cnr_field_fwd", "cnr_param_prep", "cnr_sample_rays", "cnr_render_loss", "cnr_latent_bwd",
+             "cnr_adamw_step", "cnr_step_epilogue"]
     saved_graph, tr.graph, tr.use_graph = tr.graph, None, False   # eager so that events bracket single launches
     cnr_amd._C.enable_kernel_timing(names)
     for _ in range(min(args.steps, 50)):

@@ -55,6 +55,11 @@ __device__ __forceinline__ h8 pack8_masked(const f16v& a, int s, const h8& act) 
   const us8 m = __builtin_elementwise_min(__builtin_bit_cast(us8, act), one) * (unsigned short)0xFFFF;
   return __builtin_bit_cast(h8, (us8)(__builtin_bit_cast(us8, pack8(a, s, false)) & m));
 }
+// (Tried: the chain role's MFMAs as inline asm in VGPR form -- a 512-register kernel gets AGPR-form MFMAs, which costs
+//  the chain role 16 v_accvgpr_read per layer.  With each layer's chain as one asm statement and hand-written wait
+//  states it passed the parity tests and gained 2 % (288.8 -> 282.8 us at 8192 x 128): not worth carrying hazard
+//  rules the compiler cannot check.  The chain role is bound by per-step dependent latency -- MFMA result -> mask /
+//  pack -> image store -> barrier, ~700 cycles for ~40 instructions -- not by instruction count.)
 __device__ __forceinline__ void role_barrier() {  // every wave of the workgroup executes the same number of these
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_s_barrier();

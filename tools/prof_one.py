@@ -1,4 +1,4 @@
-"""Launch each fused kernel a few times for rocprofv3 --kernel-trace."""
+"""Launch each fused kernel a few times for rocprofv3 --kernel-trace / --pmc (backward variant: CNR_FIELD_BWD)."""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -16,7 +16,7 @@ packed = ops.pack_weights(v["trunk"].contiguous())
 pts = (torch.rand(C, R, S, 3, device=dev) * 2 - 1)
 B = v["B"].contiguous()
 brows = torch.randn(C * n_obj, 4, 32, device=dev) * 0.1
-ray_row = (torch.randint(0, n_obj, (C, R), device=dev)).to(torch.int32)
+ray_row = (torch.randint(0, n_obj, (C, R), device=dev) + torch.arange(C, device=dev)[:, None] * n_obj).to(torch.int32)
 dsig = torch.randn(C, R, S, device=dev) * 1e-3
 drgb = torch.randn(C, R, S, 3, device=dev) * 1e-3
 dtrunk = torch.zeros(C, 13892, device=dev); dB = torch.zeros(C, 21, 3, device=dev); dbr = torch.zeros_like(brows)
@@ -24,5 +24,5 @@ wsp = torch.empty(_C.field_bwd_workspace_bytes(C, 0), device=dev, dtype=torch.ui
 sig = torch.empty(C, R, S, device=dev); rgb = torch.empty(C, R, S, 3, device=dev)
 for _ in range(10):
     _C.call("cnr_field_fwd", pts, B, packed, brows, ray_row, 2.0, sig, rgb, C, R, S)
-    _C.call("cnr_field_bwd", pts, B, packed, brows, ray_row, 2.0, dsig, drgb, 2048.0, dtrunk, dB, dbr, C, R, S, n_obj, blocks, wsp, wsp.numel())
+    ops.field_bwd(pts, B, packed, brows, ray_row, 2.0, dsig, drgb, 2048.0, dtrunk, dB, dbr, C, R, S, n_obj, blocks, wsp)
 torch.cuda.synchronize()
