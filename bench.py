@@ -192,7 +192,7 @@ def main():
            "config": {"workload": f"Replica room_0 shape: {C} category x {n_obj} objects, {R} rays x {S} samples "
                                   f"per GPU and step, latent {L}, W=32 CodeNeRF, random-pose synthetic pool, random init",
                       "rays_per_gpu": C * R, "samples_per_ray": S, "parallelism": f"dp{world}",
-                      "hipgraph": not args.no_graph and world == 1, "n_cu": info["n_cu"]},
+                      "hipgraph": ("one graph" if world == 1 else "two graphs around the all-reduce") if not args.no_graph else False, "n_cu": info["n_cu"]},
            "roofline": roofline}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

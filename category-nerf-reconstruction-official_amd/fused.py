@@ -74,7 +74,7 @@ class FusedCategoryTrainer:
     """C classes x n_obj objects, R rays per class per step, S = n1 + n2 samples per ray."""
 
     def __init__(self, cfg, n_cls, n_obj, pools, rays_per_step, device, seed=0, generator=None,
-                 grad_scale=None, bwd_blocks=0, process_group=None, use_graph=True):
+                 grad_scale=None, bwd_blocks=0, process_group=None, use_graph=True, split_graph=False):
         self.cfg, self.C, self.n_obj, self.R = cfg, n_cls, n_obj, rays_per_step
         self.device = torch.device(device)
         self.n1, self.n2 = cfg.n_bins_cam2surface, cfg.n_bins
@@ -111,12 +111,20 @@ class FusedCategoryTrainer:
         self.flags = torch.zeros(n_cls, device=self.device, dtype=torch.int32)
         self.dbias = self._gbuf[self.theta.numel():].view(n_cls * n_obj, 4, 32)
         self.use_graph = use_graph
+        self.split_graph = bool(split_graph)     # the two-graph form of the distributed step, for single-GPU tests
         self.graph = None
         self.steps_done = 0
         self._reshuffle()
 
     # ---- one step, eager (also the body that gets captured) ------------------------------------------
     def _step_body(self):
+        self._step_front()
+        if self.pg is not None:
+            parallel.allreduce_mean_(self.grad, self.pg, prescaled=True)   # one flat buffer, one collective
+        self._step_back()
+
+    def _step_front(self):
+        """param prep ... latent backward: everything up to the (optional) gradient all-reduce."""
         C, R, S, n_obj, L = self.C, self.R, self.S, self.n_obj, self.L
         cfg, v, lay = self.cfg, self.lay.views(self.theta), self.lay
         gv = self.lay.views(self.grad)
@@ -175,8 +183,10 @@ class FusedCategoryTrainer:
         # latent backward + code regulariser: one kernel over the flat rows
         reg = 0.0005 * inv_w                     # loss.py:5-15, train.py:165-167
         _C.call("cnr_latent_bwd", self.theta, *lat_args, zl, self.dbias, reg, self.grad)
-        if self.pg is not None:
-            parallel.allreduce_mean_(self.grad, self.pg, prescaled=True)   # one flat buffer, one collective
+
+    def _step_back(self):
+        """AdamW on the flat buffer + the step epilogue."""
+        C, R, o = self.C, self.R, self.bufs
         ops.adamw_step(self.theta, self.grad, self.exp_avg, self.exp_avg_sq, self.lr, (0.9, 0.999), 1e-8, self.wd,
                        0, d_state=self.d_state)
         # last node: loss values + flags from the render kernel's partials, the next slice's max depth, device-side
@@ -186,18 +196,38 @@ class FusedCategoryTrainer:
 
     def step(self):
         """One train step.  Returns nothing; ``self.losses`` (3,C) / ``self.flags`` (C,) hold the device-side
-        loss terms (depth, colour, opacity) and flags of the step just run."""
+        loss terms (depth, colour, opacity) and flags of the step just run.
+
+        After two eager steps the step is captured: one hipGraph on a single GPU; with a process group TWO graphs
+        around the all-reduce (front graph, eager RCCL call, back graph) -- three host calls per step instead of
+        ten, and no collective inside a capture."""
         if self.cursor + 2 * self.R > self.pool_rows:   # epoch end: reshuffle (scene_cateogries.py:439-449)
             self._reshuffle()
-        if not self.use_graph or self.pg is not None:
+        split = self.pg is not None or self.split_graph
+        if not self.use_graph or self.steps_done < 2:
             self._step_body()
-        elif self.graph is None and self.steps_done >= 2:
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self._step_body()
-            self.graph.replay()          # capture only records: run the step it stands for
         elif self.graph is None:
-            self._step_body()
+            if split:
+                ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ga):
+                    self._step_front()
+                ga.replay()                  # capture only records: run the part it stands for
+                if self.pg is not None:
+                    parallel.allreduce_mean_(self.grad, self.pg, prescaled=True)
+                with torch.cuda.graph(gb, pool=ga.pool()):
+                    self._step_back()
+                gb.replay()
+                self.graph = (ga, gb)
+            else:
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph):
+                    self._step_body()
+                self.graph.replay()
+        elif split:
+            self.graph[0].replay()
+            if self.pg is not None:
+                parallel.allreduce_mean_(self.grad, self.pg, prescaled=True)
+            self.graph[1].replay()
         else:
             self.graph.replay()
         self.cursor += self.R

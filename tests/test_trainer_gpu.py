@@ -101,6 +101,29 @@ def test_graph_replay_trains(cnr, dev):
     assert not bool((tr.flags.cpu() & 1).any())
 
 
+def test_eager_one_graph_and_two_graphs_train_identically(cnr, dev):
+    """The same 40 steps (same seeds, in-kernel Philox) run eagerly, as ONE captured hipGraph, and as the TWO graphs
+    of the distributed step (front | all-reduce | back, here with no process group): parameters bitwise equal.  The
+    kernels have no atomics on the gradient path, so this is exact, not a tolerance."""
+    cfg = cnr.cfg.synthetic_config(device=str(dev), latent_dim=256, n_bins_cam2surface=4, n_bins=28)
+    thetas = []
+    for kw in (dict(use_graph=False), dict(use_graph=True), dict(use_graph=True, split_graph=True)):
+        gen = torch.Generator().manual_seed(23)
+        pools = [cnr.scene_cateogries.synthetic_pool(16 * 256, 4, gen, "cpu")]
+        rng = torch.cuda.get_rng_state(dev)
+        torch.cuda.manual_seed(1234)               # the epoch reshuffle draws torch.randperm on the device
+        tr = cnr.fused.FusedCategoryTrainer(cfg, 1, 4, pools, 256, dev, seed=9, generator=gen, **kw)
+        for _ in range(40):                        # 16 x 256 rows / 256 per step: crosses two epoch reshuffles
+            tr.step()
+        torch.cuda.synchronize()
+        torch.cuda.set_rng_state(rng, dev)
+        if kw.get("split_graph"):
+            assert isinstance(tr.graph, tuple)
+        thetas.append((tr.theta.clone(), tr.losses.clone(), int(tr.d_state[0])))
+    for t, l, cur in thetas[1:]:
+        assert torch.equal(t, thetas[0][0]) and torch.equal(l, thetas[0][1]) and cur == thetas[0][2]
+
+
 @pytest.mark.parametrize("C,n_obj,L", [(1, 4, 256), (3, 2, 32), (2, 7, 64)])
 def test_param_prep_equals_separate_calls(cnr, dev, C, n_obj, L):
     """cnr_param_prep (pack | latent rows | zero fill side by side in one grid) == cnr_pack_weights +
