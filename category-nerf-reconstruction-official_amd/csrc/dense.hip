@@ -1,0 +1,174 @@
+// Dense layers of the background model: vMAP-style OccupancyMap, src/model.py:86-155 --
+// seven torch.nn.Linear (+ ReLU) with K = 87 / 128 / 215 / 170, N = 128 / 1 / 3, called un-vmapped on
+// 1200 rays x 14 samples per step (train.py:113-121,172-180).  Exact fp32 like the modular tier: the matrix core does
+// fp32 x fp32 products with fp32 accumulation (v_mfma_f32_32x32x2_f32), so the results sit within summation order of
+// torch.nn.functional.linear.
+//
+// One kernel covers the three products of a layer,  C[i][j] = sum_r A(i, r) * B(j, r):
+//   forward   y  = act(x W^T + b)   : A = x  (M x K),   B = W  (N x K)              r = K index
+//   backward  dx = dpre W           : A = dpre (M x N), B = W^T (r = N index runs over ROWS of W)
+//   backward  dW = dpre^T x , db    : A = dpre^T, B = x^T  (r = M index runs over rows of both) ; column K of the
+//                                     result is sum_m dpre = db (B(K, r) := 1)
+// with dpre = dy * (y > 0) formed on load when a ReLU mask is given.  Workgroup = 4 waves, 64 x 64 tile of C, each
+// wave a 32 x 32 quadrant; 32-deep slabs of A and B go through LDS as [i][r] / [j][r] (row stride 33: the per-lane
+// operand reads hit 32 different banks) whatever their orientation in memory -- global reads always run along the
+// contiguous dimension.
+#include "cnr_common.h"
+
+namespace {
+typedef float f16acc __attribute__((ext_vector_type(16)));
+constexpr int TM = 64, TN = 64, TK = 32, LDT = TK + 1;
+
+struct DenseArgs {
+  const float* A; int64_t lda; int a_trans;   // a_trans: A(i, r) = A[r * lda + i], else A[i * lda + r]
+  const float* B; int64_t ldb; int b_trans;
+  const float* mask; int mask_on_a;           // same layout as A: element used only where mask > 0
+  const float* bias; int relu;                // epilogue (per column j)
+  float* C; int64_t ldc;
+  float* extra_col; int extra_j;              // column j == extra_j (>= 0) goes to extra_col[i]; B(extra_j, r) = 1
+  int I, J, Rn;
+  int r_chunk; int64_t c_zstride;             // split over r: block z takes r in [z r_chunk, (z+1) r_chunk) and
+};                                            // writes its partial product to C + z c_zstride
+
+__global__ __launch_bounds__(256) void dense_kernel(DenseArgs p) {
+  __shared__ float As[TM * LDT];
+  __shared__ float Bs[TN * LDT];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int i0 = blockIdx.y * TM, j0 = blockIdx.x * TN;
+  const int wi = (wv >> 1) * 32, wj = (wv & 1) * 32;
+  f16acc acc;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+  const int r_lo = blockIdx.z * p.r_chunk, r_hi = r_lo + p.r_chunk < p.Rn ? r_lo + p.r_chunk : p.Rn;
+  float* Cz = p.C + (int64_t)blockIdx.z * p.c_zstride;
+  for (int r0 = r_lo; r0 < r_hi; r0 += TK) {
+    // ---- slab loads: 64 x 32 elements each, 8 per thread, consecutive threads along the contiguous dimension ----
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int idx = e * 256 + threadIdx.x;
+      int ii, rr;
+      if (p.a_trans) { ii = idx & 63; rr = idx >> 6; } else { rr = idx & 31; ii = idx >> 5; }
+      const int gi = i0 + ii, gr = r0 + rr;
+      float v = 0.0f;
+      if (gi < p.I && gr < r_hi) {
+        const int64_t off = p.a_trans ? (int64_t)gr * p.lda + gi : (int64_t)gi * p.lda + gr;
+        v = p.A[off];
+        if (p.mask && !(p.mask[off] > 0.0f)) v = 0.0f;
+      }
+      As[ii * LDT + rr] = v;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int idx = e * 256 + threadIdx.x;
+      int jj, rr;
+      if (p.b_trans) { jj = idx & 63; rr = idx >> 6; } else { rr = idx & 31; jj = idx >> 5; }
+      const int gj = j0 + jj, gr = r0 + rr;
+      float v = 0.0f;
+      if (gr < r_hi) {
+        if (gj == p.extra_j) v = 1.0f;
+        else if (gj < p.J) v = p.B[p.b_trans ? (int64_t)gr * p.ldb + gj : (int64_t)gj * p.ldb + gr];
+      }
+      Bs[jj * LDT + rr] = v;
+    }
+    __syncthreads();
+    // ---- 16 MFMAs of depth 2: lane (lane & 31) = row of its operand, (lane >> 5) = which of the two r ----
+#pragma unroll
+    for (int kk = 0; kk < TK; kk += 2) {
+      const float a = As[(wi + (lane & 31)) * LDT + kk + (lane >> 5)];
+      const float b = Bs[(wj + (lane & 31)) * LDT + kk + (lane >> 5)];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // ---- epilogue: accumulator layout col = lane & 31 (j), row = (q & 3) + 8 (q >> 2) + 4 (lane >> 5) (i) ----
+  const int j = j0 + wj + (lane & 31);
+  const float bj = (p.bias && j < p.J) ? p.bias[j] : 0.0f;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int i = i0 + wi + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+    if (i >= p.I) continue;
+    float v = acc[q] + bj;
+    if (p.relu) v = fmaxf(v, 0.0f);
+    if (j < p.J) Cz[(int64_t)i * p.ldc + j] = v;
+    else if (j == p.extra_j) {
+      if (p.extra_col) p.extra_col[i] = v;
+      else Cz[(int64_t)i * p.ldc + j] = v;   // split mode: the extra column is column J of the partial
+    }
+  }
+}
+
+// fixed-order sum of the split partials: out[i][j] = sum_z ws[z][i][j] (j < J), extra[i] = sum_z ws[z][i][J]
+__global__ __launch_bounds__(256) void dense_reduce_kernel(const float* __restrict__ ws, int nz, int I, int J,
+                                                           int has_extra, float* __restrict__ out,
+                                                           float* __restrict__ extra) {
+  const int ld = J + (has_extra ? 1 : 0);
+  const int64_t n = (int64_t)I * ld;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    float s = 0.0f;
+    for (int z = 0; z < nz; ++z) s += ws[(int64_t)z * n + e];
+    const int i = (int)(e / ld), j = (int)(e % ld);
+    if (j < J) out[(int64_t)i * J + j] = s;
+    else if (extra) extra[i] = s;
+  }
+}
+
+int launch(const DenseArgs& p, void* stream, int nz = 1) {
+  const int jn = p.extra_j >= 0 ? p.J + 1 : p.J;
+  dim3 grid((jn + TN - 1) / TN, (p.I + TM - 1) / TM, nz);
+  hipLaunchKernelGGL(dense_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+  CNR_LAUNCH_CHECK();
+  return CNR_OK;
+}
+}  // namespace
+
+extern "C" int cnr_dense_fwd(const float* x, const float* W, const float* b, float* y, int M, int K, int N, int relu,
+                             void* stream) {
+  if (!x || !W || !y || M <= 0 || K <= 0 || N <= 0) return CNR_E_ARG;
+  DenseArgs p{x, K, 0, W, K, 0, nullptr, 0, b, relu, y, N, nullptr, -1, M, N, K, K, 0};
+  return launch(p, stream);
+}
+
+// number of sample chunks of the dW product: enough blocks to fill the chip, at least 256 samples each
+static int dense_split(int M) {
+  int nz = (M + 255) / 256;
+  if (nz > 64) nz = 64;
+  return nz < 1 ? 1 : nz;
+}
+
+extern "C" int64_t cnr_dense_bwd_workspace_bytes(int M, int K, int N) {
+  if (M <= 0 || K <= 0 || N <= 0) return 0;
+  const int nz = dense_split(M);
+  return nz == 1 ? 0 : (int64_t)nz * N * (K + 1) * (int64_t)sizeof(float);
+}
+
+extern "C" int cnr_dense_bwd(const float* x, const float* W, const float* y, const float* dy, float* dx, float* dW,
+                             float* db, int M, int K, int N, int relu, void* workspace, int64_t workspace_bytes,
+                             void* stream) {
+  if (!x || !W || !dy || !dW || M <= 0 || K <= 0 || N <= 0 || (relu && !y)) return CNR_E_ARG;
+  const float* mask = relu ? y : nullptr;
+  if (dx) {  // dx (M x K) = dpre (M x N) W (N x K): r = N, B(j = k, r = n) = W[n * K + k]
+    DenseArgs p{dy, N, 0, W, K, 1, mask, 1, nullptr, 0, dx, K, nullptr, -1, M, K, N, N, 0};
+    const int rc = launch(p, stream);
+    if (rc) return rc;
+  }
+  // dW (N x K) = dpre^T x: r = M, A(i = n, r = m) = dy[m * N + n], B(j = k, r = m) = x[m * K + k]; column K = db.
+  // The contraction runs over all M samples while the result is tiny: split it over the grid's z (each block a
+  // chunk of samples, partial products to the workspace) and add the partials in a fixed order.
+  const int nz = dense_split(M);
+  if (nz == 1) {
+    DenseArgs p{dy, N, 1, x, K, 1, mask, 1, nullptr, 0, dW, K, db, db ? K : -1, N, K, M, M, 0};
+    return launch(p, stream);
+  }
+  const int ld = K + (db ? 1 : 0);
+  if (!workspace || workspace_bytes < (int64_t)nz * N * ld * (int64_t)sizeof(float)) return CNR_E_ARG;
+  const int chunk = ((M + nz - 1) / nz + TK - 1) / TK * TK;
+  DenseArgs p{dy, N, 1, x, K, 1, mask, 1, nullptr, 0, (float*)workspace, ld, nullptr, db ? K : -1, N, K, M, chunk,
+              (int64_t)N * ld};
+  const int rc = launch(p, stream, (M + chunk - 1) / chunk);
+  if (rc) return rc;
+  const int64_t n = (int64_t)N * ld;
+  hipLaunchKernelGGL(dense_reduce_kernel, dim3((unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024)), dim3(256), 0,
+                     (hipStream_t)stream, (const float*)workspace, (M + chunk - 1) / chunk, N, K, db ? 1 : 0, dW, db);
+  CNR_LAUNCH_CHECK();
+  return CNR_OK;
+}

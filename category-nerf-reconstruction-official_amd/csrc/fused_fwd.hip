@@ -8,6 +8,7 @@
 // waves per workgroup share the packed weight image in LDS (31 KB), >= 2 waves per SIMD for VALU rate.
 // Latent conditioning arrives as per-row effective biases  bias'_l[row] = W_l z_l[row] + b_l  (row =
 // object, or ray for per-ray codes): W_l (a + z) + b = W_l a + bias'_l, so the latent add costs no VALU.
+#include <cstdlib>
 #include "fused_common.h"
 #include "latent_common.h"
 
@@ -271,7 +272,8 @@ extern "C" int cnr_field_fwd(const float* pts, const float* B, const void* packe
   const int64_t N = (int64_t)R * S;
   const int64_t ntiles = (N + 31) / 32;
   int64_t blocks = (ntiles + 3) / 4;
-  if (blocks > 2048) blocks = 2048;
+  static const int64_t cap = getenv("CNR_FWD_BLOCKS") ? atoll(getenv("CNR_FWD_BLOCKS")) : 2048;
+  if (blocks > cap) blocks = cap;
   const size_t lds = (size_t)fz::PK_OFF_BWD + 66 * sizeof(float) + 8;
   dim3 grid((unsigned)blocks, (unsigned)C);
   hipLaunchKernelGGL(field_fwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, pts, B,

@@ -6,6 +6,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import ops
 from .ops import CodeNeRFTrunkFn, LATENT_LAYERS, TRUNK_LAYERS
 
 
@@ -61,3 +62,52 @@ class CodeNeRF(nn.Module):
             lin = self._linear(name)
             params += [lin.weight, lin.bias]
         return CodeNeRFTrunkFn.apply(x, zlat, *params)
+
+
+def fc_block(in_f, out_f):
+    """src/model.py:8-12 (Linear + ReLU); kept as a Sequential so that state_dict keys match ('<name>.0.weight')."""
+    return nn.Sequential(nn.Linear(in_f, out_f), nn.ReLU())
+
+
+class OccupancyMap(nn.Module):
+    """vMAP-style background / pretrained per-object field (src/model.py:86-155), same constructor, parameter names
+    and forward signature.  Every Linear (+ ReLU) runs on cnr_dense_fwd / cnr_dense_bwd (exact fp32 MFMA); the
+    concatenations are views/copies in torch."""
+
+    def __init__(self, emb_size1, emb_size2, hidden_size=256, do_color=True, hidden_layers_block=1):
+        super().__init__()
+        self.do_color = do_color
+        self.embedding_size1, self.embedding_size2 = emb_size1, emb_size2
+        self.in_layer = fc_block(emb_size1, hidden_size)
+        self.mid1 = nn.Sequential(*[fc_block(hidden_size, hidden_size) for _ in range(hidden_layers_block)])
+        self.cat_layer = fc_block(hidden_size + emb_size1, hidden_size)
+        self.mid2 = nn.Sequential(*[fc_block(hidden_size, hidden_size) for _ in range(hidden_layers_block)])
+        self.out_alpha = nn.Linear(hidden_size, 1)
+        if do_color:
+            self.color_linear = fc_block(emb_size2 + hidden_size, hidden_size)
+            self.out_color = nn.Linear(hidden_size, 3)
+
+    @staticmethod
+    def _fc(block, x):       # fc_block: Linear + ReLU in one kernel
+        return ops.DenseFn.apply(x, block[0].weight, block[0].bias, True)
+
+    def forward(self, x, noise_std=None, do_alpha=True, do_color=True, do_cat=True):
+        e1 = x[..., :self.embedding_size1]
+        fc2 = self._fc(self.in_layer, e1)
+        for blk in self.mid1:
+            fc2 = self._fc(blk, fc2)
+        fc3 = self._fc(self.cat_layer, torch.cat((fc2, e1), dim=-1)) if do_cat else fc2
+        fc4 = fc3
+        for blk in self.mid2:
+            fc4 = self._fc(blk, fc4)
+        alpha = None
+        if do_alpha:
+            raw = ops.DenseFn.apply(fc4, self.out_alpha.weight, self.out_alpha.bias, False)
+            if noise_std is not None:
+                raw = raw + torch.randn(raw.shape, device=x.device) * noise_std
+            alpha = raw * 10.0                         # unisurf scaling, src/model.py:142
+        color = None
+        if self.do_color and do_color:
+            fc5 = self._fc(self.color_linear, torch.cat((fc4, x[..., self.embedding_size1:]), dim=-1))
+            color = torch.sigmoid(ops.DenseFn.apply(fc5, self.out_color.weight, self.out_color.bias, False))
+        return alpha, color

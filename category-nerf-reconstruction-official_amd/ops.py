@@ -307,6 +307,37 @@ def pack_weights(trunk):
     return packed
 
 
+# ------------------------------------------------------------------------------------------------
+# SURVEY 8(f).1  dense layers of the background OccupancyMap (src/model.py:86-155)
+# ------------------------------------------------------------------------------------------------
+class DenseFn(Function):
+    """y = act(x W^T + b) on the exact-fp32 MFMA kernel (cnr_dense_fwd / cnr_dense_bwd); x (..., K), W (N, K)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, relu):
+        K, N = W.shape[1], W.shape[0]
+        x2 = x.reshape(-1, K).contiguous()
+        y = torch.empty(x2.shape[0], N, device=x.device, dtype=torch.float32)
+        _C.call("cnr_dense_fwd", x2, W.contiguous(), b.contiguous() if b is not None else None, y, x2.shape[0], K, N,
+                int(bool(relu)))
+        ctx.save_for_backward(x2, W, y)
+        ctx.relu, ctx.xshape, ctx.has_b = bool(relu), x.shape, b is not None
+        return y.reshape(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, W, y = ctx.saved_tensors
+        M, K, N = x2.shape[0], W.shape[1], W.shape[0]
+        dy2 = dy.reshape(M, N).contiguous()
+        dx = torch.empty(M, K, device=dy.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        dW = torch.empty(N, K, device=dy.device, dtype=torch.float32)
+        db = torch.empty(N, device=dy.device, dtype=torch.float32) if ctx.has_b else None
+        wsb = int(_C.load().cnr_dense_bwd_workspace_bytes(M, K, N))
+        ws = torch.empty(max(wsb, 16), device=dy.device, dtype=torch.uint8)
+        _C.call("cnr_dense_bwd", x2, W.contiguous(), y, dy2, dx, dW, db, M, K, N, int(ctx.relu), ws, wsb)
+        return (dx.reshape(ctx.xshape) if dx is not None else None), dW, db, None
+
+
 # cnr_field_bwd variants: "split" = two block-split launches (csrc/fused_bwd.hip), "pipe2"/"pipe3" = the single
 # pipelined launch with 2 / 3 chain waves per workgroup (csrc/fused_bwd_pipe.hip).  Same results contract.
 FIELD_BWD_VARIANT = os.environ.get("CNR_FIELD_BWD", "pipe3")

@@ -129,14 +129,18 @@ class sceneCategory():
     @classmethod
     def from_pool(cls, cfg, cls_id, obj_ids, pool, seed=0):
         self = object.__new__(cls)
-        assert cls_id != 0, "background branch is a 'next' row"
         self.cls_id = cls_id
-        self.obj_ids = list(obj_ids)
+        self.obj_ids = list(obj_ids) if cls_id != 0 else [0]          # src/scene_cateogries.py:109-112
         self.data_device = cfg.data_device
         self.training_device = cfg.training_device
-        self.obj_scale = cfg.obj_scale
-        self.hidden_feature_size = cfg.hidden_feature_size
-        self.n_bins_cam2surface = cfg.n_bins_cam2surface
+        if cls_id == 0:   # background (:116-119): vMAP OccupancyMap, world-frame rays, its own bin counts
+            self.obj_scale = cfg.bg_scale
+            self.hidden_feature_size = cfg.hidden_feature_size_bg
+            self.n_bins_cam2surface = cfg.n_bins_cam2surface_bg
+        else:
+            self.obj_scale = cfg.obj_scale
+            self.hidden_feature_size = cfg.hidden_feature_size
+            self.n_bins_cam2surface = cfg.n_bins_cam2surface
         self.min_bound, self.max_bound = cfg.min_depth, cfg.max_depth
         self.n_bins = cfg.n_bins
         self.surface_eps, self.stop_eps = cfg.surface_eps, cfg.stop_eps
@@ -144,13 +148,16 @@ class sceneCategory():
         self.rgbs_batch_all = pool["rgbs"].to(dev)
         self.depth_batch_all = pool["depth"].to(dev)
         self.ray_dirs_batch_all = pool["dirs"].to(dev)
-        self.t_co_batch_all = pool["T_co"].to(dev)
-        self.t_wc_batch_all = pool["T_wc"].to(dev) if len(self.obj_ids) == 1 else None
-        self.batch_indices_all = pool["indices"].to(dev)
+        self.world_frame = cls_id == 0 or len(self.obj_ids) == 1       # origin_dirs_W vs origin_dirs_O (:374-386)
+        self.t_co_batch_all = pool["T_co"].to(dev) if not self.world_frame else None
+        self.t_wc_batch_all = pool["T_wc"].to(dev) if self.world_frame else None
+        self.batch_indices_all = pool["indices"].to(dev) if cls_id != 0 else \
+            torch.zeros(pool["depth"].shape[0], dtype=torch.int64, device=dev)
         self.i_batch = 0
         self.parity_draws = None  # (u, g) tensors for the next get_training_samples call (tests)
         self._seed, self._calls = int(seed) * 7919 + int(cls_id) + 1, 0
         trainer_cfg = copy.copy(cfg)
+        trainer_cfg.hidden_feature_size = self.hidden_feature_size     # :328-330
         trainer_cfg.obj_scale = self.obj_scale
         self.trainer = trainer.Trainer(trainer_cfg, cls_id, self.obj_ids)
         return self
@@ -166,11 +173,12 @@ class sceneCategory():
 
     def get_training_samples(self, n_samples):
         """-> (gt_rgb uint8 (R,3), gt_depth (R,), depth_mask bool (R,), obj_mask uint8 (R,),
-        input_pcs (R,S,3), sampled_z (R,S), indices int64 (R,))  -- src/scene_cateogries.py:421-451."""
+        input_pcs (R,S,3), sampled_z (R,S), indices int64 (R,))  -- src/scene_cateogries.py:353-451.  The background
+        (cls_id 0) is the one-pool case of the per-object loop at :353-420: world-frame rays, indices all zero."""
         sl = slice(self.i_batch, self.i_batch + n_samples)
         batch_indices = self.batch_indices_all[sl]
         rgbs, depth, dirs = self.rgbs_batch_all[sl], self.depth_batch_all[sl], self.ray_dirs_batch_all[sl]
-        single = len(self.obj_ids) == 1
+        single = self.world_frame
         T = self.t_wc_batch_all[sl] if single else self.t_co_batch_all[sl]
         u, g = self.parity_draws if self.parity_draws is not None else (None, None)
         self.parity_draws = None
@@ -182,9 +190,10 @@ class sceneCategory():
             self.rgbs_batch_all = self.rgbs_batch_all[rand_idx]
             self.depth_batch_all = self.depth_batch_all[rand_idx]
             self.ray_dirs_batch_all = self.ray_dirs_batch_all[rand_idx]
-            self.t_co_batch_all = self.t_co_batch_all[rand_idx]
             if single:
                 self.t_wc_batch_all = self.t_wc_batch_all[rand_idx]
+            else:
+                self.t_co_batch_all = self.t_co_batch_all[rand_idx]
             self.i_batch = 0
         return (rgbs[:, :3], depth, out["depth_mask"][0].bool(), out["labels"][0], out["pts"][0],
                 out["z"][0], batch_indices)

@@ -21,14 +21,22 @@ class Trainer:
         self.n_unidir_funcs = cfg.n_unidir_funcs
         self.emb_size1 = 21 * (3 + 1) + 3
         self.emb_size2 = 21 * (5 + 1) + 3 - self.emb_size1
-        if cls_id == 0:
-            raise NotImplementedError("background OccupancyMap path is a 'next' row (SURVEY.md §8(f).1)")
-        self.net_hyperparams = cfg.net_hyperparams
-        self.load_codeNeRF()
-        self.load_codes()
+        if cls_id == 0:      # background: vMAP OccupancyMap, no codes (src/trainer.py:23-25)
+            self.hidden_feature_size = cfg.hidden_feature_size
+            self.load_NeRF()
+        else:
+            self.net_hyperparams = cfg.net_hyperparams
+            self.load_codeNeRF()
+            self.load_codes()
         self.extent_dict = None
-        self.bound_extent = 0.9
+        self.bound_extent = 0.995 if cls_id == 0 else 0.9
         self.scale_template = None
+
+    def load_NeRF(self):
+        self.fc_occ_map = model.OccupancyMap(self.emb_size1, self.emb_size2,
+                                             hidden_size=self.hidden_feature_size).to(self.device)
+        self.fc_occ_map.apply(model.init_weights).to(self.device)
+        self.pe = embedding.UniDirsEmbed(max_deg=self.n_unidir_funcs, scale=self.obj_scale).to(self.device)
 
     def load_codeNeRF(self):
         self.fc_occ_map = model.CodeNeRF(self.emb_size1, self.emb_size2, **self.net_hyperparams).to(self.device)
@@ -47,8 +55,9 @@ class Trainer:
 
     def eval_points(self, points, inst_id=None, chunk_size=500000):
         """Forward-only occupancy / colour of (N,3) points for one object (src/trainer.py:125-151)."""
-        obj_idx = torch.tensor(self.inst_id_to_index[inst_id], device=self.device)
-        shape_code, texture_code = self.shape_codes(obj_idx), self.texture_codes(obj_idx)
+        if self.cls_id != 0:
+            obj_idx = torch.tensor(self.inst_id_to_index[inst_id], device=self.device)
+            shape_code, texture_code = self.shape_codes(obj_idx), self.texture_codes(obj_idx)
         alpha, color = [], []
         n_chunks = int(np.ceil(points.shape[0] / chunk_size))
         with torch.no_grad():
@@ -56,7 +65,10 @@ class Trainer:
                 pts = points[k * chunk_size:(k + 1) * chunk_size, None, :]         # (n,1,3): S = 1
                 emb = self.pe(pts)
                 n = pts.shape[0]
-                a_k, c_k = self.fc_occ_map(emb, shape_code.expand(n, 1, -1), texture_code.expand(n, 1, -1))
+                if self.cls_id == 0:
+                    a_k, c_k = self.fc_occ_map(emb)
+                else:
+                    a_k, c_k = self.fc_occ_map(emb, shape_code.expand(n, 1, -1), texture_code.expand(n, 1, -1))
                 alpha.append(a_k.reshape(-1))
                 color.append(c_k.reshape(-1, 3))
         alpha, color = torch.cat(alpha), torch.cat(color)

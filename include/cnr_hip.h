@@ -190,6 +190,19 @@ int cnr_field_bwd(const float* pts, const float* B, const void* packed, const fl
                   float grad_scale, float* dtrunk, float* dB, float* dbiasrows, int C, int R, int S,
                   int rows_per_class, int max_blocks, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- dense layers of the background model, OccupancyMap (src/model.py:86-155) -----------------
+ * y (M,N) = act(x (M,K) W^T + b), W (N,K) row-major as torch.nn.Linear stores it, relu != 0: act = ReLU.
+ * Exact fp32 on the matrix core (v_mfma_f32_32x32x2_f32: fp32 products, fp32 accumulation).
+ * Backward: dpre = dy * (y > 0) (relu) or dy; dx (M,K) = dpre W (NULL to skip), dW (N,K) = dpre^T x, db (N,) =
+ * column sums of dpre (NULL to skip); all three OVERWRITTEN.  y is only read when relu != 0.
+ * workspace: >= cnr_dense_bwd_workspace_bytes(M, K, N) bytes (0 for M <= 256): the dW product is split over
+ * chunks of samples whose partial results are added in a fixed order (reproducible, no atomics). */
+int cnr_dense_fwd(const float* x, const float* W, const float* b, float* y, int M, int K, int N, int relu,
+                  void* stream);
+int64_t cnr_dense_bwd_workspace_bytes(int M, int K, int N);
+int cnr_dense_bwd(const float* x, const float* W, const float* y, const float* dy, float* dx, float* dW, float* db,
+                  int M, int K, int N, int relu, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* Parameter-only work of one fused-trainer step in ONE launch, three independent jobs side by side in the grid:
  * cnr_pack_weights (trunk of class c at theta + c * class_stride + off_trunk), cnr_latent_fwd (same arguments), and
  * a zero fill of zero_buf[0 .. zero_count) (the gradient buffers; 16-B aligned; zero_count 0 to skip). */

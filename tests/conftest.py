@@ -16,8 +16,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-def golden_names():
+def _all_golden():
     return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
+
+
+def golden_names():
+    """object-branch fixtures (CodeNeRF train step)"""
+    return [n for n in _all_golden() if not n.startswith("bg_")]
+
+
+def bg_golden_names():
+    """background-branch fixtures (OccupancyMap train step; meta[3] = hidden size)"""
+    return [n for n in _all_golden() if n.startswith("bg_")]
 
 
 class Golden:

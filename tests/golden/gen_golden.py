@@ -246,6 +246,96 @@ def run_case(name, seed, C, R, S, L, n_obj=4, single_obj=False, empty_mask_cls=N
     print(f"{name}: loss={loss.item():.6f}  -> {os.path.getsize(path) / 1e6:.2f} MB")
 
 
+def run_bg_case(name, seed, R, hidden=128, n1=5, n2=9):
+    """Background branch of one train step (train.py:113-121,172-184): Trainer(cls_id=0) -> OccupancyMap(hidden)
+    + UniDirsEmbed, world-frame rays (origin_dirs_W), sample_3d_points, PE -> OccupancyMap -> step_batch_loss with a
+    class dim of 1, backward, AdamW.  Same fixture layout as run_case where the fields coincide."""
+    torch.manual_seed(seed)
+    gen = torch.Generator().manual_seed(2000 + seed)
+    S, eps, stop_eps, scale = n1 + n2, 0.1, 0.05, 10.0
+    cfg = SimpleNamespace(training_device="cpu", obj_scale=scale, n_unidir_funcs=5, hidden_feature_size=hidden)
+    tr = ref_trainer.Trainer(cfg, cls_id=0, inst_ids=[0])
+    with torch.no_grad():
+        tr.pe.B_layer.weight.add_(0.01 * torch.randn(21, 3, generator=gen))
+    opt = torch.optim.AdamW([torch.autograd.Variable(torch.tensor(0))], lr=1e-3, weight_decay=0.013)
+    opt.add_param_group({"params": tr.fc_occ_map.parameters(), "lr": 1e-3, "weight_decay": 0.013})
+    opt.add_param_group({"params": tr.pe.parameters(), "lr": 1e-3, "weight_decay": 0.013})
+    names = [n for n, _ in tr.fc_occ_map.named_parameters()]
+    mlp0 = {n: p.detach().clone() for n, p in tr.fc_occ_map.named_parameters()}
+    B0 = tr.pe.B_layer.weight.detach().clone()
+
+    rgbs, depth, dirs, _, _ = make_pool(gen, R, 1)
+    depth = depth * 2.0                                  # room-scale depths
+    T = torch.stack([rand_pose(gen, False) for _ in range(R // 16 + 1)]).repeat_interleave(16, 0)[:R]   # T_wc
+    origins, dirs_o = ref_sc.origin_dirs_W(T, dirs)
+    o2, d2 = O.origin_dirs_W(T, dirs)
+    assert torch.equal(origins, o2) and torch.equal(dirs_o, d2)
+    ns = SimpleNamespace(n_bins_cam2surface=n1, n_bins=n2, surface_eps=eps, stop_eps=stop_eps,
+                         data_device="cpu", min_bound=0.0, this_obj=1)
+    state = torch.get_rng_state()
+    ref_out = ref_sc.sceneCategory.sample_3d_points(ns, rgbs, depth, origins, dirs_o)
+    torch.set_rng_state(state)
+    u, g = torch.zeros(R, S), torch.zeros(R, n2)
+    invalid = depth <= 0.0
+    valid = ~invalid
+    if invalid.any():
+        u[invalid] = torch.rand(int(invalid.sum()), S)
+    if valid.any():
+        u[valid, :n1] = torch.rand(int(valid.sum()), n1)
+        obj = (rgbs[:, 3] == 1) & valid
+        if obj.any():
+            g[obj] = torch.empty(int(obj.sum()), n2).normal_(mean=0.0, std=eps / 3.0)
+        oth = (rgbs[:, 3] != 1) & valid
+        if oth.any():
+            u[oth, n1:] = torch.rand(int(oth.sum()), n2)
+    mine = O.sample_3d_points(rgbs, depth, origins, dirs_o, u, g, n1, n2, eps, stop_eps)
+    for a, b in zip(ref_out, mine):
+        assert torch.equal(a, b), "oracle sampling != reference (bg)"
+    gt_rgb, gt_depth, depth_mask, labels, pts, z = ref_out
+    gt_rgb = gt_rgb / 255.0
+
+    emb = tr.pe(pts)
+    alpha, color = tr.fc_occ_map(emb)
+    loss, ld, _ = ref_loss.step_batch_loss(alpha[None], color[None], gt_depth[None], gt_rgb[None], labels[None],
+                                           depth_mask[None], z[None])
+    loss.backward()
+    grads = {n: p.grad.detach().clone() for n, p in tr.fc_occ_map.named_parameters()}
+    gB = tr.pe.B_layer.weight.grad.detach().clone()
+    opt.step()
+
+    # ---- the oracle must reproduce it ----------------------------------------------------------
+    mlp_o = {n: v.clone().requires_grad_() for n, v in mlp0.items()}
+    B_o = B0.clone().requires_grad_()
+    emb_o = O.unidirs_embed(pts[None], B_o[None], scale)[0]
+    a_o, c_o = O.occupancy_map_forward(mlp_o, emb_o)
+    loss_o, aux, _ = O.step_batch_loss(a_o[None], c_o[None], gt_depth[None], gt_rgb[None], labels[None],
+                                       depth_mask[None], z[None])
+    loss_o.backward()
+
+    def close(a, b, what, tol=2e-6):
+        a, b = a.detach().double(), b.detach().double()
+        err = (a - b).norm() / max(b.norm().item(), 1e-30)
+        assert err <= tol, f"{name}: oracle {what} off by {err:.3e}"
+    close(emb_o, emb, "emb"); close(a_o, alpha, "alpha"); close(c_o, color, "color"); close(loss_o, loss, "loss")
+    for n in names:
+        close(mlp_o[n].grad, grads[n], "grad " + n, 2e-5)
+    close(B_o.grad, gB, "grad B", 2e-5)
+
+    f = lambda t: t.detach().cpu().numpy()
+    d = dict(meta=np.array([1, R, S, hidden, 1, n1, n2, 1], dtype=np.int64), scale=np.float32(scale),
+             eps=np.float32(eps), stop_eps=np.float32(stop_eps), pool_rgbs=f(rgbs[None]), pool_depth=f(depth[None]),
+             pool_dirs=f(dirs[None]), pool_T=f(T[None]), u=f(u[None]), g=f(g[None]), z=f(z[None]), pts=f(pts[None]),
+             gt_rgb=f(gt_rgb[None]), gt_depth=f(gt_depth[None]), depth_mask=f(depth_mask[None]), labels=f(labels[None]),
+             B=f(B0[None]), sigmas=f(alpha[None]), rgbs=f(color[None]), loss=f(loss), loss_depth=f(ld["depth"]),
+             loss_color=f(ld["color"]), loss_opacity=f(ld["opacity"]), grad_B=f(gB[None]),
+             new_B=f(tr.pe.B_layer.weight[None]))
+    for n, p in tr.fc_occ_map.named_parameters():
+        d["mlp." + n] = f(mlp0[n]); d["grad." + n] = f(grads[n]); d["new." + n] = f(p)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **d)
+    print(f"{name}: loss={loss.item():.6f}  -> {os.path.getsize(path) / 1e6:.2f} MB")
+
+
 def main():
     run_case("s0_c1_r64_s16_l256", 0, 1, 64, 16, 256)
     run_case("s1_c1_r64_s16_l256", 1, 1, 64, 16, 256, keep_emb=False)
@@ -256,7 +346,13 @@ def main():
     run_case("edge_empty_mask", 3, 2, 64, 16, 32, empty_mask_cls=1, keep_emb=False)
     run_case("edge_invalid_depth", 4, 1, 64, 16, 256, all_invalid=True, keep_emb=False)
     run_case("edge_single_obj_W", 5, 1, 64, 16, 256, single_obj=True, keep_emb=False)
+    run_bg_case("bg_r240_s14_h128", 6, 240)            # background model: OccupancyMap(128), 5 + 9 samples
+    run_bg_case("bg_r100_s14_h32", 7, 100, hidden=32)  # the pretrained per-object vMAP shape (hidden 32)
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "bg":      # only the background fixtures
+        run_bg_case("bg_r240_s14_h128", 6, 240)
+        run_bg_case("bg_r100_s14_h32", 7, 100, hidden=32)
+    else:
+        main()

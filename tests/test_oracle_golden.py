@@ -2,7 +2,7 @@
 import pytest
 import torch
 
-from conftest import Golden, golden_names, rel_l2
+from conftest import Golden, bg_golden_names, golden_names, rel_l2
 from oracle import ref_cpu as O
 
 
@@ -67,3 +67,34 @@ def test_empty_mask_quirk():
     g = Golden("edge_empty_mask")
     assert float(g.t("loss_depth").abs().sum()) == 0.0 and float(g.t("loss_color").abs().sum()) == 0.0
     assert float(g.t("loss_opacity").abs().sum()) > 0.0
+
+
+def _bg_oracle_step(g):
+    mlp = {k: v.clone().requires_grad_() for k, v in g.mlp().items()}
+    B = g.t("B").clone().requires_grad_()
+    emb = O.unidirs_embed(g.t("pts"), B, g.scale)[0]
+    alpha, color = O.occupancy_map_forward(mlp, emb)
+    loss, aux, _ = O.step_batch_loss(alpha[None], color[None], g.t("gt_depth"), g.t("gt_rgb"), g.t("labels"),
+                                     g.t("depth_mask"), g.t("z"))
+    loss.backward()
+    return mlp, B, alpha, color, loss, aux
+
+
+@pytest.mark.parametrize("name", bg_golden_names())
+def test_background_branch(name):
+    """the background step (world-frame rays, OccupancyMap) of the oracle against the reference's
+    vectors: sampling bit-exact, forward <= 2e-6, gradients <= 2e-5."""
+    g = Golden(name)
+    o, d = O.origin_dirs_W(g.t("pool_T")[0], g.t("pool_dirs")[0])
+    out = O.sample_3d_points(g.t("pool_rgbs")[0], g.t("pool_depth")[0], o, d, g.t("u")[0], g.t("g")[0], g.n1, g.n2,
+                             g.eps, g.stop_eps)
+    assert torch.equal(out[5], g.t("z")[0]) and torch.equal(out[4], g.t("pts")[0])
+    assert torch.equal(out[2], g.t("depth_mask")[0]) and torch.equal(out[3], g.t("labels")[0])
+    mlp, B, alpha, color, loss, aux = _bg_oracle_step(g)
+    assert rel_l2(alpha[None], g.t("sigmas")) < 2e-6 and rel_l2(color[None], g.t("rgbs")) < 2e-6
+    assert rel_l2(loss, g.t("loss")) < 2e-6
+    for k in ("depth", "color", "opacity"):
+        assert rel_l2(aux[k], g.t("loss_" + k)) < 2e-6
+    for n, p in mlp.items():
+        assert rel_l2(p.grad, g.t("grad." + n)) < 2e-5, n
+    assert rel_l2(B.grad, g.t("grad_B")[0]) < 2e-5

@@ -8,7 +8,7 @@ against an fp64 evaluation of the oracle: ours must be within 5x of it."""
 import pytest
 import torch
 
-from conftest import Golden, golden_names, rel_l2
+from conftest import Golden, bg_golden_names, golden_names, rel_l2
 from oracle import ref_cpu as O
 
 pytestmark = pytest.mark.gpu
@@ -282,3 +282,67 @@ def test_render_loss_single_launch_equals_three_calls(cnr, dev, C, R, S, empty):
         assert torch.equal(a, b)
     if empty:
         assert int(flags[0]) & 4 and float(losses[1].abs().sum()) == 0.0
+
+
+# ---- background model (OccupancyMap) ---------------------------------------------------
+@pytest.mark.parametrize("M,K,N,relu", [(16800, 87, 128, True), (16800, 215, 128, True), (16800, 128, 1, False),
+                                        (1000, 170, 128, True), (77, 128, 3, False), (64, 32, 64, True),
+                                        (1, 87, 32, True)])
+def test_dense_kernels_against_torch(cnr, dev, M, K, N, relu):
+    """cnr_dense_fwd / cnr_dense_bwd (exact-fp32 MFMA) == torch.nn.functional.linear (+ ReLU) and its autograd,
+    to fp32 summation order (fp64 evaluation as the yardstick)."""
+    gen = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=gen).to(dev).requires_grad_()
+    W = (torch.randn(N, K, generator=gen) / K ** 0.5).to(dev).requires_grad_()
+    b = (torch.randn(N, generator=gen) * 0.1).to(dev).requires_grad_()
+    y = cnr.ops.DenseFn.apply(x, W, b, relu)
+    dy = torch.randn(M, N, generator=gen).to(dev)
+    y.backward(dy)
+    xd, Wd, bd = (t.detach().double().requires_grad_() for t in (x, W, b))
+    yd = torch.nn.functional.linear(xd, Wd, bd)
+    yd = torch.relu(yd) if relu else yd
+    yd.backward(dy.double())
+    assert rel_l2(y, yd) < 2e-6
+    # ReLU'(0) ties: a pre-activation within fp32 rounding of zero can be masked differently in fp64
+    tol = 1e-5 if not relu else 2e-4
+    assert rel_l2(x.grad, xd.grad) < tol and rel_l2(W.grad, Wd.grad) < tol and rel_l2(b.grad, bd.grad) < tol
+
+
+@pytest.mark.parametrize("name", bg_golden_names())
+def test_background_step_against_reference(cnr, dev, name):
+    """The background branch through the drop-in modules (sceneCategory.from_pool(cls_id=0) -> Trainer ->
+    UniDirsEmbed -> OccupancyMap -> loss.step_batch_loss, train.py:113-121,172-184) against the reference's vectors:
+    sampling bit-exact, alpha / colour / losses <= 2e-5, gradients within GRAD_TOL, AdamW update."""
+    g = Golden(name, dev)
+    hidden = g.L                                                   # meta[3] holds the hidden size here
+    cfg = cnr.cfg.synthetic_config(device=str(dev), latent_dim=32, obj_scale=g.scale, n_bins_cam2surface=g.n1,
+                                   n_bins=g.n2)
+    cfg.bg_scale, cfg.hidden_feature_size_bg, cfg.n_bins_cam2surface_bg = g.scale, hidden, g.n1
+    cfg.surface_eps, cfg.stop_eps = g.eps, g.stop_eps
+    pool = dict(rgbs=g.t("pool_rgbs")[0], depth=g.t("pool_depth")[0], dirs=g.t("pool_dirs")[0], T_wc=g.t("pool_T")[0])
+    # a pool longer than one slice so that no reshuffle happens inside the call
+    pool = {k: torch.cat([v, v, v]) for k, v in pool.items()}
+    sc = cnr.scene_cateogries.sceneCategory.from_pool(cfg, 0, [0], pool)
+    assert type(sc.trainer.fc_occ_map).__name__ == "OccupancyMap"
+    sc.trainer.fc_occ_map.load_state_dict(g.mlp())
+    with torch.no_grad():
+        sc.trainer.pe.B_layer.weight.copy_(g.t("B")[0])
+    sc.parity_draws = (g.t("u"), g.t("g"))
+    gt_rgb, gt_depth, dmask, labels, pts, z, idx = sc.get_training_samples(g.R)
+    assert torch.equal(labels, g.t("labels")[0]) and torch.equal(dmask, g.t("depth_mask")[0])
+    assert rel_l2(z, g.t("z")[0]) < 1e-6 and rel_l2(pts, g.t("pts")[0]) < 1e-5 and int(idx.abs().sum()) == 0
+    params = list(sc.trainer.fc_occ_map.parameters()) + list(sc.trainer.pe.parameters())
+    opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=0.013)
+    emb = sc.trainer.pe(pts)
+    alpha, color = sc.trainer.fc_occ_map(emb)
+    assert rel_l2(alpha[None], g.t("sigmas")) < FWD_TOL and rel_l2(color[None], g.t("rgbs")) < FWD_TOL
+    loss, ld, _ = cnr.loss.step_batch_loss(alpha[None], color[None], gt_depth[None], gt_rgb[None] / 255.0, labels[None],
+                                           dmask[None], z[None])
+    assert rel_l2(loss, g.t("loss")) < FWD_TOL
+    loss.backward()
+    for n, p in sc.trainer.fc_occ_map.named_parameters():
+        assert rel_l2(p.grad, g.t("grad." + n)) < GRAD_TOL, n
+    assert rel_l2(sc.trainer.pe.B_layer.weight.grad, g.t("grad_B")[0]) < GRAD_TOL
+    opt.step()
+    for n, p in sc.trainer.fc_occ_map.named_parameters():
+        assert rel_l2(p, g.t("new." + n)) < 1e-4, n
