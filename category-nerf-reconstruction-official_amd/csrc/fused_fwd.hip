@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void param_prep_kernel(const float* __restrict
 
 namespace {
 
-__global__ __launch_bounds__(256, 2) void field_fwd_kernel(
+__global__ __launch_bounds__(256, 4) void field_fwd_kernel(
     const float* __restrict__ pts, const float* __restrict__ Bdir, const unsigned char* __restrict__ packed,
     const float* __restrict__ biasrows, const int* __restrict__ ray_row, float inv_scale,
     float* __restrict__ sigmas, float* __restrict__ rgbs, int64_t N /* samples per class */, int S, int R) {

@@ -4,9 +4,10 @@ functions ``origin_dirs_O/W``, ``stratified_bins``, ``normal_bins_sampling``, ``
 
 Differences by design: the ray pool is DEVICE-resident (the reference slices CPU
 tensors and pays an H2D copy per step), and the whole of a2-a5 for a pool slice is one HIP launch
-(cnr_sample_rays) with no count_nonzero host syncs.  Building the pool from dataset frames
-(:107-350) is out of scope; :func:`synthetic_pool` generates the SURVEY §8(d) random-pose pool and
-``sceneCategory.from_pool`` accepts any pool with the same fields.
+(cnr_sample_rays) with no count_nonzero host syncs.  ``sceneCategory(cfg, cls_id, inst_dict, sample_dict, rays)``
+builds the pool from dataset frames (:107-350) with one device gather (cnr_gather_pool);
+:func:`synthetic_pool` generates the SURVEY §8(d) random-pose pool and ``sceneCategory.from_pool`` accepts any
+pool with the same fields.
 """
 import copy
 
@@ -117,18 +118,84 @@ def synthetic_pool(n_rays, n_obj, generator, device, width=1200, height=680, fx=
 class sceneCategory():
     """shared MLP + instance-specific codes for one category; single batch holds all its instances.
 
-    Construct with :meth:`from_pool` (the dataset-driven ``__init__`` of the reference,
-    src/scene_cateogries.py:107-350, is out of scope)."""
+    Construct from the reference's dataset dictionaries (``__init__``, src/scene_cateogries.py:107-350) or from a
+    ready pool (:meth:`from_pool`)."""
 
     other_obj, this_obj, unknown_obj = 0, 1, 2  # pixel states (:141-143)
 
     def __init__(self, cfg, cls_id, inst_dict, sample_dict, cached_rays_dir):
-        raise NotImplementedError("building the ray pool from dataset frames is out of scope; "
-                                  "use sceneCategory.from_pool(cfg, cls_id, obj_ids, pool)")
+        """The reference's constructor (src/scene_cateogries.py:107-350): ``inst_dict`` {inst_id: {T_obj, bbox3D,
+        frame_info: [{frame, bbox}]}} (background: {bbox3D, frame_info}), ``sample_dict`` {frame: {image (W,H,3)
+        u8, depth (W,H), T (4,4) = T_wc, obj_mask (W,H)}}, ``cached_rays_dir`` (W,H,3).  The frames go to the
+        device once; every crop of every instance becomes pool rows in one gather launch, global shuffle included
+        (same ``np.random.shuffle`` call as the reference, so a seeded run gives the same pool order)."""
+        obj_ids = list(inst_dict.keys()) if cls_id != 0 else [0]
+        self._init_common(cfg, cls_id, obj_ids)
+        dev = self.data_device
+        init_idx = list(sample_dict.keys())[0]
+        self.frames_width, self.frames_height = sample_dict[init_idx]["image"].shape[:2]
+        W, H = self.frames_width, self.frames_height
+        infos = {0: inst_dict} if cls_id == 0 else inst_dict
+        frames = sorted({fi["frame"] for info in infos.values() for fi in info["frame_info"]})
+        slot = {f: i for i, f in enumerate(frames)}
+        stack = lambda key, dt: torch.from_numpy(np.stack([np.asarray(sample_dict[f][key]) for f in frames])).to(dt)
+        images = stack("image", torch.uint8).to(dev).contiguous()
+        depths = stack("depth", torch.float32).to(dev).contiguous()
+        masks = stack("obj_mask", torch.int32).to(dev).contiguous()
+        T_wc = stack("T", torch.float32).to(dev)
+        rays = torch.as_tensor(cached_rays_dir, dtype=torch.float32).to(dev).contiguous()
+        crops, T_crop, areas = [], [], []
+        if cls_id != 0:
+            self.extent_dict, self.object_tensor_dict = {}, {}
+        for inst_id in obj_ids:
+            info = infos[inst_id]
+            if cls_id != 0:
+                self.extent_dict[inst_id] = info["bbox3D"].extent if "bbox3D" in info else np.array([2.0, 2.0, 2.0])
+                T_obj = torch.from_numpy(np.asarray(info["T_obj"]).astype(np.float32)).to(dev)
+                self.object_tensor_dict[inst_id] = T_obj      # the 4x4 sim3 itself (the reference keeps scale+quat+t)
+            index = 0 if len(obj_ids) == 1 else obj_ids.index(inst_id)
+            sl = [slot[fi["frame"]] for fi in info["frame_info"]]
+            t_wc = T_wc[sl]                                                        # (n_frames_of_inst, 4, 4)
+            pose = t_wc if self.world_frame else torch.linalg.inv(t_wc) @ T_obj[None]  # :237-238
+            for idx, fi in enumerate(info["frame_info"]):
+                w0, w1, h0, h1 = [int(v) for v in fi["bbox"]]
+                crops.append([sl[idx], int(inst_id), index, w0, w1, h0, h1, idx])
+                areas.append((w1 - w0) * (h1 - h0))
+            T_crop.append(pose)
+            if cls_id == 0:
+                self.t_wc_batch_dict = {0: t_wc}
+        N = int(sum(areas))
+        shuffled_idx = np.arange(N)
+        np.random.shuffle(shuffled_idx)                                            # :251-252 / :309-310
+        crops_t = torch.tensor(crops, dtype=torch.int32, device=dev)
+        off_t = torch.tensor(np.concatenate([[0], np.cumsum(areas)]), dtype=torch.int64, device=dev)
+        perm_t = torch.from_numpy(shuffled_idx).to(dev)
+        T_crop = torch.cat(T_crop).contiguous()
+        self.rgbs_batch_all = torch.empty(N, 4, dtype=torch.uint8, device=dev)
+        self.depth_batch_all = torch.empty(N, device=dev)
+        self.ray_dirs_batch_all = torch.empty(N, 3, device=dev)
+        T_rows = torch.empty(N, 4, 4, device=dev)
+        self.batch_indices_all = torch.empty(N, dtype=torch.int64, device=dev)
+        frame_rows = torch.empty(N, dtype=torch.int64, device=dev)
+        from . import _C
+        _C.call("cnr_gather_pool", images, depths, masks, rays, T_crop, crops_t, off_t, perm_t, W, H, len(crops), N,
+                self.rgbs_batch_all, self.depth_batch_all, self.ray_dirs_batch_all, T_rows, self.batch_indices_all,
+                frame_rows)
+        self.t_wc_batch_all = T_rows if self.world_frame else None
+        self.t_co_batch_all = None if self.world_frame else T_rows
+        if cls_id == 0:   # the reference's per-object dict view of the background pool (:318-324)
+            self.rgbs_batch_dict, self.depth_batch_dict = {0: self.rgbs_batch_all}, {0: self.depth_batch_all}
+            self.frame_batch_dict, self.ray_dirs_batch_dict = {0: frame_rows}, {0: self.ray_dirs_batch_all}
+            self.i_batch_dict = {0: 0}
+        self._make_trainer(cfg)
+        if cls_id == 0:
+            self.trainer.bound = inst_dict.get("bbox3D")
+        elif len(obj_ids) == 1:
+            self.trainer.bound_dict = {i: inst_dict[i].get("bbox3D") for i in obj_ids}
+        else:
+            self.trainer.extent_dict = self.extent_dict
 
-    @classmethod
-    def from_pool(cls, cfg, cls_id, obj_ids, pool, seed=0):
-        self = object.__new__(cls)
+    def _init_common(self, cfg, cls_id, obj_ids):
         self.cls_id = cls_id
         self.obj_ids = list(obj_ids) if cls_id != 0 else [0]          # src/scene_cateogries.py:109-112
         self.data_device = cfg.data_device
@@ -144,22 +211,31 @@ class sceneCategory():
         self.min_bound, self.max_bound = cfg.min_depth, cfg.max_depth
         self.n_bins = cfg.n_bins
         self.surface_eps, self.stop_eps = cfg.surface_eps, cfg.stop_eps
+        self.world_frame = cls_id == 0 or len(self.obj_ids) == 1       # origin_dirs_W vs origin_dirs_O (:374-386)
+        self.i_batch = 0
+        self.parity_draws = None  # (u, g) tensors for the next get_training_samples call (tests)
+
+    def _make_trainer(self, cfg, seed=0):
+        self._seed, self._calls = int(seed) * 7919 + int(self.cls_id) + 1, 0
+        trainer_cfg = copy.copy(cfg)
+        trainer_cfg.hidden_feature_size = self.hidden_feature_size     # :328-330
+        trainer_cfg.obj_scale = self.obj_scale
+        self.trainer = trainer.Trainer(trainer_cfg, self.cls_id, self.obj_ids)
+
+    @classmethod
+    def from_pool(cls, cfg, cls_id, obj_ids, pool, seed=0):
+        """A ready pool dict {rgbs (N,4) u8, depth (N,), dirs (N,3), T_co / T_wc (N,4,4), indices (N,)} on any device."""
+        self = object.__new__(cls)
+        self._init_common(cfg, cls_id, obj_ids)
         dev = self.data_device
         self.rgbs_batch_all = pool["rgbs"].to(dev)
         self.depth_batch_all = pool["depth"].to(dev)
         self.ray_dirs_batch_all = pool["dirs"].to(dev)
-        self.world_frame = cls_id == 0 or len(self.obj_ids) == 1       # origin_dirs_W vs origin_dirs_O (:374-386)
         self.t_co_batch_all = pool["T_co"].to(dev) if not self.world_frame else None
         self.t_wc_batch_all = pool["T_wc"].to(dev) if self.world_frame else None
         self.batch_indices_all = pool["indices"].to(dev) if cls_id != 0 else \
             torch.zeros(pool["depth"].shape[0], dtype=torch.int64, device=dev)
-        self.i_batch = 0
-        self.parity_draws = None  # (u, g) tensors for the next get_training_samples call (tests)
-        self._seed, self._calls = int(seed) * 7919 + int(cls_id) + 1, 0
-        trainer_cfg = copy.copy(cfg)
-        trainer_cfg.hidden_feature_size = self.hidden_feature_size     # :328-330
-        trainer_cfg.obj_scale = self.obj_scale
-        self.trainer = trainer.Trainer(trainer_cfg, cls_id, self.obj_ids)
+        self._make_trainer(cfg, seed)
         return self
 
     def sample_3d_points(self, sampled_rgbs, sampled_depth, T, dirs_c, world_frame, u=None, g=None):

@@ -203,6 +203,19 @@ int64_t cnr_dense_bwd_workspace_bytes(int M, int K, int N);
 int cnr_dense_bwd(const float* x, const float* W, const float* y, const float* dy, float* dx, float* dW, float* db,
                   int M, int K, int N, int relu, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- ray-pool construction from frames (src/scene_cateogries.py:164-260, 262-325) ------------
+ * images (F,W,H,3) u8, depth (F,W,H) f32, obj_mask (F,W,H) i32 (instance id per pixel, -1 unknown), rays_dir (W,H,3):
+ * the frames of one scene stacked in HBM.  crops (n_crops,8) i32 = {frame slot, instance id, object index, w0, w1,
+ * h0, h1, frame index in the instance's own frame list}; crop_offset (n_crops + 1) i64 = exclusive prefix sum of the crop areas; T_crop (n_crops,4,4) = the pose
+ * every ray of the crop carries (T_co = inv(T_wc) T_obj, or T_wc for the background / a single object).
+ * perm (N,) i64 or NULL: output row r is source row perm[r] (the reference's global shuffle x = x[shuffled_idx]).
+ * Outputs, N = crop_offset[n_crops] rows: rgbs (N,4) u8 [r,g,b,state], depth (N,), dirs (N,3), T (N,4,4) (NULL to
+ * skip), indices (N,) i64 = object index (NULL to skip), frame (N,) i64 = that frame index (NULL to skip). */
+int cnr_gather_pool(const uint8_t* images, const float* depth, const int32_t* obj_mask, const float* rays_dir,
+                    const float* T_crop, const int32_t* crops, const int64_t* crop_offset, const int64_t* perm, int W,
+                    int H, int n_crops, int64_t N, uint8_t* rgbs, float* depth_out, float* dirs, float* T_out,
+                    int64_t* indices, int64_t* frame_out, void* stream);
+
 /* Parameter-only work of one fused-trainer step in ONE launch, three independent jobs side by side in the grid:
  * cnr_pack_weights (trunk of class c at theta + c * class_stride + off_trunk), cnr_latent_fwd (same arguments), and
  * a zero fill of zero_buf[0 .. zero_count) (the gradient buffers; 16-B aligned; zero_count 0 to skip). */

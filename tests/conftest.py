@@ -22,7 +22,12 @@ def _all_golden():
 
 def golden_names():
     """object-branch fixtures (CodeNeRF train step)"""
-    return [n for n in _all_golden() if not n.startswith("bg_")]
+    return [n for n in _all_golden() if not n.startswith("bg_") and not n.startswith("pool_")]
+
+
+def pool_golden_names():
+    """ray-pool construction fixtures (frames + the pools the reference's sceneCategory.__init__ built)"""
+    return [n for n in _all_golden() if n.startswith("pool_")]
 
 
 def bg_golden_names():

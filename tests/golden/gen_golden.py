@@ -336,6 +336,68 @@ def run_bg_case(name, seed, R, hidden=128, n1=5, n2=9):
     print(f"{name}: loss={loss.item():.6f}  -> {os.path.getsize(path) / 1e6:.2f} MB")
 
 
+def run_pool_case(name, seed, W=24, H=20, n_frames=6):
+    """Ray-pool construction from frames (scene_cateogries.py:107-350) by the reference's own
+    sceneCategory.__init__: one object category with three instances and the background, on small synthetic frames.
+    Stored: the frames / metadata and the pools the reference builds (np.random.seed pins its shuffle)."""
+    rng = np.random.RandomState(seed)
+    gen = torch.Generator().manual_seed(3000 + seed)
+    cfg = SimpleNamespace(data_device="cpu", training_device="cpu", bg_scale=5.0, obj_scale=2.0,
+                          hidden_feature_size=32, hidden_feature_size_bg=32, n_bins_cam2surface=1,
+                          n_bins_cam2surface_bg=5, n_bins=9, min_depth=0.0, max_depth=10.0, surface_eps=0.1,
+                          stop_eps=0.05, n_unidir_funcs=5,
+                          net_hyperparams=dict(shape_blocks=2, texture_blocks=1, W=32, latent_dim=32))
+    inst_ids = [3, 7, 12]
+    sample_dict = {}
+    for f in range(n_frames):
+        mask = rng.choice([-1, 0] + inst_ids, size=(W, H), p=[0.05, 0.35, 0.2, 0.2, 0.2]).astype(np.int64)
+        sample_dict[10 + f] = dict(image=rng.randint(0, 256, size=(W, H, 3)).astype(np.uint8),
+                                   depth=(rng.rand(W, H) * 4).astype(np.float32),
+                                   T=rand_pose(gen, False).numpy().astype(np.float32), obj_mask=mask)
+    rays_dir = torch.randn(W, H, 3, generator=gen)
+
+    def bbox():
+        w0, h0 = rng.randint(0, W - 6), rng.randint(0, H - 6)
+        return [int(w0), int(w0 + rng.randint(2, 6)), int(h0), int(h0 + rng.randint(2, 6))]
+    inst_dict = {}
+    for k, iid in enumerate(inst_ids):
+        frames = sorted(rng.choice(n_frames, size=3, replace=False).tolist())
+        inst_dict[iid] = dict(T_obj=rand_pose(gen, True).numpy().astype(np.float64),
+                              bbox3D=SimpleNamespace(extent=np.array([1.0, 2.0, 1.5])),
+                              frame_info=[dict(frame=10 + f, bbox=bbox()) for f in frames])
+    bg_dict = dict(bbox3D=SimpleNamespace(extent=np.array([6.0, 6.0, 3.0])),
+                   frame_info=[dict(frame=10 + f, bbox=[0, W, 0, H]) for f in range(0, n_frames, 2)])
+
+    import copy as _copy
+    np.random.seed(777 + seed)
+    sc = ref_sc.sceneCategory(cfg, 5, _copy.deepcopy(inst_dict), sample_dict, rays_dir)
+    np.random.seed(888 + seed)
+    bg = ref_sc.sceneCategory(cfg, 0, _copy.deepcopy(bg_dict), sample_dict, rays_dir)
+
+    f = lambda t: t.detach().cpu().numpy()
+    frames = sorted(sample_dict.keys())
+    d = dict(meta=np.array([W, H, n_frames, len(inst_ids), seed], dtype=np.int64),
+             frame_ids=np.array(frames, dtype=np.int64),
+             images=np.stack([sample_dict[k]["image"] for k in frames]),
+             depths=np.stack([sample_dict[k]["depth"] for k in frames]),
+             masks=np.stack([sample_dict[k]["obj_mask"] for k in frames]),
+             T_wc=np.stack([sample_dict[k]["T"] for k in frames]), rays_dir=f(rays_dir),
+             inst_ids=np.array(inst_ids, dtype=np.int64),
+             T_obj=np.stack([inst_dict[i]["T_obj"] for i in inst_ids]),
+             obj_frames=np.array([[fi["frame"] for fi in inst_dict[i]["frame_info"]] for i in inst_ids], dtype=np.int64),
+             obj_bboxes=np.array([[fi["bbox"] for fi in inst_dict[i]["frame_info"]] for i in inst_ids], dtype=np.int64),
+             bg_frames=np.array([fi["frame"] for fi in bg_dict["frame_info"]], dtype=np.int64),
+             bg_bboxes=np.array([fi["bbox"] for fi in bg_dict["frame_info"]], dtype=np.int64),
+             obj_rgbs=f(sc.rgbs_batch_all), obj_depth=f(sc.depth_batch_all), obj_dirs=f(sc.ray_dirs_batch_all),
+             obj_T_co=f(sc.t_co_batch_all), obj_indices=f(sc.batch_indices_all),
+             bg_rgbs=f(bg.rgbs_batch_dict[0]), bg_depth=f(bg.depth_batch_dict[0]), bg_dirs=f(bg.ray_dirs_batch_dict[0]),
+             bg_frame=f(bg.frame_batch_dict[0]), bg_T_wc=f(bg.t_wc_batch_dict[0]))
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **d)
+    print(f"{name}: obj pool {tuple(sc.rgbs_batch_all.shape)}, bg pool {tuple(bg.rgbs_batch_dict[0].shape)} "
+          f"-> {os.path.getsize(path) / 1e6:.2f} MB")
+
+
 def main():
     run_case("s0_c1_r64_s16_l256", 0, 1, 64, 16, 256)
     run_case("s1_c1_r64_s16_l256", 1, 1, 64, 16, 256, keep_emb=False)
@@ -348,10 +410,13 @@ def main():
     run_case("edge_single_obj_W", 5, 1, 64, 16, 256, single_obj=True, keep_emb=False)
     run_bg_case("bg_r240_s14_h128", 6, 240)            # background model: OccupancyMap(128), 5 + 9 samples
     run_bg_case("bg_r100_s14_h32", 7, 100, hidden=32)  # the pretrained per-object vMAP shape (hidden 32)
+    run_pool_case("pool_w24_h20_f6", 8)                # ray-pool construction from frames
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "bg":      # only the background fixtures
+    if len(sys.argv) > 1 and sys.argv[1] == "pool":
+        run_pool_case("pool_w24_h20_f6", 8)
+    elif len(sys.argv) > 1 and sys.argv[1] == "bg":      # only the background fixtures
         run_bg_case("bg_r240_s14_h128", 6, 240)
         run_bg_case("bg_r100_s14_h32", 7, 100, hidden=32)
     else:

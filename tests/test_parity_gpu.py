@@ -8,7 +8,7 @@ against an fp64 evaluation of the oracle: ours must be within 5x of it."""
 import pytest
 import torch
 
-from conftest import Golden, bg_golden_names, golden_names, rel_l2
+from conftest import Golden, bg_golden_names, golden_names, pool_golden_names, rel_l2
 from oracle import ref_cpu as O
 
 pytestmark = pytest.mark.gpu
@@ -346,3 +346,49 @@ def test_background_step_against_reference(cnr, dev, name):
     opt.step()
     for n, p in sc.trainer.fc_occ_map.named_parameters():
         assert rel_l2(p, g.t("new." + n)) < 1e-4, n
+
+
+# ---- ray-pool construction from frames -------------------------------------------------------
+@pytest.mark.parametrize("name", pool_golden_names())
+def test_pool_construction_against_reference(cnr, dev, name):
+    """sceneCategory(cfg, cls_id, inst_dict, sample_dict, rays) -- one cnr_gather_pool launch -- against the pools
+    the reference's own constructor built from the same frames (src/scene_cateogries.py:107-350): pixel rows,
+    states, object indices and the shuffle order bit-exact, poses to fp32 rounding of the 4x4 inverse."""
+    import os
+    from types import SimpleNamespace
+    import numpy as np
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    seed = int(z["meta"][4])
+    frames = [int(f) for f in z["frame_ids"]]
+    sample_dict = {f: dict(image=z["images"][i], depth=z["depths"][i], T=z["T_wc"][i], obj_mask=z["masks"][i])
+                   for i, f in enumerate(frames)}
+    inst_dict = {}
+    for k, iid in enumerate(int(i) for i in z["inst_ids"]):
+        inst_dict[iid] = dict(T_obj=z["T_obj"][k], bbox3D=SimpleNamespace(extent=np.array([1.0, 2.0, 1.5])),
+                              frame_info=[dict(frame=int(f), bbox=[int(v) for v in b])
+                                          for f, b in zip(z["obj_frames"][k], z["obj_bboxes"][k])])
+    bg_dict = dict(bbox3D=SimpleNamespace(extent=np.array([6.0, 6.0, 3.0])),
+                   frame_info=[dict(frame=int(f), bbox=[int(v) for v in b]) for f, b in zip(z["bg_frames"], z["bg_bboxes"])])
+    cfg = cnr.cfg.synthetic_config(device=str(dev), latent_dim=32)
+    cfg.hidden_feature_size_bg = 32
+    rays = torch.from_numpy(z["rays_dir"])
+    t = lambda k: torch.from_numpy(z[k]).to(dev)
+
+    np.random.seed(777 + seed)
+    sc = cnr.scene_cateogries.sceneCategory(cfg, 5, inst_dict, sample_dict, rays)
+    assert torch.equal(sc.rgbs_batch_all, t("obj_rgbs")) and torch.equal(sc.depth_batch_all, t("obj_depth"))
+    assert torch.equal(sc.ray_dirs_batch_all, t("obj_dirs")) and torch.equal(sc.batch_indices_all, t("obj_indices"))
+    assert rel_l2(sc.t_co_batch_all, t("obj_T_co")) < 1e-6
+    assert type(sc.trainer.fc_occ_map).__name__ == "CodeNeRF" and sc.trainer.n_obj == 3
+
+    np.random.seed(888 + seed)
+    bg = cnr.scene_cateogries.sceneCategory(cfg, 0, bg_dict, sample_dict, rays)
+    assert torch.equal(bg.rgbs_batch_dict[0], t("bg_rgbs")) and torch.equal(bg.depth_batch_dict[0], t("bg_depth"))
+    assert torch.equal(bg.ray_dirs_batch_dict[0], t("bg_dirs")) and torch.equal(bg.frame_batch_dict[0], t("bg_frame"))
+    assert torch.equal(bg.t_wc_batch_dict[0], t("bg_T_wc"))
+    assert torch.equal(bg.t_wc_batch_all, t("bg_T_wc")[t("bg_frame")])
+    # and the constructed pools feed the sampler: one slice of each
+    out = sc.get_training_samples(16)
+    assert out[4].shape == (16, cfg.n_bins_cam2surface + cfg.n_bins, 3) and torch.isfinite(out[4]).all()
+    out = bg.get_training_samples(64)
+    assert out[4].shape == (64, cfg.n_bins_cam2surface_bg + cfg.n_bins, 3) and int(out[6].abs().sum()) == 0
