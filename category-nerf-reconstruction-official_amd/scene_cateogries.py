@@ -45,6 +45,8 @@ def stratified_bins(min_depth, max_depth, n_bins, n_rays, type=torch.float32, de
     rng = max_depth - min_depth
     lower = (rng[..., None] * lim + min_depth[..., None])[:, :-1]
     assert lower.shape == (n_rays, n_bins)
+    # z_fixed is accepted and IGNORED, as in the reference (its fixed-z branch is commented out, :70-72): the probe
+    # rays of category_registration.py:145 are jittered too
     return lower + torch.rand(n_rays, n_bins, device=device, dtype=torch.float32) * (rng / n_bins)[..., None]
 
 
@@ -273,3 +275,52 @@ class sceneCategory():
             self.i_batch = 0
         return (rgbs[:, :3], depth, out["depth_mask"][0].bool(), out["labels"][0], out["pts"][0],
                 out["z"][0], batch_indices)
+
+    # ---- checkpoint interchange (src/scene_cateogries.py:548-597): same file name, same dict keys -------------
+    def save_checkpoints(self, path, iter):
+        import os
+        ckpt_file = os.path.join(path, "cls_" + str(self.cls_id) + "_iteration_{:05d}.pth".format(iter))
+        save_dict = {
+            "global_step": iter,
+            "PE_state_dict": self.trainer.pe.state_dict(),
+            "FC_state_dict": self.trainer.fc_occ_map.state_dict(),
+            "cls_id": self.cls_id,
+            "instance_id_to_index": self.trainer.inst_id_to_index,
+            "obj_scale": self.trainer.obj_scale,
+        }
+        if self.cls_id == 0:
+            save_dict["bound"] = getattr(self.trainer, "bound", None)
+        else:
+            save_dict["obj_tensor_dict"] = getattr(self, "object_tensor_dict", {})
+            if len(self.obj_ids) > 1:
+                save_dict["extent_dict"] = getattr(self, "extent_dict", None)
+            save_dict["shape_code_state_dict"] = self.trainer.shape_codes.state_dict()
+            save_dict["texture_code_state_dict"] = self.trainer.texture_codes.state_dict()
+            save_dict["bound"] = self.trainer.extent_dict
+        torch.save(save_dict, ckpt_file)
+        return ckpt_file
+
+    def load_checkpoints(self, ckpt_file):
+        import os
+        if not os.path.exists(ckpt_file):
+            print("ckpt not exist ", ckpt_file)
+            return
+        checkpoint = torch.load(ckpt_file, map_location=self.training_device, weights_only=False)
+        self.cls_id = checkpoint["cls_id"]
+        self.trainer.fc_occ_map.load_state_dict(checkpoint["FC_state_dict"])
+        self.trainer.pe.load_state_dict(checkpoint["PE_state_dict"])
+        self.trainer.fc_occ_map.to(self.training_device)
+        self.trainer.pe.to(self.training_device)
+        if self.cls_id != 0:
+            self.object_tensor_dict = checkpoint["obj_tensor_dict"]
+            self.trainer.shape_codes.load_state_dict(checkpoint["shape_code_state_dict"])
+            self.trainer.texture_codes.load_state_dict(checkpoint["texture_code_state_dict"])
+            self.trainer.shape_codes.to(self.training_device)
+            self.trainer.texture_codes.to(self.training_device)
+            self.trainer.bound = checkpoint["bound"]
+        else:
+            self.trainer.extent_dict = checkpoint["bound"]
+        self.trainer.inst_id_to_index = checkpoint["instance_id_to_index"]
+        self.trainer.obj_scale = checkpoint["obj_scale"]
+        self.start = checkpoint["global_step"]
+

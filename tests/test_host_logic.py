@@ -85,3 +85,35 @@ def test_synthetic_pool_and_shards(cnr):
     assert lo[0] == 0 and hi[-1] == 1000 and all(h == l2 for h, l2 in zip(hi[:-1], lo[1:]))
     sh = cnr.parallel.shard_pool(pool, 1, 3)
     assert torch.equal(sh["depth"], pool["depth"][lo[1]:hi[1]])
+
+
+def test_checkpoint_round_trip_in_the_reference_format(cnr, tmp_path):
+    """save_checkpoints / load_checkpoints (src/scene_cateogries.py:548-597): file name, dict keys and state_dict key
+    names of the reference, for an object category and for the background model; weights survive the round trip and
+    the FC_state_dict keys are exactly the reference's (taken from the golden fixtures it generated)."""
+    cfg = cnr.cfg.synthetic_config(device="cpu", latent_dim=32)
+    cfg.hidden_feature_size_bg = 32
+    gen = torch.Generator().manual_seed(3)
+    pool = cnr.scene_cateogries.synthetic_pool(256, 3, gen, "cpu")
+    for cls_id, obj_ids, fixture in ((4, [11, 12, 13], "s0_c2_r64_s16_l32"), (0, [0], "bg_r100_s14_h32")):
+        a = cnr.scene_cateogries.sceneCategory.from_pool(cfg, cls_id, obj_ids, pool)
+        b = cnr.scene_cateogries.sceneCategory.from_pool(cfg, cls_id, obj_ids, pool, seed=1)
+        a.object_tensor_dict = {i: torch.eye(4) for i in obj_ids}
+        a.trainer.extent_dict = {i: [1.0, 1.0, 1.0] for i in obj_ids}
+        a.trainer.bound = "bbox"
+        f = a.save_checkpoints(str(tmp_path), 42)
+        assert f.endswith(f"cls_{cls_id}_iteration_00042.pth")
+        ck = torch.load(f, weights_only=False)
+        want = {"global_step", "PE_state_dict", "FC_state_dict", "cls_id", "instance_id_to_index", "obj_scale", "bound"}
+        if cls_id != 0:
+            want |= {"obj_tensor_dict", "extent_dict", "shape_code_state_dict", "texture_code_state_dict"}
+        assert set(ck.keys()) == want
+        assert sorted(ck["FC_state_dict"].keys()) == sorted(Golden(fixture).mlp().keys())
+        assert list(ck["PE_state_dict"].keys()) == ["scale", "B_layer.weight"]
+        assert not torch.equal(next(iter(a.trainer.fc_occ_map.parameters())), next(iter(b.trainer.fc_occ_map.parameters())))
+        b.load_checkpoints(f)
+        for (n, p), (_, q) in zip(a.trainer.fc_occ_map.state_dict().items(), b.trainer.fc_occ_map.state_dict().items()):
+            assert torch.equal(p, q), n
+        assert b.start == 42 and b.trainer.inst_id_to_index == a.trainer.inst_id_to_index
+        if cls_id != 0:
+            assert torch.equal(a.trainer.shape_codes.weight, b.trainer.shape_codes.weight)

@@ -392,3 +392,38 @@ def test_pool_construction_against_reference(cnr, dev, name):
     assert out[4].shape == (16, cfg.n_bins_cam2surface + cfg.n_bins, 3) and torch.isfinite(out[4]).all()
     out = bg.get_training_samples(64)
     assert out[4].shape == (64, cfg.n_bins_cam2surface_bg + cfg.n_bins, 3) and int(out[6].abs().sum()) == 0
+
+
+@pytest.mark.parametrize("name", [n for n in bg_golden_names() if n.endswith("h32")])
+def test_uncertainty_field_probe_forward(cnr, dev, name):
+    """the forward-only probe of get_uncertainty_fields (src/category_registration.py:127-152) --
+    stratified bins (96 per ray; z_fixed is a no-op in the reference), UniDirsEmbed, a hidden-32 OccupancyMap, sigmoid(10 sigma), non-batch
+    occupancy_to_termination, ray entropies -- on the drop-in modules against the oracle on the same weights."""
+    g = Golden(name, dev)
+    cfg = cnr.cfg.synthetic_config(device=str(dev), latent_dim=32, obj_scale=g.scale)
+    cfg.hidden_feature_size = g.L
+    tr = cnr.trainer.Trainer(cfg, 0, [0])
+    tr.fc_occ_map.load_state_dict(g.mlp())
+    with torch.no_grad():
+        tr.pe.B_layer.weight.copy_(g.t("B")[0])
+    gen = torch.Generator().manual_seed(5)
+    n_rays, r = 500, 1.3
+    d = torch.nn.functional.normalize(torch.randn(n_rays, 3, generator=gen), dim=-1)
+    rays_o, viewdir = (r * d).to(dev), (-d).to(dev)
+    zj = cnr.scene_cateogries.stratified_bins(0, 2 * r, 96, n_rays, device=dev, z_fixed=True)   # jittered all the same
+    lo = O.stratified_bins(0.0, 2 * r, 96, n_rays, torch.zeros(n_rays, 96)).to(dev)
+    assert bool(((zj >= lo) & (zj <= lo + 2 * r / 96 + 1e-6)).all()) and float((zj - lo).std()) > 1e-3
+    z = O.stratified_bins(0.0, 2 * r, 96, n_rays, torch.rand(n_rays, 96, generator=gen)).to(dev)
+    xyz = rays_o[..., None, :] + viewdir[:, None, :] * z[..., None]
+    with torch.no_grad():
+        sig, _ = tr.fc_occ_map(tr.pe(xyz))
+        occ = torch.sigmoid(10 * sig.squeeze(-1))
+        term = cnr.render_rays.occupancy_to_termination(occ)
+        ent = (-term * torch.log(term + 1e-10)).sum(-1)
+    mlp = {k: v.cpu() for k, v in g.mlp().items()}
+    emb = O.unidirs_embed(xyz.cpu()[None], g.t("B").cpu(), g.scale)[0]
+    sig_o, _ = O.occupancy_map_forward(mlp, emb)
+    occ_o = torch.sigmoid(10 * sig_o.squeeze(-1))
+    term_o = O.occupancy_to_termination(occ_o)
+    ent_o = (-term_o * torch.log(term_o + 1e-10)).sum(-1)
+    assert rel_l2(sig, sig_o) < FWD_TOL and rel_l2(term, term_o) < 1e-4 and rel_l2(ent, ent_o) < 1e-4
