@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include "fused_common.h"
 #include "latent_common.h"
+#include "sample_common.h"
 
 namespace {
 using namespace fz;
@@ -98,10 +99,13 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ tru
 // Parameter-only work of one train step in ONE launch (three independent jobs side by side in the grid instead of
 // three launches in a row): operand image of the trunk (pack_block), per-object latent rows (latent_fwd_block),
 // and the zero fill of the gradient buffers.  grid (NPACK + 4 n_obj + nzero, C).
+// With sample blocks appended (cnr_step_prologue) the sampler -- which depends on the ray pool and the step state
+// only -- runs beside them as well: grid (NPACK + 4 n_obj + nzero + ceil(R / 4), C), one wavefront per ray.
 __global__ __launch_bounds__(256) void param_prep_kernel(const float* __restrict__ theta, cnr::FlatLayout lay,
                                                          int64_t off_trunk, unsigned char* __restrict__ packed,
                                                          float* __restrict__ zl, float* __restrict__ biasrows,
-                                                         float* __restrict__ zero_buf, int64_t zero_count, int nzero) {
+                                                         float* __restrict__ zero_buf, int64_t zero_count, int nzero,
+                                                         cnr_sample::SampleArgs sa, int nsample) {
   constexpr int NPACK = NKK_FWD + NKK_BWD + 1;
   const int c = blockIdx.y, C = gridDim.y;
   const float* th = theta + (int64_t)c * lay.stride;
@@ -110,6 +114,11 @@ __global__ __launch_bounds__(256) void param_prep_kernel(const float* __restrict
   b -= NPACK;
   if (b < 4 * lay.n_obj) { cnr::latent_fwd_block(th, th + off_trunk, lay, zl, biasrows, b >> 2, b & 3, c); return; }
   b -= 4 * lay.n_obj;
+  if (b >= nzero) {  // a2-a5: four rays of class c per block
+    const int r = (b - nzero) * 4 + (threadIdx.x >> 6);
+    if (nsample > 0 && r < sa.R) cnr_sample::sample_ray(sa, (int64_t)c * sa.R + r, threadIdx.x & 63);
+    return;
+  }
   // zero fill: block (b, c) of nzero * C takes a contiguous float4 range
   const int64_t nvec = zero_count >> 2, nblk = (int64_t)nzero * C, me = (int64_t)c * nzero + b;
   const int64_t per = (nvec + nblk - 1) / nblk;
@@ -258,7 +267,42 @@ extern "C" int cnr_param_prep(const float* theta, int64_t class_stride, int64_t 
   if (nzero > 256) nzero = 256;
   dim3 grid(fz::NKK_FWD + fz::NKK_BWD + 1 + 4 * n_obj + nzero, (unsigned)C);
   hipLaunchKernelGGL(param_prep_kernel, grid, dim3(256), 0, (hipStream_t)stream, theta, lay, off_trunk,
-                     (unsigned char*)packed, zl, biasrows, zero_buf, zero_count, nzero);
+                     (unsigned char*)packed, zl, biasrows, zero_buf, zero_count, nzero, cnr_sample::SampleArgs{}, 0);
+  CNR_LAUNCH_CHECK();
+  return CNR_OK;
+}
+
+extern "C" int cnr_step_prologue(
+    /* cnr_param_prep */ const float* theta, int64_t class_stride, int64_t off_trunk, int64_t off_latW, int64_t off_latb,
+    int64_t off_shape, int64_t off_tex, int L, int n_obj, int C, void* packed, float* zl, float* biasrows,
+    float* zero_buf, int64_t zero_count,
+    /* cnr_sample_rays */ const uint8_t* rgbs, const float* depth, const float* dirs_c, const float* T, const float* u,
+    const float* g, uint64_t seed, uint64_t offset, const int64_t* d_state, int64_t pool_rows, const float* max_bound,
+    int world_frame, int R, int n1, int n2, float eps, float stop_eps, float min_bound, float* z, float* pts,
+    float* origins, float* dirs_o, float* gt_rgb, float* gt_depth, uint8_t* depth_mask, uint8_t* labels,
+    const int64_t* pool_indices, int* ray_row, const int* perm, void* stream) {
+  if (!theta || !packed || !zl || !biasrows || L <= 0 || n_obj <= 0 || C <= 0 || zero_count < 0 ||
+      (zero_count > 0 && !zero_buf))
+    return CNR_E_ARG;
+  if (((uintptr_t)packed & 15) != 0 || ((uintptr_t)zero_buf & 15) != 0) return CNR_E_ALIGN;
+  if (!rgbs || !depth || !dirs_c || !T || !max_bound || !z || !pts || !gt_rgb || !depth_mask || !labels) return CNR_E_ARG;
+  if (R <= 0 || n1 < 0 || n2 <= 0) return CNR_E_ARG;
+  if (n2 > 128) return CNR_E_SHAPE;
+  if ((u == nullptr) != (g == nullptr)) return CNR_E_ARG;
+  if (pool_rows < 0 || (pool_rows > 0 && (!d_state || pool_rows < R))) return CNR_E_ARG;
+  if (ray_row && !pool_indices) return CNR_E_ARG;
+  if (perm && pool_rows == 0) return CNR_E_ARG;
+  cnr::FlatLayout lay{class_stride, off_latW, off_latb, off_shape, off_tex, L, n_obj};
+  int nzero = zero_count > 0 ? (int)((zero_count / 4 + 256 * 8 - 1) / (256 * 8) / C) : 0;
+  if (zero_count > 0 && nzero < 1) nzero = 1;
+  if (nzero > 256) nzero = 256;
+  const int nsample = (R + 3) / 4;
+  cnr_sample::SampleArgs sa{rgbs, depth, dirs_c, T, u, g, seed, offset, d_state, pool_rows, max_bound, world_frame,
+                            C, R, n1, n2, eps, stop_eps, min_bound, z, pts, origins, dirs_o, gt_rgb, gt_depth,
+                            depth_mask, labels, pool_indices, n_obj, ray_row, perm};
+  dim3 grid(fz::NKK_FWD + fz::NKK_BWD + 1 + 4 * n_obj + nzero + nsample, (unsigned)C);
+  hipLaunchKernelGGL(param_prep_kernel, grid, dim3(256), 0, (hipStream_t)stream, theta, lay, off_trunk,
+                     (unsigned char*)packed, zl, biasrows, zero_buf, zero_count, nzero, sa, nsample);
   CNR_LAUNCH_CHECK();
   return CNR_OK;
 }

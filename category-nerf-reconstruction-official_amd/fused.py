@@ -151,16 +151,14 @@ class FusedCategoryTrainer:
         # One stream, one chain of kernels.  (Parallel hipGraph branches -- parameter prep beside sampling, the loss
         # values beside the field backward -- were measured: every cross-queue edge costs more than the few
         # microseconds of overlap it buys at this step size, 0.154 -> 0.170 ms per step.)
-        # parameter-only work, one launch: zero the gradient buffers | a7 + latent layers (per-object rows) | f16
-        # operand image of the trunk
-        _C.call("cnr_param_prep", self.theta, lay.total, lay.trunk[0], lay.latW[0], lay.latb[0], lay.shape[0],
-                lay.tex[0], L, n_obj, C, packed, zl, brows, self._gbuf, self._gbuf.numel())
-        # a2-a6: slice the device pool at the device cursor, transform, sample (the slice's max depth is already in
-        # self.max_bound: the previous step's epilogue, or _reshuffle, put it there)
-        b = ops.sample_rays(self.pool["rgbs"], self.pool["depth"], self.pool["dirs"], self.pool["T"], self.n1,
-                            self.n2, cfg.surface_eps, cfg.stop_eps, min_bound=cfg.min_depth, world_frame=False,
-                            seed=self.seed, d_state=self.d_state, rays=R, out=self.bufs, max_bound=self.max_bound,
-                            pool_indices=self.pool["indices"], n_obj=n_obj, perm=self.perm)
+        # First node, one launch, four independent jobs side by side in the grid: zero the gradient buffers | a7 +
+        # latent layers (per-object bias rows) | f16 operand image of the trunk | a2-a6: slice the device pool at
+        # the device cursor, transform, sample (the slice's max depth is already in self.max_bound: the previous
+        # step's epilogue, or _reshuffle, put it there)
+        b = ops.step_prologue(self.theta, lay, L, n_obj, packed, zl, brows, self._gbuf, self.pool["rgbs"],
+                              self.pool["depth"], self.pool["dirs"], self.pool["T"], self.n1, self.n2, cfg.surface_eps,
+                              cfg.stop_eps, cfg.min_depth, self.seed, self.d_state, R, self.bufs, self.max_bound,
+                              self.pool["indices"], self.perm)
         ray_row = b["ray_row"]
         # a8 + a9 fused forward
         sig, rgb = o["sig"], o["rgbs"]

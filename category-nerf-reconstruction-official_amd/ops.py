@@ -269,6 +269,27 @@ def sample_rays(rgbs, depth, dirs_c, T, n1, n2, eps, stop_eps, min_bound=0.0, wo
     return o
 
 
+def step_prologue(theta, lay, L, n_obj, packed, zl, brows, zero_buf, rgbs, depth, dirs_c, T, n1, n2, eps, stop_eps,
+                  min_bound, seed, d_state, rays, out, max_bound, pool_indices, perm):
+    """cnr_step_prologue: the parameter-only jobs (pack | latent rows | gradient zero fill) and the sampler of one
+    fused-trainer step in ONE launch.  Same outputs dict as :func:`sample_rays` (device pools, device cursor)."""
+    C, R, S = depth.shape[0], int(rays), n1 + n2
+    dev = depth.device
+    def buf(name, shape, dtype=torch.float32):
+        if name not in out:
+            out[name] = torch.empty(*shape, device=dev, dtype=dtype)
+        return out[name]
+    z, pts = buf("z", (C, R, S)), buf("pts", (C, R, S, 3))
+    gt, gd = buf("gt_rgb", (C, R, 3)), buf("gt_depth", (C, R))
+    dm, lab = buf("depth_mask", (C, R), torch.uint8), buf("labels", (C, R), torch.uint8)
+    rr = buf("ray_row", (C, R), torch.int32)
+    _C.call("cnr_step_prologue", theta, lay.total, lay.trunk[0], lay.latW[0], lay.latb[0], lay.shape[0], lay.tex[0],
+            L, n_obj, C, packed, zl, brows, zero_buf, zero_buf.numel(),
+            rgbs, depth, dirs_c, T, None, None, int(seed), 0, d_state, depth.shape[1], max_bound, 0, R, n1, n2,
+            float(eps), float(stop_eps), float(min_bound), z, pts, None, None, gt, gd, dm, lab, pool_indices, rr, perm)
+    return out
+
+
 def adamw_step(param, grad, exp_avg, exp_avg_sq, lr, betas, eps, weight_decay, step, grad_unscale=1.0,
                d_state=None):
     _C.call("cnr_adamw_step", param, grad, exp_avg, exp_avg_sq, param.numel(), float(lr), float(betas[0]),

@@ -223,6 +223,19 @@ int cnr_param_prep(const float* theta, int64_t class_stride, int64_t off_trunk, 
                    int64_t off_shape, int64_t off_tex, int L, int n_obj, int C, void* packed, float* zl,
                    float* biasrows, float* zero_buf, int64_t zero_count, void* stream);
 
+/* cnr_param_prep and cnr_sample_rays side by side in ONE launch (same arguments, in that order; max_bound must be
+ * given here): the sampler needs the ray pool and the step state only, so the first node of the fused trainer's step
+ * runs it beside the parameter-only jobs instead of after them. */
+int cnr_step_prologue(const float* theta, int64_t class_stride, int64_t off_trunk, int64_t off_latW, int64_t off_latb,
+                      int64_t off_shape, int64_t off_tex, int L, int n_obj, int C, void* packed, float* zl,
+                      float* biasrows, float* zero_buf, int64_t zero_count,
+                      const uint8_t* rgbs, const float* depth, const float* dirs_c, const float* T, const float* u,
+                      const float* g, uint64_t seed, uint64_t offset, const int64_t* d_state, int64_t pool_rows,
+                      const float* max_bound, int world_frame, int R, int n1, int n2, float eps, float stop_eps,
+                      float min_bound, float* z, float* pts, float* origins, float* dirs_o, float* gt_rgb,
+                      float* gt_depth, uint8_t* depth_mask, uint8_t* labels, const int64_t* pool_indices,
+                      int* ray_row, const int* perm, void* stream);
+
 /* a11-a15 fused for the render + loss step of the fused trainer: cnr_composite_fwd -> cnr_loss_fwd_bwd ->
  * cnr_composite_bwd in ONE kernel (src/render_rays.py:3-7,25-33,46-95; src/loss.py:18-74).  Possible because the
  * gradient of the masked-mean losses w.r.t. one ray's renders needs that ray's values and the mask counts only.
