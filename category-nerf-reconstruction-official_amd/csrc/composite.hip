@@ -11,6 +11,11 @@
 //   d alpha_i = d occ_i occ_i (1 - occ_i) ; d c_i = term_i dC
 #include "cnr_common.h"
 
+// no fused multiply-add contraction in this file: composite.hip and render_loss.hip evaluate the same expressions and
+// must round them the same way whatever the surrounding code looks like (the one-launch form is tested bitwise
+// against the three-call form)
+#pragma clang fp contract(off)
+
 namespace {
 
 // inclusive product scan across the wave (Hillis-Steele, 6 steps)

@@ -16,6 +16,11 @@
 // summation order.  Block = 16 waves, one ray per wave at a time.
 #include "cnr_common.h"
 
+// no fused multiply-add contraction in this file: composite.hip and render_loss.hip evaluate the same expressions and
+// must round them the same way whatever the surrounding code looks like (the one-launch form is tested bitwise
+// against the three-call form)
+#pragma clang fp contract(off)
+
 namespace {
 constexpr int RL_WAVES = 16, RL_THREADS = RL_WAVES * 64, RL_MAX_CHUNKS = 8;
 // rays per block = 16 waves x rays per wave: one ray per wave (all rays in flight at once) until the grid is
@@ -88,6 +93,58 @@ __global__ __launch_bounds__(RL_THREADS) void render_loss_kernel(
     if (r >= R) break;  // wave-uniform
     const size_t ray = (size_t)c * R + r;
     const size_t base = ray * S;
+    if (nchunk == 1) {
+      // ---- S <= 64: the whole ray sits in one register per lane; sigmoid, scan and loads happen once -------------
+      const int s = lane;
+      const bool live = s < S;
+      const float occ = live ? sigmoid_exact(sigmas[base + s]) : 0.0f;
+      const float f = live ? (1.0f - occ + 1e-10f) : 1.0f;
+      const float incl = incl_prod(f, lane);
+      float T = __shfl_up(incl, 1, 64);
+      if (lane == 0) T = 1.0f;
+      const float term = occ * (1.0f * T);
+      float zz = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
+      if (live) { zz = z[base + s]; const float* cp = colors + (base + s) * 3; c0 = cp[0]; c1 = cp[1]; c2 = cp[2]; }
+      float sd = 0.f, so = 0.f, sr = 0.f, sg = 0.f, sb = 0.f;
+      if (live) { sd += term * zz; so += term; sr += term * c0; sg += term * c1; sb += term * c2; }
+      sd = cnr::wave_sum(sd); so = cnr::wave_sum(so);
+      sr = cnr::wave_sum(sr); sg = cnr::wave_sum(sg); sb = cnr::wave_sum(sb);
+      float sv = 0.f;
+      if (live) { const float dz = zz - sd; sv += occ * 1.0f * T * dz * dz; }
+      sv = cnr::wave_sum(sv);
+      if (lane == 0) {
+        if (depth_out) depth_out[ray] = sd;
+        if (var_out) var_out[ray] = sv;
+        if (opacity_out) opacity_out[ray] = so;
+        if (rgb_out) { rgb_out[ray * 3 + 0] = sr; rgb_out[ray * 3 + 1] = sg; rgb_out[ray * 3 + 2] = sb; }
+      }
+      const uint8_t lab = labels[ray];
+      const bool mo = lab != 0, ms = lab != 2, md = (depth_mask[ray] != 0) && mo;
+      const float fd = md ? 1.f : 0.f, fo = mo ? 1.f : 0.f, fs = ms ? 1.f : 0.f;
+      const float rd = sd - gt_depth[ray];
+      const float info = 1.0f / (sqrtf(sv) + 1e-4f);
+      const float rc0 = sr - gt_rgb[ray * 3 + 0], rc1 = sg - gt_rgb[ray * 3 + 1], rc2 = sb - gt_rgb[ray * 3 + 2];
+      const float ro = so - fo;
+      ld += fabsf(rd) * fd * info;
+      lc += (fabsf(rc0) + fabsf(rc1) + fabsf(rc2)) * fo;
+      lo += fabsf(ro) * fs;
+      const float dD = grad_scale * sgn(rd) * fd * info * wd;
+      const float dR = grad_scale * color_scaling * sgn(rc0) * fo * wc;
+      const float dG = grad_scale * color_scaling * sgn(rc1) * fo * wc;
+      const float dBl = grad_scale * color_scaling * sgn(rc2) * fo * wc;
+      const float dO = grad_scale * opacity_scaling * sgn(ro) * fs * wo;
+      const float g = live ? dD * zz + dR * c0 + dG * c1 + dBl * c2 + dO : 0.0f;
+      const float tg = term * g;
+      const float incl_suf = incl_suffix_sum(tg, lane);
+      const float suf = (incl_suf - tg) + 0.0f;
+      if (live) {
+        const float docc = T * g - suf / f;
+        d_sigmas[base + s] = docc * occ * (1.0f - occ);
+        float* dc = d_colors + (base + s) * 3;
+        dc[0] = term * dR; dc[1] = term * dG; dc[2] = term * dBl;
+      }
+      continue;
+    }
     // ---- forward composite ----------------------------------------------------------------------------------
     float carry_in[RL_MAX_CHUNKS];
     float carry = 1.0f;
