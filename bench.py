@@ -158,14 +158,13 @@ def main():
 
     # ---- roofline leg: the dominant kernel (fused backward) timed with HIP events on its launch stream ----
     bwd_name = "cnr_field_bwd" if cnr_amd.ops.FIELD_BWD_VARIANT == "split" else "cnr_field_bwd_pipe"
-    names = [bwd_name, "cnr_field_fwd", "cnr_param_prep", "cnr_sample_rays", "cnr_render_loss", "cnr_latent_bwd",
-             "cnr_adamw_step", "cnr_step_epilogue"]
-    saved_graph, tr.graph, tr.use_graph = tr.graph, None, False   # eager so that events bracket single launches
+    names = [bwd_name, "cnr_field_fwd", "cnr_step_prologue", "cnr_render_loss", "cnr_latent_bwd", "cnr_adamw_epilogue"]
+    tr.use_graph = False                                           # eager so that events bracket single launches
     cnr_amd._C.enable_kernel_timing(names)
     for _ in range(min(args.steps, 50)):
         tr.step()
     tms = cnr_amd._C.kernel_timings_ms()
-    tr.graph, tr.use_graph = saved_graph, not args.no_graph
+    tr.use_graph = not args.no_graph
     avg = {k: (sum(v) / len(v) if v else 0.0) for k, v in tms.items()}
     dom = max((bwd_name, "cnr_field_fwd"), key=lambda k: avg[k])
     # the backward call = the field kernel(s) (pipe: one launch; split: texture + geometry launches) + reduce_records:
@@ -192,7 +191,7 @@ def main():
            "config": {"workload": f"Replica room_0 shape: {C} category x {n_obj} objects, {R} rays x {S} samples "
                                   f"per GPU and step, latent {L}, W=32 CodeNeRF, random-pose synthetic pool, random init",
                       "rays_per_gpu": C * R, "samples_per_ray": S, "parallelism": f"dp{world}",
-                      "hipgraph": ("one graph" if world == 1 else "two graphs around the all-reduce") if not args.no_graph else False, "n_cu": info["n_cu"]},
+                      "hipgraph": ("one graph per state parity" if world == 1 else "two graphs around the all-reduce, per state parity") if not args.no_graph else False, "n_cu": info["n_cu"]},
            "roofline": roofline}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

@@ -6,7 +6,7 @@
 //     (render_rays.py:67-72) is evaluated by every block from the labels of all classes;
 //   - "loss explode" (render_rays.py:87-89, exit(-1) there) is reported in flags[c] bit 0.
 // One 256-thread block per class.
-#include "cnr_common.h"
+#include "adamw_common.h"
 
 namespace {
 __device__ __forceinline__ float block_sum(float v, float* sm /*[4]*/) {
@@ -78,25 +78,10 @@ __global__ __launch_bounds__(256) void loss_kernel(
   }
 }
 
-__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
-                                                    float* __restrict__ m, float* __restrict__ v, int64_t n,
-                                                    float lr, float b1, float b2, float eps, float wd,
-                                                    float step_size, float inv_bc2_sqrt, float gunscale,
+__global__ __launch_bounds__(256) void adamw_kernel(cnr::AdamArgs a, float step_size, float inv_bc2_sqrt,
                                                     const int64_t* __restrict__ d_state) {
-  if (d_state) {  // step number lives on the device (hipGraph replay): bias corrections computed here
-    const double t = (double)(d_state[2] + 1);
-    step_size = (float)((double)lr / (1.0 - pow((double)b1, t)));
-    inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow((double)b2, t)));
-  }
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const float gi = g[i] * gunscale;
-    float pi = p[i] * (1.0f - lr * wd);
-    const float mi = m[i] + (gi - m[i]) * (1.0f - b1);
-    const float vi = v[i] * b2 + (1.0f - b2) * gi * gi;
-    const float denom = sqrtf(vi) * inv_bc2_sqrt + eps;
-    pi -= step_size * (mi / denom);
-    p[i] = pi; m[i] = mi; v[i] = vi;
-  }
+  if (d_state) cnr::adam_coefficients(a, d_state[2] + 1, step_size, inv_bc2_sqrt);  // step number on the device
+  cnr::adam_update(a, step_size, inv_bc2_sqrt, blockIdx.x, gridDim.x);
 }
 }  // namespace
 
@@ -126,9 +111,9 @@ extern "C" int cnr_adamw_step(float* param, const float* grad, float* exp_avg, f
   const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
   int64_t blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad,
-                     exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step_size, inv_bc2_sqrt,
-                     grad_unscale, d_state);
+  cnr::AdamArgs a{param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, grad_unscale};
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, step_size,
+                     inv_bc2_sqrt, d_state);
   CNR_LAUNCH_CHECK();
   return CNR_OK;
 }

@@ -14,7 +14,7 @@
 // Same arithmetic, expression for expression, as composite.hip + loss.hip (the modular path): d sigma / d colour
 // are bit-identical to cnr_composite_fwd -> cnr_loss_fwd_bwd -> cnr_composite_bwd, the loss values agree to
 // summation order.  Block = 16 waves, one ray per wave at a time.
-#include "cnr_common.h"
+#include "adamw_common.h"
 
 // no fused multiply-add contraction in this file: composite.hip and render_loss.hip evaluate the same expressions and
 // must round them the same way whatever the surrounding code looks like (the one-launch form is tested bitwise
@@ -300,6 +300,43 @@ __global__ __launch_bounds__(256) void step_epilogue_kernel(const float* __restr
   __syncthreads();
   if (threadIdx.x == 0) { d_state[0] = cursor; d_state[1] += 1; d_state[2] += 1; }
 }
+
+// The step's last launch when the step state ping-pongs between two buffers: AdamW on the flat parameter buffer
+// (blocks 0 .. gridDim.x - 2, reading the optimiser step from the CURRENT state) beside the epilogue work (last
+// block: loss values, next slice's max depth, NEXT state = current + (add_rows, 1, 1) written to the other buffer).
+// Nobody writes the current state during the launch, so the two jobs need no ordering between them.
+__global__ __launch_bounds__(256) void adamw_epilogue_kernel(cnr::AdamArgs a, const int64_t* __restrict__ state_cur,
+                                                             int64_t* __restrict__ state_next, int64_t add_rows,
+                                                             const float* __restrict__ partials, int nb,
+                                                             float* __restrict__ losses, int32_t* __restrict__ flags,
+                                                             int C, const float* __restrict__ depth, int64_t pool_rows,
+                                                             const int* __restrict__ perm, int R,
+                                                             float* __restrict__ max_bound) {
+  if (blockIdx.x + 1 < gridDim.x) {
+    float step_size, inv_bc2_sqrt;
+    cnr::adam_coefficients(a, state_cur[2] + 1, step_size, inv_bc2_sqrt);
+    cnr::adam_update(a, step_size, inv_bc2_sqrt, blockIdx.x, gridDim.x - 1);
+    return;
+  }
+  __shared__ float sm[4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t cursor = state_cur[0] + add_rows;
+  if (max_bound) {
+    for (int c = 0; c < C; ++c) {
+      float m = -INFINITY;
+      const int64_t base = (int64_t)c * pool_rows + cursor;
+      for (int r = threadIdx.x; r < R; r += 256)
+        m = fmaxf(m, depth[perm ? (int64_t)c * pool_rows + perm[base + r] : base + r]);
+      m = cnr::wave_max(m);
+      __syncthreads();
+      if (lane == 0) sm[wv] = m;
+      __syncthreads();
+      if (threadIdx.x == 0) max_bound[c] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    }
+  }
+  for (int c = wv; c < C; c += 4) finish_class(partials, nb, losses, flags, C, c, lane);
+  if (threadIdx.x == 0) { state_next[0] = cursor; state_next[1] = state_cur[1] + 1; state_next[2] = state_cur[2] + 1; }
+}
 }  // namespace
 
 extern "C" int64_t cnr_render_loss_workspace_bytes(int C, int R) {
@@ -348,6 +385,28 @@ extern "C" int cnr_step_epilogue(int64_t* d_state, int64_t add_rows, const void*
   const int nb = (R + rpb - 1) / rpb;
   hipLaunchKernelGGL(step_epilogue_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, nb,
                      losses, flags, C, d_state, add_rows, depth, pool_rows, perm, R, next_max_bound);
+  CNR_LAUNCH_CHECK();
+  return CNR_OK;
+}
+
+extern "C" int cnr_adamw_epilogue(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                  float lr, float beta1, float beta2, float eps, float weight_decay,
+                                  float grad_unscale, const int64_t* state_cur, int64_t* state_next, int64_t add_rows,
+                                  const void* workspace, float* losses, int32_t* flags, const float* depth,
+                                  int64_t pool_rows, const int* perm, float* next_max_bound, int C, int R,
+                                  void* stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || !state_cur || !state_next || state_cur == state_next ||
+      !workspace || !losses || !flags || C <= 0 || R <= 0)
+    return CNR_E_ARG;
+  if (next_max_bound && (!depth || pool_rows < R)) return CNR_E_ARG;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  const int rpb = rl_rays_per_block(C, R);
+  const int nb = (R + rpb - 1) / rpb;
+  cnr::AdamArgs a{param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, grad_unscale};
+  hipLaunchKernelGGL(adamw_epilogue_kernel, dim3((unsigned)blocks + 1), dim3(256), 0, (hipStream_t)stream, a, state_cur,
+                     state_next, add_rows, (const float*)workspace, nb, losses, flags, C, depth, pool_rows, perm, R,
+                     next_max_bound);
   CNR_LAUNCH_CHECK();
   return CNR_OK;
 }

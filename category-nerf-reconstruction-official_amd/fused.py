@@ -97,7 +97,10 @@ class FusedCategoryTrainer:
         self.pool = dict(rgbs=st("rgbs"), depth=st("depth"), dirs=st("dirs"), T=st("T_co"), indices=st("indices"))
         self.pool_rows = self.pool["depth"].shape[1]
         assert self.pool_rows >= 2 * self.R
-        self.d_state = torch.zeros(3, device=self.device, dtype=torch.int64)   # cursor, rng step, opt step
+        # device-side step state {pool cursor, rng step, optimiser step}, two copies: step k reads copy k & 1 and its
+        # last kernel writes copy (k + 1) & 1 -- no kernel ever writes a state another kernel of the same step reads
+        self.d_state2 = torch.zeros(2, 3, device=self.device, dtype=torch.int64)
+        self.parity = 0
         # epoch shuffle as an index permutation (C, pool_rows): the pool itself never moves
         self.perm = torch.empty(n_cls, self.pool_rows, device=self.device, dtype=torch.int32)
         self._zero64 = torch.zeros(1, device=self.device, dtype=torch.int64)
@@ -112,11 +115,16 @@ class FusedCategoryTrainer:
         self.dbias = self._gbuf[self.theta.numel():].view(n_cls * n_obj, 4, 32)
         self.use_graph = use_graph
         self.split_graph = bool(split_graph)     # the two-graph form of the distributed step, for single-GPU tests
-        self.graph = None
+        self.graphs = {}                         # parity -> captured graph (or (front, back) pair)
         self.steps_done = 0
         self._reshuffle()
 
     # ---- one step, eager (also the body that gets captured) ------------------------------------------
+    @property
+    def d_state(self):
+        """the state the NEXT step will read (int64[3] view)"""
+        return self.d_state2[self.parity]
+
     def _step_body(self):
         self._step_front()
         if self.pg is not None:
@@ -157,7 +165,8 @@ class FusedCategoryTrainer:
         # step's epilogue, or _reshuffle, put it there)
         b = ops.step_prologue(self.theta, lay, L, n_obj, packed, zl, brows, self._gbuf, self.pool["rgbs"],
                               self.pool["depth"], self.pool["dirs"], self.pool["T"], self.n1, self.n2, cfg.surface_eps,
-                              cfg.stop_eps, cfg.min_depth, self.seed, self.d_state, R, self.bufs, self.max_bound,
+                              cfg.stop_eps, cfg.min_depth, self.seed, self.d_state2[self.parity], R, self.bufs,
+                              self.max_bound,
                               self.pool["indices"], self.perm)
         ray_row = b["ray_row"]
         # a8 + a9 fused forward
@@ -183,28 +192,27 @@ class FusedCategoryTrainer:
         _C.call("cnr_latent_bwd", self.theta, *lat_args, zl, self.dbias, reg, self.grad)
 
     def _step_back(self):
-        """AdamW on the flat buffer + the step epilogue."""
-        C, R, o = self.C, self.R, self.bufs
-        ops.adamw_step(self.theta, self.grad, self.exp_avg, self.exp_avg_sq, self.lr, (0.9, 0.999), 1e-8, self.wd,
-                       0, d_state=self.d_state)
-        # last node: loss values + flags from the render kernel's partials, the next slice's max depth, device-side
-        # step state advanced
-        _C.call("cnr_step_epilogue", self.d_state, R, o["rl_ws"], self.losses, self.flags, self.pool["depth"],
-                self.pool_rows, self.perm, self.max_bound, C, R)
+        """Last launch: AdamW on the flat buffer beside the epilogue (loss values + flags from the render kernel's
+        partials, the next slice's max depth, next step state into the other state copy)."""
+        C, R, o, par = self.C, self.R, self.bufs, self.parity
+        _C.call("cnr_adamw_epilogue", self.theta, self.grad, self.exp_avg, self.exp_avg_sq, self.theta.numel(),
+                self.lr, 0.9, 0.999, 1e-8, self.wd, 1.0, self.d_state2[par], self.d_state2[1 - par], R, o["rl_ws"],
+                self.losses, self.flags, self.pool["depth"], self.pool_rows, self.perm, self.max_bound, C, R)
 
     def step(self):
         """One train step.  Returns nothing; ``self.losses`` (3,C) / ``self.flags`` (C,) hold the device-side
         loss terms (depth, colour, opacity) and flags of the step just run.
 
-        After two eager steps the step is captured: one hipGraph on a single GPU; with a process group TWO graphs
-        around the all-reduce (front graph, eager RCCL call, back graph) -- three host calls per step instead of
-        ten, and no collective inside a capture."""
+        After two eager steps the step is captured, once per state parity: one hipGraph on a single GPU; with a
+        process group TWO graphs around the all-reduce (front graph, eager RCCL call, back graph) -- three host
+        calls per step, and no collective inside a capture."""
         if self.cursor + 2 * self.R > self.pool_rows:   # epoch end: reshuffle (scene_cateogries.py:439-449)
             self._reshuffle()
         split = self.pg is not None or self.split_graph
+        par = self.parity
         if not self.use_graph or self.steps_done < 2:
             self._step_body()
-        elif self.graph is None:
+        elif par not in self.graphs:
             if split:
                 ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
                 with torch.cuda.graph(ga):
@@ -215,19 +223,21 @@ class FusedCategoryTrainer:
                 with torch.cuda.graph(gb, pool=ga.pool()):
                     self._step_back()
                 gb.replay()
-                self.graph = (ga, gb)
+                self.graphs[par] = (ga, gb)
             else:
-                self.graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
                     self._step_body()
-                self.graph.replay()
+                g.replay()
+                self.graphs[par] = g
         elif split:
-            self.graph[0].replay()
+            self.graphs[par][0].replay()
             if self.pg is not None:
                 parallel.allreduce_mean_(self.grad, self.pg, prescaled=True)
-            self.graph[1].replay()
+            self.graphs[par][1].replay()
         else:
-            self.graph.replay()
+            self.graphs[par].replay()
+        self.parity ^= 1
         self.cursor += self.R
         self.steps_done += 1
 
@@ -236,8 +246,9 @@ class FusedCategoryTrainer:
         for c in range(self.C):
             self.perm[c].copy_(torch.randperm(self.pool_rows, device=self.device))
         self.cursor = 0
-        self.d_state[0:1].copy_(self._zero64)
-        _C.call("cnr_sample_maxdepth", self.pool["depth"], self.max_bound, self.d_state, self.pool_rows, self.perm,
+        self.d_state2[self.parity, 0:1].copy_(self._zero64)
+        _C.call("cnr_sample_maxdepth", self.pool["depth"], self.max_bound, self.d_state2[self.parity], self.pool_rows,
+                self.perm,
                 self.C, self.R)
 
     # ---- reference-named export ------------------------------------------------------------------------

@@ -262,6 +262,17 @@ int cnr_step_epilogue(int64_t* d_state, int64_t add_rows, const void* workspace,
                       const float* depth, int64_t pool_rows, const int* perm, float* next_max_bound, int C, int R,
                       void* stream);
 
+/* cnr_adamw_step and cnr_step_epilogue side by side in ONE launch, for a step state that ping-pongs between two
+ * int64[3] buffers: every kernel of step k reads state_cur, this launch writes state_next = state_cur + (add_rows,
+ * 1, 1); the caller swaps the two for step k + 1 (two captured graphs, or a pointer swap in eager mode).  With the
+ * current state read-only during the launch, the AdamW blocks (optimiser step = state_cur[2] + 1) and the epilogue
+ * block need no ordering.  Arguments as in cnr_adamw_step / cnr_step_epilogue. */
+int cnr_adamw_epilogue(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                       float beta1, float beta2, float eps, float weight_decay, float grad_unscale,
+                       const int64_t* state_cur, int64_t* state_next, int64_t add_rows, const void* workspace,
+                       float* losses, int32_t* flags, const float* depth, int64_t pool_rows, const int* perm,
+                       float* next_max_bound, int C, int R, void* stream);
+
 /* Same contract and results as cnr_field_bwd, ONE field kernel + the record reduction: each workgroup is
  * `chain_waves` (2 or 3) waves that run forward recompute + data-gradient chain + PE backward for one 32-sample
  * tile each, plus 4 - chain_waves waves that own the weight-gradient accumulators and consume the chain waves'
