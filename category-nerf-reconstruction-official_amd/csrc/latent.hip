@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(const float* __restrict
   latent_fwd_block(th, th, lay, zl, biasrows, blockIdx.x >> 2, blockIdx.x & 3, blockIdx.y);
 }
 
-// grid (NB, C), 256 threads.  Every block recomputes the tiny d pre table (n_obj x 128 values) and the code
+// grid (NB, C), 256 threads, NB = outputs / 256.  Every block recomputes the tiny d pre table (n_obj x 128 values) and the code
 // norms into LDS, then takes its grid-stride share of the concatenated output space
 //   [ d Wt_k[:, :32] and d bt_k : 4*32*33 | d Wl : 4*32*L | d bl : 128 | d shape codes : n_obj*L | d tex codes : n_obj*L ]
 __global__ __launch_bounds__(256) void latent_bwd_kernel(const float* __restrict__ theta, FlatLayout lay,
@@ -111,7 +111,11 @@ extern "C" int cnr_latent_bwd(const float* theta, int64_t class_stride, int64_t 
   if (n_obj > 64) return CNR_E_SHAPE;
   FlatLayout lay{class_stride, off_latW, off_latb, off_shape, off_tex, L, n_obj};
   const size_t lds = (size_t)(n_obj * 128 + 2 * n_obj) * sizeof(float);
-  hipLaunchKernelGGL(latent_bwd_kernel, dim3(64, C), dim3(256), lds, (hipStream_t)stream, theta, lay, zl, dbiasrows,
+  // one output per thread in the second phase (every block repeats the small first phase)
+  const int64_t n4 = 4 * 32 * 33 + (int64_t)4 * 32 * L + 128 + (int64_t)2 * n_obj * L;
+  int nblk = (int)((n4 + 255) / 256);
+  if (nblk > 256) nblk = 256;
+  hipLaunchKernelGGL(latent_bwd_kernel, dim3(nblk, C), dim3(256), lds, (hipStream_t)stream, theta, lay, zl, dbiasrows,
                      n_obj > 1 ? reg_scale : 0.0f, grad);
   CNR_LAUNCH_CHECK();
   return CNR_OK;

@@ -26,6 +26,14 @@ __device__ __forceinline__ void latent_fwd_block(const float* __restrict__ th, c
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const float* code = th + (k == 3 ? lay.tex : lay.shape) + (int64_t)obj * lay.L;
   __shared__ float zs[32];
+  // second-phase operands do not depend on the first phase: fetch them now, ahead of the barrier
+  int w_off, b_off, ld;
+  latent_target(k, w_off, b_off, ld);
+  const int o2 = threadIdx.x >> 3, p2 = threadIdx.x & 7;
+  float tw[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) tw[q] = trunk[w_off + o2 * ld + p2 * 4 + q];
+  const float tb = trunk[b_off + o2];
   float acc[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -43,19 +51,17 @@ __device__ __forceinline__ void latent_fwd_block(const float* __restrict__ th, c
   }
   __syncthreads();
   {  // 32 outputs x 32 inputs on 256 threads: 8 lanes per output, 4 inputs each, then an 8-lane sum
-    int w_off, b_off, ld;
-    latent_target(k, w_off, b_off, ld);
-    const int o = threadIdx.x >> 3, p = threadIdx.x & 7;
+    const int o = o2, p = p2;
     float br = 0.0f;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) br = fmaf(trunk[w_off + o * ld + p * 4 + q], zs[p * 4 + q], br);
+    for (int q = 0; q < 4; ++q) br = fmaf(tw[q], zs[p * 4 + q], br);
     br += __shfl_xor(br, 1, 64);
     br += __shfl_xor(br, 2, 64);
     br += __shfl_xor(br, 4, 64);
     if (p == 0) {
       const int64_t row = (int64_t)c * lay.n_obj + obj;
       zl[(row * 4 + k) * 32 + o] = zs[o];
-      biasrows[(row * 4 + k) * 32 + o] = br + trunk[b_off + o];
+      biasrows[(row * 4 + k) * 32 + o] = br + tb;
     }
   }
 }

@@ -321,6 +321,8 @@ __global__ __launch_bounds__(256) void adamw_epilogue_kernel(cnr::AdamArgs a, co
   __shared__ float sm[4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t cursor = state_cur[0] + add_rows;
+  // the loss values first: their loads are in flight while the max-depth chain (state -> perm -> depth) runs
+  for (int c = wv; c < C; c += 4) finish_class(partials, nb, losses, flags, C, c, lane);
   if (max_bound) {
     for (int c = 0; c < C; ++c) {
       float m = -INFINITY;
@@ -334,7 +336,6 @@ __global__ __launch_bounds__(256) void adamw_epilogue_kernel(cnr::AdamArgs a, co
       if (threadIdx.x == 0) max_bound[c] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
     }
   }
-  for (int c = wv; c < C; c += 4) finish_class(partials, nb, losses, flags, C, c, lane);
   if (threadIdx.x == 0) { state_next[0] = cursor; state_next[1] = state_cur[1] + 1; state_next[2] = state_cur[2] + 1; }
 }
 }  // namespace
