@@ -241,6 +241,26 @@ class FusedCategoryTrainer:
         self.cursor += self.R
         self.steps_done += 1
 
+    def time_field_bwd(self, iters=50):
+        """Average duration (ms) of the dominant call -- the fused field backward on the live buffers of the last step
+        -- launched back to back between two HIP events on the launch stream (outputs go to scratch)."""
+        C, R, S, n_obj, o, b = self.C, self.R, self.S, self.n_obj, self.bufs, self.bufs
+        v = self.lay.views(self.theta)
+        Bc = v["B"] if C == 1 else v["B"].contiguous()
+        kw = dict(device=self.device, dtype=torch.float32)
+        dtrunk, dB, dbias = torch.zeros(C, TRUNK_PARAMS, **kw), torch.zeros(C, 21, 3, **kw), torch.zeros_like(self.dbias)
+        run = lambda: ops.field_bwd(b["pts"], Bc, o["packed"], o["brows"], b["ray_row"], self.scale, o["dsig"], o["drgb"],
+                                    self.grad_scale, dtrunk, dB, dbias, C, R, S, n_obj, self.bwd_blocks, o["bwd_ws"])
+        for _ in range(3):
+            run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+
     def _reshuffle(self):
         """New permutation, cursor back to 0 (scene_cateogries.py:439-449); all on the device, no host sync."""
         for c in range(self.C):

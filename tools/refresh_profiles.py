@@ -1,0 +1,24 @@
+"""Copy the judged summaries of a tools/collect_round.sh run (gpurun_out/<name>) into profiles/r01_*."""
+import csv, json, os, subprocess, sys
+src = sys.argv[1]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = os.path.join(ROOT, "profiles")
+open(os.path.join(P, "r01_bench_2048x64.json"), "w").write(open(f"{src}/bench.json").read().strip().splitlines()[-1] + "\n")
+open(os.path.join(P, "r01_bench_2048x64_under_rocprof.json"), "w").write(
+    open(f"{src}/bench_rocprof.json").read().strip().splitlines()[-1] + "\n")
+subprocess.check_call(["cp", f"{src}/rocprof/b_kernel_stats.csv", os.path.join(P, "r01_bench_2048x64_kernel_stats.csv")])
+for n in ("2048x64", "8192x128"):
+    for name, d in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
+        rows = [r for r in csv.DictReader(open(f"{src}/{d}_{n}/p_counter_collection.csv"))
+                if any(k in r["Kernel_Name"] for k in ("field_", "reduce_records", "pack_kernel"))]
+        with open(os.path.join(P, f"r01_pmc_{name}_{n}.csv"), "w", newline="") as f:
+            w = csv.DictWriter(f, fieldnames=list(rows[0].keys())); w.writeheader(); w.writerows(rows)
+    R, S = n.split("x")
+    out = os.path.join(P, "r01_pmc_traffic.json" if n == "2048x64" else f"r01_pmc_traffic_{n}.json")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools/pmc_summary.py"), f"{src}/pmc_fetch_{n}/p_counter_collection.csv",
+                           f"{src}/pmc_write_{n}/p_counter_collection.csv", out, R, S], stdout=subprocess.DEVNULL)
+sq = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools/pmc_sq_summary.py"),
+                              f"{src}/pmc_sq_2048x64/p_counter_collection.csv", f"{src}/pmc_sq_8192x128/p_counter_collection.csv"])
+open(os.path.join(P, "r01_pmc_sq_mfma_busy.json"), "wb").write(sq)
+subprocess.check_call(["cp", f"{src}/bench_kernels.log", os.path.join(P, "r01_bench_kernels.txt")])
+print("profiles refreshed from", src)
