@@ -151,3 +151,55 @@ def test_param_prep_equals_separate_calls(cnr, dev, C, n_obj, L):
         zref.append(torch.relu(torch.einsum("col,cnl->cno", v["latW"][:, k], code) + v["latb"][:, k][:, None, :]))
     zref = torch.stack(zref, dim=2).reshape(C * n_obj, 4, 32)
     assert rel_l2(zl1, zref) < 1e-6
+
+
+def test_prologue_and_epilogue_launches_equal_their_parts(cnr, dev):
+    """cnr_step_prologue == cnr_param_prep + cnr_sample_rays, and cnr_adamw_epilogue == cnr_adamw_step +
+    cnr_step_epilogue (on a second state copy): every output bitwise equal -- the one-launch forms are the same
+    device functions side by side in one grid."""
+    _C, ops = cnr._C, cnr.ops
+    C, n_obj, L, R, n1, n2 = 2, 4, 64, 200, 3, 13
+    gen = torch.Generator().manual_seed(4)
+    theta, lay = cnr.fused.init_params(C, L, n_obj, gen, dev)
+    pools = [cnr.scene_cateogries.synthetic_pool(8 * R, n_obj, gen, "cpu") for _ in range(C)]
+    st = lambda k: torch.stack([p[k] for p in pools]).to(dev).contiguous()
+    rgbs, depth, dirs, T, idx = st("rgbs"), st("depth"), st("dirs"), st("T_co"), st("indices")
+    pool_rows = depth.shape[1]
+    perm = torch.stack([torch.randperm(pool_rows, generator=gen) for _ in range(C)]).to(torch.int32).to(dev)
+    state = torch.tensor([3 * R, 7, 11], dtype=torch.int64, device=dev)
+    mb = torch.empty(C, device=dev)
+    _C.call("cnr_sample_maxdepth", depth, mb, state, pool_rows, perm, C, R)
+    # ---- prologue
+    pk = [torch.empty(C, _C.pack_bytes(), device=dev, dtype=torch.uint8) for _ in range(2)]
+    zl, br = [torch.empty(C * n_obj, 4, 32, device=dev) for _ in range(2)], [torch.empty(C * n_obj, 4, 32, device=dev) for _ in range(2)]
+    zb = [torch.full((1000,), 5.0, device=dev) for _ in range(2)]
+    _C.call("cnr_param_prep", theta, lay.total, lay.trunk[0], lay.latW[0], lay.latb[0], lay.shape[0], lay.tex[0], L, n_obj,
+            C, pk[0], zl[0], br[0], zb[0], zb[0].numel())
+    a = ops.sample_rays(rgbs, depth, dirs, T, n1, n2, 0.1, 0.05, seed=9, d_state=state, rays=R, out={}, max_bound=mb,
+                        pool_indices=idx, n_obj=n_obj, perm=perm)
+    b = ops.step_prologue(theta, lay, L, n_obj, pk[1], zl[1], br[1], zb[1], rgbs, depth, dirs, T, n1, n2, 0.1, 0.05, 0.0, 9,
+                          state, R, {}, mb, idx, perm)
+    assert torch.equal(pk[0], pk[1]) and torch.equal(zl[0], zl[1]) and torch.equal(br[0], br[1]) and torch.equal(zb[0], zb[1])
+    for k in ("z", "pts", "gt_rgb", "gt_depth", "depth_mask", "labels", "ray_row"):
+        assert torch.equal(a[k], b[k]), k
+    # ---- epilogue
+    n = theta.numel()
+    grad = torch.randn(n, generator=gen).to(dev) * 1e-3
+    ws = torch.rand(_C.render_loss_workspace_bytes(C, R) // 4, generator=gen).to(dev)
+    outs = []
+    for fused in (False, True):
+        p, m, v = theta.clone().reshape(-1), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        s_cur, s_next = state.clone(), torch.zeros(3, dtype=torch.int64, device=dev)
+        losses, flags, mbn = torch.empty(3, C, device=dev), torch.empty(C, device=dev, dtype=torch.int32), torch.empty(C, device=dev)
+        if fused:
+            _C.call("cnr_adamw_epilogue", p, grad, m, v, n, 1e-3, 0.9, 0.999, 1e-8, 0.013, 1.0, s_cur, s_next, R, ws, losses,
+                    flags, depth, pool_rows, perm, mbn, C, R)
+            new_state = s_next
+        else:
+            ops.adamw_step(p, grad, m, v, 1e-3, (0.9, 0.999), 1e-8, 0.013, 0, d_state=s_cur)
+            _C.call("cnr_step_epilogue", s_cur, R, ws, losses, flags, depth, pool_rows, perm, mbn, C, R)
+            new_state = s_cur
+        outs.append((p, m, v, losses, flags, mbn, new_state.clone()))
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+    assert outs[1][6].tolist() == [4 * R, 8, 12]
