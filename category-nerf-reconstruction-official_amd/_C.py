@@ -35,10 +35,10 @@ SIGNATURES = {
     "cnr_adamw_step": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i64, _f, _vp, _vp],
     "cnr_pack_bytes": [],
     "cnr_pack_weights": [_vp, _vp, _i, _vp],
-    "cnr_field_fwd": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _vp],
-    "cnr_field_bwd": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i64, _vp],
-    "cnr_field_bwd_pipe": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i64,
-                           _vp],
+    "cnr_field_fwd": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i64, _vp],
+    "cnr_field_bwd": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i64, _i64, _i64,
+                      _i64, _vp],
+    "cnr_field_bwd_pipe": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i64, _i64, _i64, _i64, _vp],
     "cnr_field_bwd_workspace_bytes": [_i, _i],
     "cnr_gather_pool": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "cnr_dense_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],

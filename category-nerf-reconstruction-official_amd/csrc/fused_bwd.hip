@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(
     const float* __restrict__ biasrows, const int* __restrict__ ray_row, float inv_scale,
     const float* __restrict__ d_sigma, const float* __restrict__ d_rgb, float gscale,
     float* __restrict__ records, float* __restrict__ dbiasrows,
-    int64_t N, int S, int R, int rows_per_class) {
+    int64_t N, int S, int R, int rows_per_class, int64_t B_stride) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int c = blockIdx.y;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, h = lane >> 5, col = lane & 31;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(
     float* Bl = reinterpret_cast<float*>(smem + LDS_BL);
     for (int i = threadIdx.x; i < 66; i += 256) {
       const int hh = i / 33, k = i % 33, d = k / 3;
-      Bl[i] = (hh == 1 && d == 10) ? 0.0f : Bdir[(size_t)c * 63 + (11 * hh + d) * 3 + (k % 3)];
+      Bl[i] = (hh == 1 && d == 10) ? 0.0f : Bdir[(size_t)c * B_stride + (11 * hh + d) * 3 + (k % 3)];
     }
     float* rt = reinterpret_cast<float*>(ws + WS_ROWTAB);
     for (int i = lane; i < ROWS_LDS * 128 + 64; i += 64) rt[i] = 0.0f;
@@ -537,7 +537,7 @@ extern "C" int cnr_field_bwd(const float* pts, const float* B, const void* packe
                              const int* ray_row, float scale, const float* d_sigma, const float* d_rgb,
                              float grad_scale, float* dtrunk, float* dB, float* dbiasrows, int C, int R, int S,
                              int rows_per_class, int max_blocks, void* workspace, int64_t workspace_bytes,
-                             void* stream) {
+                             int64_t B_stride, int64_t dtrunk_stride, int64_t dB_stride, void* stream) {
   if (!pts || !B || !packed || !biasrows || !d_sigma || !d_rgb || !dtrunk || !dB || !dbiasrows || !workspace)
     return CNR_E_ARG;
   if (C <= 0 || R <= 0 || S <= 0 || !(scale > 0.f) || !(grad_scale > 0.f)) return CNR_E_ARG;
@@ -569,13 +569,14 @@ extern "C" int cnr_field_bwd(const float* pts, const float* B, const void* packe
 #define CNR_LAUNCH_BWD(BIG, PART)                                                                               \
   hipLaunchKernelGGL((field_bwd_kernel<BIG, PART>), grid, dim3(256), LDS_TOTAL, (hipStream_t)stream, pts, B,    \
                      (const unsigned char*)packed, biasrows, ray_row, 1.0f / scale, d_sigma, d_rgb, grad_scale, \
-                     (float*)workspace, dbiasrows, N, S, R, rows_per_class)
+                     (float*)workspace, dbiasrows, N, S, R, rows_per_class, B_stride > 0 ? B_stride : (int64_t)63)
   if (S >= 32) { CNR_LAUNCH_BWD(true, 1); CNR_LAUNCH_BWD(true, 0); }
   else { CNR_LAUNCH_BWD(false, 1); CNR_LAUNCH_BWD(false, 0); }
 #undef CNR_LAUNCH_BWD
   CNR_LAUNCH_CHECK();
   hipLaunchKernelGGL(reduce_records_kernel, dim3(REC_FLOATS / 64, (unsigned)C), dim3(256), 0, (hipStream_t)stream,
-                     (const float*)workspace, (int)blocks, dtrunk, dB, dbiasrows, rows_per_class);
+                     (const float*)workspace, (int)blocks, dtrunk, dB, dbiasrows, rows_per_class,
+                     dtrunk_stride > 0 ? dtrunk_stride : (int64_t)TRUNK, dB_stride > 0 ? dB_stride : (int64_t)63);
   CNR_LAUNCH_CHECK();
   return CNR_OK;
 }

@@ -149,7 +149,8 @@ __device__ __forceinline__ bool rec_entry_written(int i, int rows_per_class) {
 }
 __global__ __launch_bounds__(256) void reduce_records_kernel(const float* __restrict__ records, int nwg,
                                                              float* __restrict__ dtrunk, float* __restrict__ dB,
-                                                             float* __restrict__ dbiasrows, int rows_per_class) {
+                                                             float* __restrict__ dbiasrows, int rows_per_class,
+                                                             int64_t st_trunk, int64_t st_B) {
   __shared__ float part[4][64];
   const int c = blockIdx.y;
   const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
@@ -174,8 +175,8 @@ __global__ __launch_bounds__(256) void reduce_records_kernel(const float* __rest
   __syncthreads();
   if (q == 0 && live) {
     const float v = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
-    if (i < TRUNK) dtrunk[(size_t)c * TRUNK + i] += v;
-    else if (i < TRUNK + 63) atomicAdd(&dB[(size_t)c * 63 + (i - TRUNK)], v);        // two addends per element
+    if (i < TRUNK) dtrunk[(size_t)c * st_trunk + i] += v;
+    else if (i < TRUNK + 63) atomicAdd(&dB[(size_t)c * st_B + (i - TRUNK)], v);        // two addends per element
     else if (i < TRUNK + 126) atomicAdd(&dB[(size_t)c * 63 + (i - TRUNK - 63)], v);
     else dbiasrows[(size_t)c * rows_per_class * 128 + (i - (TRUNK + 126))] += v;
   }

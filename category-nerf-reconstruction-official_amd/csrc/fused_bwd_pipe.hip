@@ -71,7 +71,8 @@ __global__ __launch_bounds__(256, 1) void field_bwd_pipe_kernel(
     const float* __restrict__ pts, const float* __restrict__ Bdir, const unsigned char* __restrict__ packed,
     const float* __restrict__ biasrows, const int* __restrict__ ray_row, float inv_scale,
     const float* __restrict__ d_sigma, const float* __restrict__ d_rgb, float gscale,
-    float* __restrict__ records, float* __restrict__ dbiasrows, int N, int S, int R, int rows_per_class) {
+    float* __restrict__ records, float* __restrict__ dbiasrows, int N, int S, int R, int rows_per_class,
+    int64_t B_stride) {
   constexpr int NDW = 4 - NCH;
   constexpr int NW = NBLOCKS / NDW;  // accumulator blocks per dW wave
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_pipe_kernel(
     float* Bl = reinterpret_cast<float*>(smem + P_LDS_BL);
     for (int i = threadIdx.x; i < 66; i += 256) {
       const int hh = i / 33, k = i % 33, d = k / 3;
-      Bl[i] = (hh == 1 && d == 10) ? 0.0f : Bdir[(size_t)c * 63 + (11 * hh + d) * 3 + (k % 3)];
+      Bl[i] = (hh == 1 && d == 10) ? 0.0f : Bdir[(size_t)c * B_stride + (11 * hh + d) * 3 + (k % 3)];
     }
     float* br = reinterpret_cast<float*>(smem + P_LDS_BR);  // host guarantees 1 <= rows_per_class <= ROWS_LDS
     for (int i = threadIdx.x; i < rows_per_class * 128; i += 256) br[i] = biasrows[(size_t)c * rows_per_class * 128 + i];
@@ -609,7 +610,8 @@ extern "C" int cnr_field_bwd_pipe(const float* pts, const float* B, const void* 
                                   const int* ray_row, float scale, const float* d_sigma, const float* d_rgb,
                                   float grad_scale, float* dtrunk, float* dB, float* dbiasrows, int C, int R, int S,
                                   int rows_per_class, int max_blocks, int chain_waves, void* workspace,
-                                  int64_t workspace_bytes, void* stream) {
+                                  int64_t workspace_bytes, int64_t B_stride, int64_t dtrunk_stride, int64_t dB_stride,
+                                  void* stream) {
   if (!pts || !B || !packed || !biasrows || !d_sigma || !d_rgb || !dtrunk || !dB || !dbiasrows || !workspace)
     return CNR_E_ARG;
   if (C <= 0 || R <= 0 || S <= 0 || !(scale > 0.f) || !(grad_scale > 0.f)) return CNR_E_ARG;
@@ -618,7 +620,8 @@ extern "C" int cnr_field_bwd_pipe(const float* pts, const float* B, const void* 
   // Everything else (one row per ray, many objects) takes the block-split kernels.
   if (ray_row == nullptr || rows_per_class < 1 || rows_per_class > ROWS_LDS)
     return cnr_field_bwd(pts, B, packed, biasrows, ray_row, scale, d_sigma, d_rgb, grad_scale, dtrunk, dB, dbiasrows, C,
-                         R, S, rows_per_class, max_blocks, workspace, workspace_bytes, stream);
+                         R, S, rows_per_class, max_blocks, workspace, workspace_bytes, B_stride, dtrunk_stride, dB_stride,
+                         stream);
   if (S > 240) return CNR_E_SHAPE;
   if (((uintptr_t)packed & 15) != 0 || ((uintptr_t)biasrows & 15) != 0 || ((uintptr_t)workspace & 15) != 0)
     return CNR_E_ALIGN;
@@ -648,12 +651,14 @@ extern "C" int cnr_field_bwd_pipe(const float* pts, const float* B, const void* 
 #define CNR_LAUNCH_PIPE(NCH)                                                                                  \
   hipLaunchKernelGGL((field_bwd_pipe_kernel<NCH>), grid, dim3(256), p_lds_total<NCH>(), (hipStream_t)stream,  \
                      pts, B, (const unsigned char*)packed, biasrows, ray_row, 1.0f / scale, d_sigma, d_rgb,   \
-                     grad_scale, (float*)workspace, dbiasrows, (int)N, S, R, rows_per_class)
+                     grad_scale, (float*)workspace, dbiasrows, (int)N, S, R, rows_per_class,                    \
+                     B_stride > 0 ? B_stride : (int64_t)63)
   if (chain_waves == 3) CNR_LAUNCH_PIPE(3); else CNR_LAUNCH_PIPE(2);
 #undef CNR_LAUNCH_PIPE
   CNR_LAUNCH_CHECK();
   hipLaunchKernelGGL(reduce_records_kernel, dim3(REC_FLOATS / 64, (unsigned)C), dim3(256), 0, (hipStream_t)stream,
-                     (const float*)workspace, (int)blocks, dtrunk, dB, dbiasrows, rows_per_class);
+                     (const float*)workspace, (int)blocks, dtrunk, dB, dbiasrows, rows_per_class,
+                     dtrunk_stride > 0 ? dtrunk_stride : (int64_t)TRUNK, dB_stride > 0 ? dB_stride : (int64_t)63);
   CNR_LAUNCH_CHECK();
   return CNR_OK;
 }

@@ -135,7 +135,8 @@ namespace {
 __global__ __launch_bounds__(256, 4) void field_fwd_kernel(
     const float* __restrict__ pts, const float* __restrict__ Bdir, const unsigned char* __restrict__ packed,
     const float* __restrict__ biasrows, const int* __restrict__ ray_row, float inv_scale,
-    float* __restrict__ sigmas, float* __restrict__ rgbs, int64_t N /* samples per class */, int S, int R) {
+    float* __restrict__ sigmas, float* __restrict__ rgbs, int64_t N /* samples per class */, int S, int R,
+    int64_t B_stride) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int c = blockIdx.y;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, h = lane >> 5, col = lane & 31;
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(256, 4) void field_fwd_kernel(
     float* Bl = reinterpret_cast<float*>(smem + PK_OFF_BWD);  // [2][33] per-half rows
     for (int i = threadIdx.x; i < 66; i += 256) {
       const int hh = i / 33, k = i % 33, d = k / 3;
-      Bl[i] = (hh == 1 && d == 10) ? 0.0f : Bdir[(size_t)c * 63 + (11 * hh + d) * 3 + (k % 3)];
+      Bl[i] = (hh == 1 && d == 10) ? 0.0f : Bdir[(size_t)c * B_stride + (11 * hh + d) * 3 + (k % 3)];
     }
   }
   __syncthreads();
@@ -309,7 +310,7 @@ extern "C" int cnr_step_prologue(
 
 extern "C" int cnr_field_fwd(const float* pts, const float* B, const void* packed, const float* biasrows,
                              const int* ray_row, float scale, float* sigmas, float* rgbs, int C, int R, int S,
-                             void* stream) {
+                             int64_t B_stride, void* stream) {
   if (!pts || !B || !packed || !biasrows || !sigmas || !rgbs || C <= 0 || R <= 0 || S <= 0 || !(scale > 0.f))
     return CNR_E_ARG;
   if (((uintptr_t)packed & 15) != 0 || ((uintptr_t)biasrows & 15) != 0) return CNR_E_ALIGN;
@@ -321,7 +322,8 @@ extern "C" int cnr_field_fwd(const float* pts, const float* B, const void* packe
   const size_t lds = (size_t)fz::PK_OFF_BWD + 66 * sizeof(float) + 8;
   dim3 grid((unsigned)blocks, (unsigned)C);
   hipLaunchKernelGGL(field_fwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, pts, B,
-                     (const unsigned char*)packed, biasrows, ray_row, 1.0f / scale, sigmas, rgbs, N, S, R);
+                     (const unsigned char*)packed, biasrows, ray_row, 1.0f / scale, sigmas, rgbs, N, S, R,
+                     B_stride > 0 ? B_stride : (int64_t)63);
   CNR_LAUNCH_CHECK();
   return CNR_OK;
 }

@@ -302,8 +302,8 @@ __global__ __launch_bounds__(256) void step_epilogue_kernel(const float* __restr
 }
 
 // The step's last launch when the step state ping-pongs between two buffers: AdamW on the flat parameter buffer
-// (blocks 0 .. gridDim.x - 2, reading the optimiser step from the CURRENT state) beside the epilogue work (last
-// block: loss values, next slice's max depth, NEXT state = current + (add_rows, 1, 1) written to the other buffer).
+// (the first blocks, reading the optimiser step from the CURRENT state) beside the epilogue work (one block per class:
+// loss values, next slice's max depth; class 0 also writes NEXT state = current + (add_rows, 1, 1) to the other buffer).
 // Nobody writes the current state during the launch, so the two jobs need no ordering between them.
 __global__ __launch_bounds__(256) void adamw_epilogue_kernel(cnr::AdamArgs a, const int64_t* __restrict__ state_cur,
                                                              int64_t* __restrict__ state_next, int64_t add_rows,
@@ -312,31 +312,31 @@ __global__ __launch_bounds__(256) void adamw_epilogue_kernel(cnr::AdamArgs a, co
                                                              int C, const float* __restrict__ depth, int64_t pool_rows,
                                                              const int* __restrict__ perm, int R,
                                                              float* __restrict__ max_bound) {
-  if (blockIdx.x + 1 < gridDim.x) {
+  const int nadam = gridDim.x - C;   // AdamW blocks first, then one epilogue block per class
+  if ((int)blockIdx.x < nadam) {
     float step_size, inv_bc2_sqrt;
     cnr::adam_coefficients(a, state_cur[2] + 1, step_size, inv_bc2_sqrt);
-    cnr::adam_update(a, step_size, inv_bc2_sqrt, blockIdx.x, gridDim.x - 1);
+    cnr::adam_update(a, step_size, inv_bc2_sqrt, blockIdx.x, nadam);
     return;
   }
   __shared__ float sm[4];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int c = blockIdx.x - nadam, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t cursor = state_cur[0] + add_rows;
   // the loss values first: their loads are in flight while the max-depth chain (state -> perm -> depth) runs
-  for (int c = wv; c < C; c += 4) finish_class(partials, nb, losses, flags, C, c, lane);
+  if (wv == 0) finish_class(partials, nb, losses, flags, C, c, lane);
   if (max_bound) {
-    for (int c = 0; c < C; ++c) {
-      float m = -INFINITY;
-      const int64_t base = (int64_t)c * pool_rows + cursor;
-      for (int r = threadIdx.x; r < R; r += 256)
-        m = fmaxf(m, depth[perm ? (int64_t)c * pool_rows + perm[base + r] : base + r]);
-      m = cnr::wave_max(m);
-      __syncthreads();
-      if (lane == 0) sm[wv] = m;
-      __syncthreads();
-      if (threadIdx.x == 0) max_bound[c] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
-    }
+    float m = -INFINITY;
+    const int64_t base = (int64_t)c * pool_rows + cursor;
+    for (int r = threadIdx.x; r < R; r += 256)
+      m = fmaxf(m, depth[perm ? (int64_t)c * pool_rows + perm[base + r] : base + r]);
+    m = cnr::wave_max(m);
+    if (lane == 0) sm[wv] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) max_bound[c] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
   }
-  if (threadIdx.x == 0) { state_next[0] = cursor; state_next[1] = state_cur[1] + 1; state_next[2] = state_cur[2] + 1; }
+  if (c == 0 && threadIdx.x == 0) {
+    state_next[0] = cursor; state_next[1] = state_cur[1] + 1; state_next[2] = state_cur[2] + 1;
+  }
 }
 }  // namespace
 
@@ -405,7 +405,7 @@ extern "C" int cnr_adamw_epilogue(float* param, const float* grad, float* exp_av
   const int rpb = rl_rays_per_block(C, R);
   const int nb = (R + rpb - 1) / rpb;
   cnr::AdamArgs a{param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, grad_unscale};
-  hipLaunchKernelGGL(adamw_epilogue_kernel, dim3((unsigned)blocks + 1), dim3(256), 0, (hipStream_t)stream, a, state_cur,
+  hipLaunchKernelGGL(adamw_epilogue_kernel, dim3((unsigned)blocks + C), dim3(256), 0, (hipStream_t)stream, a, state_cur,
                      state_next, add_rows, (const float*)workspace, nb, losses, flags, C, depth, pool_rows, perm, R,
                      next_max_bound);
   CNR_LAUNCH_CHECK();

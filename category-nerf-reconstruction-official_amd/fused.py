@@ -150,12 +150,12 @@ class FusedCategoryTrainer:
             o["rl_ws"] = torch.zeros(_C.render_loss_workspace_bytes(C, R), device=self.device, dtype=torch.uint8)
             o["bwd_ws"] = torch.empty(_C.field_bwd_workspace_bytes(C, self.bwd_blocks), device=self.device,
                                       dtype=torch.uint8)
-            if C > 1:
-                o["dtrunk"] = torch.empty(C, TRUNK_PARAMS, **kw)
-                o["dB"] = torch.empty(C, 21, 3, **kw)
         zl, brows, packed = o["zl"], o["brows"], o["packed"]
         lat_args = (lay.total, lay.latW[0], lay.latb[0], lay.shape[0], lay.tex[0], L, n_obj, C)
-        Bc = v["B"] if C == 1 else v["B"].contiguous()
+        # B, dtrunk, dB: class 0's slice of the flat (C, P) buffers + the class stride P (no gather / scatter copies)
+        P = lay.total
+        Bc = self.theta[0, lay.B[0]:lay.B[1]]
+        g_trunk, g_B = self.grad[0, lay.trunk[0]:lay.trunk[1]], self.grad[0, lay.B[0]:lay.B[1]]
         # One stream, one chain of kernels.  (Parallel hipGraph branches -- parameter prep beside sampling, the loss
         # values beside the field backward -- were measured: every cross-queue edge costs more than the few
         # microseconds of overlap it buys at this step size, 0.154 -> 0.170 ms per step.)
@@ -171,22 +171,16 @@ class FusedCategoryTrainer:
         ray_row = b["ray_row"]
         # a8 + a9 fused forward
         sig, rgb = o["sig"], o["rgbs"]
-        _C.call("cnr_field_fwd", b["pts"], Bc, packed, brows, ray_row, self.scale, sig, rgb, C, R, S)
+        _C.call("cnr_field_fwd", b["pts"], Bc, packed, brows, ray_row, self.scale, sig, rgb, C, R, S, P)
         # a11-a15 in one launch: composite, losses, their gradient, composite backward
         inv_w = 1.0 / self.world
         _C.call("cnr_render_loss", sig, rgb, b["z"], b["gt_depth"], b["gt_rgb"], b["labels"], b["depth_mask"],
                 5.0, 10.0, inv_w, o["dsig"], o["drgb"], o["depth"], o["var"], o["rgb"], o["opa"], C, R, S,
                 o["rl_ws"], o["rl_ws"].numel())
         # fused backward: dtrunk, dB, dbiasrows straight into the flat gradient buffer views
-        if C == 1:   # one class: the views of the flat gradient row are contiguous, accumulate in place
-            dtrunk, dB = gv["trunk"], gv["B"]
-        else:
-            dtrunk, dB = o["dtrunk"].zero_(), o["dB"].zero_()
-        ops.field_bwd(b["pts"], Bc, packed, brows, ray_row, self.scale, o["dsig"], o["drgb"],
-                      self.grad_scale, dtrunk, dB, self.dbias, C, R, S, n_obj, self.bwd_blocks, o["bwd_ws"])
-        if C > 1:
-            gv["trunk"].copy_(dtrunk)
-            gv["B"].copy_(dB)
+        ops.field_bwd(b["pts"], Bc, packed, brows, ray_row, self.scale, o["dsig"], o["drgb"], self.grad_scale,
+                      g_trunk, g_B, self.dbias, C, R, S, n_obj, self.bwd_blocks, o["bwd_ws"],
+                      B_stride=P, dtrunk_stride=P, dB_stride=P)
         # latent backward + code regulariser: one kernel over the flat rows
         reg = 0.0005 * inv_w                     # loss.py:5-15, train.py:165-167
         _C.call("cnr_latent_bwd", self.theta, *lat_args, zl, self.dbias, reg, self.grad)
@@ -246,7 +240,7 @@ class FusedCategoryTrainer:
         -- launched back to back between two HIP events on the launch stream (outputs go to scratch)."""
         C, R, S, n_obj, o, b = self.C, self.R, self.S, self.n_obj, self.bufs, self.bufs
         v = self.lay.views(self.theta)
-        Bc = v["B"] if C == 1 else v["B"].contiguous()
+        Bc = v["B"].contiguous()
         kw = dict(device=self.device, dtype=torch.float32)
         dtrunk, dB, dbias = torch.zeros(C, TRUNK_PARAMS, **kw), torch.zeros(C, 21, 3, **kw), torch.zeros_like(self.dbias)
         run = lambda: ops.field_bwd(b["pts"], Bc, o["packed"], o["brows"], b["ray_row"], self.scale, o["dsig"], o["drgb"],

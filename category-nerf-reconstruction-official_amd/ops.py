@@ -365,14 +365,17 @@ FIELD_BWD_VARIANT = os.environ.get("CNR_FIELD_BWD", "pipe3")
 
 
 def field_bwd(pts, B, packed, biasrows, ray_row, scale, d_sig, d_rgb, grad_scale, dtrunk, dB, dbiasrows, C, R, S,
-              rows_per_class, max_blocks, workspace, variant=None):
+              rows_per_class, max_blocks, workspace, variant=None, B_stride=0, dtrunk_stride=0, dB_stride=0):
+    """strides (floats, 0 = dense): B / dtrunk / dB may be views into a flat (C, P) buffer, see cnr_hip.h"""
     v = variant or FIELD_BWD_VARIANT
     if v == "split":
         _C.call("cnr_field_bwd", pts, B, packed, biasrows, ray_row, scale, d_sig, d_rgb, grad_scale, dtrunk, dB,
-                dbiasrows, C, R, S, rows_per_class, max_blocks, workspace, workspace.numel())
+                dbiasrows, C, R, S, rows_per_class, max_blocks, workspace, workspace.numel(), int(B_stride),
+                int(dtrunk_stride), int(dB_stride))
     elif v in ("pipe2", "pipe3"):
         _C.call("cnr_field_bwd_pipe", pts, B, packed, biasrows, ray_row, scale, d_sig, d_rgb, grad_scale, dtrunk,
-                dB, dbiasrows, C, R, S, rows_per_class, max_blocks, int(v[-1]), workspace, workspace.numel())
+                dB, dbiasrows, C, R, S, rows_per_class, max_blocks, int(v[-1]), workspace, workspace.numel(), int(B_stride),
+                int(dtrunk_stride), int(dB_stride))
     else:
         raise ValueError(f"unknown cnr_field_bwd variant {v!r}")
 
@@ -383,7 +386,7 @@ def field_fwd(pts, B, packed, biasrows, ray_row, scale):
     sig = torch.empty(C, R, S, device=pts.device, dtype=torch.float32)
     rgb = torch.empty(C, R, S, 3, device=pts.device, dtype=torch.float32)
     _C.call("cnr_field_fwd", pts.contiguous(), B.contiguous(), packed, biasrows.contiguous(), ray_row,
-            float(scale), sig, rgb, C, R, S)
+            float(scale), sig, rgb, C, R, S, 0)
     return sig, rgb
 
 

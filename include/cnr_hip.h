@@ -166,9 +166,12 @@ int cnr_pack_weights(const float* trunk, void* packed, int C, void* stream);
 
 /* pts (C,R,S,3), B (C,21,3), packed (C,cnr_pack_bytes()), biasrows (rows,4,32) -> sigmas (C,R,S) = raw*10,
  * rgbs (C,R,S,3).  f16 MFMA operands / fp32 accumulate, fp32 PE, fp32 sigma head.  Any S. */
+/* Class strides (floats; 0 = dense): B_stride between the (21,3) direction matrices of consecutive classes,
+ * dtrunk_stride / dB_stride between the per-class gradient blocks -- so that B, dtrunk and dB may be views of a flat
+ * (C, P) parameter / gradient buffer (the fused trainer's layout) with no gather or scatter copies. */
 int cnr_field_fwd(const float* pts, const float* B, const void* packed, const float* biasrows,
                   const int* ray_row, float scale, float* sigmas, float* rgbs, int C, int R, int S,
-                  void* stream);
+                  int64_t B_stride, void* stream);
 
 /* Backward of cnr_field_fwd (recomputes the forward per tile): d_sigma (C,R,S) = dL/dsigmas,
  * d_rgb (C,R,S,3) -> dtrunk (C,13892), dB (C,21,3), dbiasrows (rows,4,32); all three ACCUMULATED
@@ -188,7 +191,8 @@ int64_t cnr_field_bwd_workspace_bytes(int C, int max_blocks);
 int cnr_field_bwd(const float* pts, const float* B, const void* packed, const float* biasrows,
                   const int* ray_row, float scale, const float* d_sigma, const float* d_rgb,
                   float grad_scale, float* dtrunk, float* dB, float* dbiasrows, int C, int R, int S,
-                  int rows_per_class, int max_blocks, void* workspace, int64_t workspace_bytes, void* stream);
+                  int rows_per_class, int max_blocks, void* workspace, int64_t workspace_bytes, int64_t B_stride,
+                  int64_t dtrunk_stride, int64_t dB_stride, void* stream);
 
 /* ---- dense layers of the background model, OccupancyMap (src/model.py:86-155) -----------------
  * y (M,N) = act(x (M,K) W^T + b), W (N,K) row-major as torch.nn.Linear stores it, relu != 0: act = ReLU.
@@ -281,7 +285,8 @@ int cnr_field_bwd_pipe(const float* pts, const float* B, const void* packed, con
                        const int* ray_row, float scale, const float* d_sigma, const float* d_rgb,
                        float grad_scale, float* dtrunk, float* dB, float* dbiasrows, int C, int R, int S,
                        int rows_per_class, int max_blocks, int chain_waves, void* workspace,
-                       int64_t workspace_bytes, void* stream);
+                       int64_t workspace_bytes, int64_t B_stride,
+                       int64_t dtrunk_stride, int64_t dB_stride, void* stream);
 
 #ifdef __cplusplus
 }
