@@ -47,14 +47,30 @@ __device__ long long g_pipe_stamps[160];
 template <int V> using IC = std::integral_constant<int, V>;
 enum Step { ST_R2, ST_R0, ST_T1, ST_VD, ST_ES, ST_S2, ST_CAT, ST_S1, ST_XYZ, NSTEPS };
 
-typedef unsigned short us8 __attribute__((ext_vector_type(8)));
 // f16 pack of the 8 accumulator registers of k-step s, zeroed where the (post-ReLU, hence non-negative) activation
-// is zero: three packed 16-bit integer ops per register pair instead of a compare + select per element
-__device__ __forceinline__ h8 pack8_masked(const f16v& a, int s, const h8& act) {
-  const us8 one = {1, 1, 1, 1, 1, 1, 1, 1};
-  const us8 m = __builtin_elementwise_min(__builtin_bit_cast(us8, act), one) * (unsigned short)0xFFFF;
-  return __builtin_bit_cast(h8, (us8)(__builtin_bit_cast(us8, pack8(a, s, false)) & m));
+// is zero.  Three packed-integer VALU ops per register pair -- min(act, 1) per half, times 0xFFFF, and -- written as
+// inline asm: from the portable vector form hipcc builds a compare / select / shift / permute sequence per element
+// (9 instructions and VCC wait states per pair; these masks are on every backward step's critical path).
+typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+// 0xFFFF per half where the activation is non-zero.  Only depends on the forward: the backward steps compute the
+// mask of the NEXT step before their barrier, so that after the barrier a step is MFMA -> cvt -> and -> store.
+__device__ __forceinline__ u4v relu_mask(const h8& act) {
+  const u4v av = __builtin_bit_cast(u4v, act);
+  u4v m;
+  const unsigned int ones = 0x00010001u;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    unsigned int t;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(t) : "v"(av[i]), "s"(ones));
+    asm("v_pk_mul_lo_u16 %0, %1, -1" : "=v"(t) : "v"(t));
+    m[i] = t;
+  }
+  return m;
 }
+__device__ __forceinline__ h8 pack8_and(const f16v& a, int s, const u4v& m) {
+  return __builtin_bit_cast(h8, (u4v)(__builtin_bit_cast(u4v, pack8(a, s, false)) & m));
+}
+__device__ __forceinline__ h8 pack8_masked(const f16v& a, int s, const h8& act) { return pack8_and(a, s, relu_mask(act)); }
 // (Tried: the chain role's MFMAs as inline asm in VGPR form -- a 512-register kernel gets AGPR-form MFMAs, which costs
 //  the chain role 16 v_accvgpr_read per layer.  With each layer's chain as one asm statement and hand-written wait
 //  states it passed the parity tests and gained 2 % (288.8 -> 282.8 us at 8192 x 128): not worth carrying hazard
@@ -313,6 +329,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_pipe_kernel(
         stage_h(slot_D(ST_R2) + HIMG_BYTES, A7a, one, col, h);
       }
       D0 = pack8_masked(acc, 0, A7a); D1 = zero8();
+      u4v Mn0 = relu_mask(A6a), Mn1 = relu_mask(A6b);   // masks of the next step, ahead of the barrier
       // (the weight fragments of the next step are fetched before each barrier: its fence would otherwise pin
       //  their LDS reads behind it, in front of the MFMA that needs them)
       PSYNC();
@@ -321,7 +338,8 @@ __global__ __launch_bounds__(256, 1) void field_bwd_pipe_kernel(
       Wn0 = lds_frag(bwf, KT_T1 + 0, lane); Wn1 = lds_frag(bwf, KT_T1 + 1, lane);
       stage_h(slot_D(ST_R0), D0, D1, col, h);
       stage_h(slot_D(ST_R0) + HIMG_BYTES, A6a, A6b, col, h);
-      D0 = pack8_masked(acc, 0, A6a); D1 = pack8_masked(acc, 1, A6b);
+      D0 = pack8_and(acc, 0, Mn0); D1 = pack8_and(acc, 1, Mn1);
+      Mn0 = relu_mask(A5a); Mn1 = relu_mask(A5b);
       PSYNC();
       // ---- step ST_T1 ------------------------------------------------------------------------------
       acc = MFMA(Wn0, D0, zero16());
@@ -329,7 +347,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_pipe_kernel(
       Wn0 = lds_frag(bwf, KT_VD_Y + 0, lane); Wn1 = lds_frag(bwf, KT_VD_Y + 1, lane);
       stage_h(slot_D(ST_T1), D0, D1, col, h);
       stage_h(slot_D(ST_T1) + HIMG_BYTES, A5a, A5b, col, h);
-      D0 = pack8_masked(acc, 0, A5a); D1 = pack8_masked(acc, 1, A5b);
+      D0 = pack8_and(acc, 0, Mn0); D1 = pack8_and(acc, 1, Mn1);
       PSYNC();
       // ---- step ST_VD : inputs [y4 | e2] -----------------------------------------------------------
       acc = MFMA(Wn0, D0, zero16());
@@ -350,6 +368,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_pipe_kernel(
         for (int i = 0; i < 16; ++i) acc[i] = fmaf(wsg[i], draw, acc[i]);
       }
       D0 = pack8(acc, 0, false); D1 = pack8(acc, 1, false);
+      Mn0 = relu_mask(A3a); Mn1 = relu_mask(A3b);
       PSYNC();
       // ---- step ST_ES (no activation) --------------------------------------------------------------
       acc = MFMA(Wn0, D0, zero16());
@@ -357,18 +376,24 @@ __global__ __launch_bounds__(256, 1) void field_bwd_pipe_kernel(
       Wn0 = lds_frag(bwf, KT_S2 + 0, lane); Wn1 = lds_frag(bwf, KT_S2 + 1, lane);
       stage_h(slot_D(ST_ES), D0, D1, col, h);
       stage_h(slot_D(ST_ES) + HIMG_BYTES, A3a, A3b, col, h);
-      D0 = pack8_masked(acc, 0, A3a); D1 = pack8_masked(acc, 1, A3b);
+      D0 = pack8_and(acc, 0, Mn0); D1 = pack8_and(acc, 1, Mn1);
       pe_backward(de2, 2, 4, 22);  // bands 4 and 5 -> dB
+      {
+        h8 a, b;
+        load_h(A2img, a, b, col, h);
+        Mn0 = relu_mask(a); Mn1 = relu_mask(b);
+      }
       PSYNC();
       // ---- step ST_S2 : input a2 (parked) ------------------------------------------------------------
       acc = MFMA(Wn0, D0, zero16());
       acc = MFMA(Wn1, D1, acc);  // d a2
       Wn0 = lds_frag(bwf, KT_CAT_Y + 0, lane); Wn1 = lds_frag(bwf, KT_CAT_Y + 1, lane);
+      stage_h(slot_D(ST_S2), D0, D1, col, h);
+      D0 = pack8_and(acc, 0, Mn0); D1 = pack8_and(acc, 1, Mn1);
       {
         h8 a, b;
-        load_h(A2img, a, b, col, h);
-        stage_h(slot_D(ST_S2), D0, D1, col, h);
-        D0 = pack8_masked(acc, 0, a); D1 = pack8_masked(acc, 1, b);
+        load_h(A1img, a, b, col, h);
+        Mn0 = relu_mask(a); Mn1 = relu_mask(b);
       }
       PSYNC();
       // ---- step ST_CAT : inputs [a1 | e1] (both parked) ----------------------------------------------
@@ -376,11 +401,12 @@ __global__ __launch_bounds__(256, 1) void field_bwd_pipe_kernel(
       acc = MFMA(Wn1, D1, acc);  // d a1
       Wn0 = lds_frag(bwf, KT_S1 + 0, lane); Wn1 = lds_frag(bwf, KT_S1 + 1, lane);
       const h8 Dc0 = D0, Dc1 = D1;  // its d e1 part is formed together with encoding_xyz's
+      stage_h(slot_D(ST_CAT), D0, D1, col, h);
+      D0 = pack8_and(acc, 0, Mn0); D1 = pack8_and(acc, 1, Mn1);
       {
         h8 a, b;
-        load_h(A1img, a, b, col, h);
-        stage_h(slot_D(ST_CAT), D0, D1, col, h);
-        D0 = pack8_masked(acc, 0, a); D1 = pack8_masked(acc, 1, b);
+        load_h(A0img, a, b, col, h);
+        Mn0 = relu_mask(a); Mn1 = relu_mask(b);
       }
       PSYNC();
       // ---- step ST_S1 : input a0 (parked) --------------------------------------------------------------
@@ -392,12 +418,8 @@ __global__ __launch_bounds__(256, 1) void field_bwd_pipe_kernel(
         de[b] = MFMA(lds_frag(bwf, KT_CAT_E + 2 * b + 0, lane), Dc0, zero16());
         de[b] = MFMA(lds_frag(bwf, KT_CAT_E + 2 * b + 1, lane), Dc1, de[b]);
       }
-      {
-        h8 a, b;
-        load_h(A0img, a, b, col, h);
-        stage_h(slot_D(ST_S1), D0, D1, col, h);
-        D0 = pack8_masked(acc, 0, a); D1 = pack8_masked(acc, 1, b);
-      }
+      stage_h(slot_D(ST_S1), D0, D1, col, h);
+      D0 = pack8_and(acc, 0, Mn0); D1 = pack8_and(acc, 1, Mn1);
       load_inputs(clamp_tile(tile + tile_step));  // next tile's sample: in flight across the next two steps
       PSYNC();
       // ---- step ST_XYZ : input e1 (parked) ------------------------------------------------------------------
