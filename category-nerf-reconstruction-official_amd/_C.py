@@ -49,6 +49,8 @@ SIGNATURES = {
                           _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "cnr_adamw_epilogue": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64,
                            _vp, _vp, _i, _i, _vp],
+    "cnr_step_tail": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _vp, _vp, _f, _i, _f, _f, _f,
+                      _f, _f, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i, _vp],
     "cnr_param_prep": [_vp, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp],
     "cnr_render_loss_workspace_bytes": [_i, _i],
     "cnr_render_loss": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp,

@@ -65,4 +65,103 @@ __device__ __forceinline__ void latent_fwd_block(const float* __restrict__ th, c
     }
   }
 }
+
+// Backward of the latent path for one class (th = its parameter row, z / dbr = its (n_obj,4,32) post-ReLU activations
+// and bias-row gradients).  Every block recomputes the small d pre table (n_obj x 128 values) and the code norms into
+// `sm` (n_obj * 128 + 2 n_obj floats of LDS), then takes its grid-stride share of the concatenated output space
+//   [ d Wt_k[:, :32] and d bt_k : 4*32*33 | d Wl : 4*32*L | d bl : 128 | d shape codes : n_obj*L | d tex codes : n_obj*L ]
+// and hands each value to the sink: trunk_add(index in the class row, v) for the first group (skipped when
+// with_trunk is false), latent_set(index, v) for the rest.  reg_scale * code / ||code|| (src/loss.py:5-15) is
+// included in the code gradients.
+template <class Sink>
+__device__ __forceinline__ void latent_bwd_block(const float* __restrict__ th, const FlatLayout& lay,
+                                                 const float* __restrict__ z, const float* __restrict__ dbr,
+                                                 float reg_scale, float* sm, const Sink& sink, int blk, int nblk,
+                                                 bool with_trunk) {
+  const int n_obj = lay.n_obj, L = lay.L;
+  float* dpre = sm;
+  float* inv_s = sm + n_obj * 128;
+  float* inv_t = inv_s + n_obj;
+  for (int i = threadIdx.x; i < n_obj * 128; i += 256) {   // d z -> d pre
+    const int ob = i >> 7, k = (i >> 5) & 3, j = i & 31;
+    int w_off, b_off, ld;
+    latent_target(k, w_off, b_off, ld);
+    float s = 0.0f;
+#pragma unroll
+    for (int o = 0; o < 32; ++o) s = fmaf(dbr[(ob * 4 + k) * 32 + o], th[w_off + o * ld + j], s);
+    dpre[i] = z[i] > 0.0f ? s : 0.0f;
+  }
+  {  // code norms for the regulariser: one wave per code row
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int t = wv; t < 2 * n_obj; t += 4) {
+      const int ob = t % n_obj;
+      const float* code = th + (t < n_obj ? lay.shape : lay.tex) + (int64_t)ob * L;
+      float s = 0.0f;
+      for (int l = lane; l < L; l += 64) s = fmaf(code[l], code[l], s);
+      s = wave_sum(s);
+      if (lane == 0) (t < n_obj ? inv_s : inv_t)[ob] = reg_scale / sqrtf(s);
+    }
+  }
+  __syncthreads();
+  const int n0 = 4 * 32 * 33, n1 = n0 + 4 * 32 * L, n2 = n1 + 128, n3 = n2 + n_obj * L, n4 = n3 + n_obj * L;
+  for (int t = (with_trunk ? 0 : n0) + blk * 256 + threadIdx.x; t < n4; t += nblk * 256) {
+    if (t < n0) {  // added: the field backward wrote the a-part of these weights already
+      const int k = t / (32 * 33), r = t % (32 * 33), o = r / 33, j = r % 33;
+      int w_off, b_off, ld;
+      latent_target(k, w_off, b_off, ld);
+      float s = 0.0f;
+      for (int ob = 0; ob < n_obj; ++ob) {
+        const float d = dbr[(ob * 4 + k) * 32 + o];
+        s += j < 32 ? d * z[(ob * 4 + k) * 32 + j] : d;
+      }
+      sink.trunk_add(j < 32 ? w_off + o * ld + j : b_off + o, s);
+    } else if (t < n1) {
+      const int i = t - n0, k = i / (32 * L), r = i % (32 * L), o = r / L, l = r % L;
+      float s = 0.0f;
+      for (int ob = 0; ob < n_obj; ++ob)
+        s = fmaf(dpre[(ob * 4 + k) * 32 + o], th[(k == 3 ? lay.tex : lay.shape) + (int64_t)ob * L + l], s);
+      sink.latent_set(lay.latW + i, s);
+    } else if (t < n2) {
+      const int i = t - n1;
+      float s = 0.0f;
+      for (int ob = 0; ob < n_obj; ++ob) s += dpre[ob * 128 + i];
+      sink.latent_set(lay.latb + i, s);
+    } else if (t < n3) {
+      const int i = t - n2, ob = i / L, l = i % L;
+      float s = 0.0f;
+      for (int ko = 0; ko < 96; ++ko) s = fmaf(dpre[ob * 128 + ko], th[lay.latW + (int64_t)ko * L + l], s);
+      sink.latent_set(lay.shape + i, s + inv_s[ob] * th[lay.shape + i]);
+    } else {
+      const int i = t - n3, ob = i / L, l = i % L;
+      float s = 0.0f;
+      for (int o = 0; o < 32; ++o) s = fmaf(dpre[ob * 128 + 96 + o], th[lay.latW + (int64_t)(96 + o) * L + l], s);
+      sink.latent_set(lay.tex + i, s + inv_t[ob] * th[lay.tex + i]);
+    }
+  }
+}
+// the trunk-entry term of that first group for ONE trunk index q of a class row (0 when q is not a latent-target
+// weight / bias): what latent_bwd_block would have added there.  For consumers that finish the trunk gradient
+// themselves (tail.hip).
+__device__ __forceinline__ float latent_trunk_term(int q, const float* __restrict__ z, const float* __restrict__ dbr,
+                                                   int n_obj) {
+  int k, o, j;
+  if (q >= OFF_S1_W && q < OFF_S1_W + 1024) { k = 0; o = (q - OFF_S1_W) >> 5; j = (q - OFF_S1_W) & 31; }
+  else if (q >= OFF_S1_B && q < OFF_S1_B + 32) { k = 0; o = q - OFF_S1_B; j = 32; }
+  else if (q >= OFF_CAT_W && q < OFF_CAT_W + 32 * (32 + E1)) {
+    k = 1; o = (q - OFF_CAT_W) / (32 + E1); j = (q - OFF_CAT_W) % (32 + E1);
+    if (j >= 32) return 0.0f;
+  }
+  else if (q >= OFF_CAT_B && q < OFF_CAT_B + 32) { k = 1; o = q - OFF_CAT_B; j = 32; }
+  else if (q >= OFF_S2_W && q < OFF_S2_W + 1024) { k = 2; o = (q - OFF_S2_W) >> 5; j = (q - OFF_S2_W) & 31; }
+  else if (q >= OFF_S2_B && q < OFF_S2_B + 32) { k = 2; o = q - OFF_S2_B; j = 32; }
+  else if (q >= OFF_T1_W && q < OFF_T1_W + 1024) { k = 3; o = (q - OFF_T1_W) >> 5; j = (q - OFF_T1_W) & 31; }
+  else if (q >= OFF_T1_B && q < OFF_T1_B + 32) { k = 3; o = q - OFF_T1_B; j = 32; }
+  else return 0.0f;
+  float s = 0.0f;
+  for (int ob = 0; ob < n_obj; ++ob) {
+    const float d = dbr[(ob * 4 + k) * 32 + o];
+    s += j < 32 ? d * z[(ob * 4 + k) * 32 + j] : d;
+  }
+  return s;
+}
 }  // namespace cnr

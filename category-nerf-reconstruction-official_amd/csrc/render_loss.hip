@@ -15,6 +15,7 @@
 // are bit-identical to cnr_composite_fwd -> cnr_loss_fwd_bwd -> cnr_composite_bwd, the loss values agree to
 // summation order.  Block = 16 waves, one ray per wave at a time.
 #include "adamw_common.h"
+#include "render_common.h"
 
 // no fused multiply-add contraction in this file: composite.hip and render_loss.hip evaluate the same expressions and
 // must round them the same way whatever the surrounding code looks like (the one-launch form is tested bitwise
@@ -22,16 +23,7 @@
 #pragma clang fp contract(off)
 
 namespace {
-constexpr int RL_WAVES = 16, RL_THREADS = RL_WAVES * 64, RL_MAX_CHUNKS = 8;
-// rays per block = 16 waves x rays per wave: one ray per wave (all rays in flight at once) until the grid is
-// several blocks per CU, then more rays per wave so that the per-block mask count (2 bytes x C x R) stays small
-__host__ __device__ inline int rl_rays_per_block(int C, int R) {
-  int rpw = (int)(((int64_t)C * R + 8191) / 8192);
-  if (rpw < 1) rpw = 1;
-  if (rpw > 8) rpw = 8;
-  return RL_WAVES * rpw;
-}
-
+using namespace cnr_rl;
 __device__ __forceinline__ float incl_prod(float v, int lane) {
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
@@ -249,22 +241,6 @@ __global__ __launch_bounds__(RL_THREADS) void render_loss_kernel(
   }
 }
 
-// one wave per class: partials in a fixed order, flags
-__device__ __forceinline__ void finish_class(const float* __restrict__ partials, int nb, float* __restrict__ losses,
-                                             int32_t* __restrict__ flags, int C, int c, int lane) {
-  const float* hdr = partials + (size_t)C * nb * 3 + (size_t)c * 4;
-  const float wd = hdr[0], wc = hdr[1], wo = hdr[2];
-  float sd = 0.f, sc = 0.f, so = 0.f;
-  const float* pp = partials + (size_t)c * nb * 3;
-  for (int b = lane; b < nb; b += 64) { sd += pp[b * 3 + 0]; sc += pp[b * 3 + 1]; so += pp[b * 3 + 2]; }
-  sd = cnr::wave_sum(sd) * wd; sc = cnr::wave_sum(sc) * wc; so = cnr::wave_sum(so) * wo;
-  if (lane == 0) {
-    losses[0 * C + c] = sd; losses[1 * C + c] = sc; losses[2 * C + c] = so;
-    int32_t fl = (int32_t)hdr[3];
-    if (sd > 100000.f || sc > 100000.f || so > 100000.f) fl |= 1;
-    flags[c] = fl;
-  }
-}
 __global__ __launch_bounds__(64) void render_loss_finish_kernel(const float* __restrict__ partials, int nb,
                                                                 float* __restrict__ losses, int32_t* __restrict__ flags,
                                                                 int C) {

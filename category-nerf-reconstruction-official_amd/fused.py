@@ -84,7 +84,11 @@ class FusedCategoryTrainer:
         self.lr, self.wd = cfg.learning_rate, cfg.weight_decay
         assert cfg.code_learning_rate == cfg.learning_rate and cfg.code_weight_decay == cfg.weight_decay, \
             "one flat AdamW group: the shipped configs use identical lr / weight decay for codes and networks"
-        self.theta, self.lay = init_params(n_cls, self.L, n_obj, generator, self.device)
+        theta0, self.lay = init_params(n_cls, self.L, n_obj, generator, self.device)
+        # parameters in two copies, like the step state: step k reads copy k & 1, its last launch (AdamW, out of place)
+        # writes copy (k + 1) & 1 -- gradient kernels and the optimiser never touch the same copy in one launch
+        self.theta2 = torch.stack([theta0, theta0.clone()])
+        self.parity = 0
         # gradient of the flat parameters and of the per-object bias rows in ONE allocation: one fill per step
         self._gbuf = torch.zeros(self.theta.numel() + n_cls * n_obj * 128, device=self.device)
         self.grad = self._gbuf[:self.theta.numel()].view_as(self.theta)
@@ -100,7 +104,6 @@ class FusedCategoryTrainer:
         # device-side step state {pool cursor, rng step, optimiser step}, two copies: step k reads copy k & 1 and its
         # last kernel writes copy (k + 1) & 1 -- no kernel ever writes a state another kernel of the same step reads
         self.d_state2 = torch.zeros(2, 3, device=self.device, dtype=torch.int64)
-        self.parity = 0
         # epoch shuffle as an index permutation (C, pool_rows): the pool itself never moves
         self.perm = torch.empty(n_cls, self.pool_rows, device=self.device, dtype=torch.int32)
         self._zero64 = torch.zeros(1, device=self.device, dtype=torch.int64)
@@ -120,6 +123,11 @@ class FusedCategoryTrainer:
         self._reshuffle()
 
     # ---- one step, eager (also the body that gets captured) ------------------------------------------
+    @property
+    def theta(self):
+        """the current parameters (C, P): what the NEXT step will read"""
+        return self.theta2[self.parity]
+
     @property
     def d_state(self):
         """the state the NEXT step will read (int64[3] view)"""
@@ -181,17 +189,21 @@ class FusedCategoryTrainer:
         ops.field_bwd(b["pts"], Bc, packed, brows, ray_row, self.scale, o["dsig"], o["drgb"], self.grad_scale,
                       g_trunk, g_B, self.dbias, C, R, S, n_obj, self.bwd_blocks, o["bwd_ws"],
                       B_stride=P, dtrunk_stride=P, dB_stride=P)
-        # latent backward + code regulariser: one kernel over the flat rows
-        reg = 0.0005 * inv_w                     # loss.py:5-15, train.py:165-167
-        _C.call("cnr_latent_bwd", self.theta, *lat_args, zl, self.dbias, reg, self.grad)
+        self._reg = 0.0005 * inv_w               # code regulariser scale: loss.py:5-15, train.py:165-167
+        if self.pg is not None:                  # data parallel: the all-reduce needs the complete gradient first
+            _C.call("cnr_latent_bwd", self.theta, *lat_args, zl, self.dbias, self._reg, self.grad)
 
     def _step_back(self):
-        """Last launch: AdamW on the flat buffer beside the epilogue (loss values + flags from the render kernel's
-        partials, the next slice's max depth, next step state into the other state copy)."""
-        C, R, o, par = self.C, self.R, self.bufs, self.parity
-        _C.call("cnr_adamw_epilogue", self.theta, self.grad, self.exp_avg, self.exp_avg_sq, self.theta.numel(),
-                self.lr, 0.9, 0.999, 1e-8, self.wd, 1.0, self.d_state2[par], self.d_state2[1 - par], R, o["rl_ws"],
-                self.losses, self.flags, self.pool["depth"], self.pool_rows, self.perm, self.max_bound, C, R)
+        """Last launch (cnr_step_tail): latent backward + code regulariser (single GPU; with a process group it ran
+        before the all-reduce), AdamW out of place into the other parameter copy, and the epilogue (loss values +
+        flags from the render kernel's partials, the next slice's max depth, next step state into the other state
+        copy) -- side by side in one grid."""
+        C, R, o, par, lay = self.C, self.R, self.bufs, self.parity, self.lay
+        _C.call("cnr_step_tail", self.theta2[par], self.theta2[1 - par], self.grad, self.exp_avg, self.exp_avg_sq,
+                lay.total, lay.B[0], lay.latW[0], lay.latb[0], lay.shape[0], lay.tex[0], self.L, self.n_obj, C,
+                o["zl"], self.dbias, self._reg, 0 if self.pg is not None else 1, self.lr, 0.9, 0.999, 1e-8, self.wd,
+                self.d_state2[par], self.d_state2[1 - par], R, o["rl_ws"], self.losses, self.flags,
+                self.pool["depth"], self.pool_rows, self.perm, self.max_bound, R)
 
     def step(self):
         """One train step.  Returns nothing; ``self.losses`` (3,C) / ``self.flags`` (C,) hold the device-side

@@ -277,6 +277,23 @@ int cnr_adamw_epilogue(float* param, const float* grad, float* exp_avg, float* e
                        float* losses, int32_t* flags, const float* depth, int64_t pool_rows, const int* perm,
                        float* next_max_bound, int C, int R, void* stream);
 
+/* The tail of the fused trainer's step in ONE launch: cnr_latent_bwd (do_latent != 0), AdamW on the flat parameter
+ * buffer and cnr_step_epilogue, for PING-PONG parameters and step state: every kernel of step k reads theta_in /
+ * state_cur, this launch writes theta_out / state_next (AdamW out of place), the caller swaps them for step k + 1.
+ * With nothing written that anything in the launch reads, the three jobs run side by side; a latent-path gradient
+ * element is applied by the thread that produces it, and the trunk entries the latent path adds to are finished by
+ * the AdamW blocks.  do_latent = 0: grad already holds the complete gradient (cnr_latent_bwd ran, e.g. before a
+ * multi-GPU all-reduce) and only AdamW + epilogue run.  grad is updated to the complete gradient either way.
+ * Layout arguments as cnr_latent_bwd (trunk at offset 0 of a class row, B at off_B); rl_workspace etc. as
+ * cnr_step_epilogue. */
+int cnr_step_tail(const float* theta_in, float* theta_out, float* grad, float* exp_avg, float* exp_avg_sq,
+                  int64_t class_stride, int64_t off_B, int64_t off_latW, int64_t off_latb, int64_t off_shape,
+                  int64_t off_tex, int L, int n_obj, int C, const float* zl, const float* dbiasrows, float reg_scale,
+                  int do_latent, float lr, float beta1, float beta2, float eps, float weight_decay,
+                  const int64_t* state_cur, int64_t* state_next, int64_t add_rows, const void* rl_workspace,
+                  float* losses, int32_t* flags, const float* depth, int64_t pool_rows, const int* perm,
+                  float* next_max_bound, int R, void* stream);
+
 /* Same contract and results as cnr_field_bwd, ONE field kernel + the record reduction: each workgroup is
  * `chain_waves` (2 or 3) waves that run forward recompute + data-gradient chain + PE backward for one 32-sample
  * tile each, plus 4 - chain_waves waves that own the weight-gradient accumulators and consume the chain waves'
