@@ -38,8 +38,9 @@ SIGNATURES = {
     "cnr_field_fwd": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i64, _vp],
     "cnr_field_bwd": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i64, _i64, _i64,
                       _i64, _vp],
-    "cnr_field_bwd_pipe": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i64, _i64, _i64, _i64, _vp],
+    "cnr_field_bwd_pipe": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i64, _i64, _i64, _i64, _vp, _i, _vp],
     "cnr_field_bwd_workspace_bytes": [_i, _i],
+    "cnr_field_bwd_pipe_blocks": [_i, _i, _i, _i],
     "cnr_gather_pool": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "cnr_dense_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "cnr_dense_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i64, _vp],
@@ -50,7 +51,7 @@ SIGNATURES = {
     "cnr_adamw_epilogue": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64,
                            _vp, _vp, _i, _i, _vp],
     "cnr_step_tail": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _vp, _vp, _f, _i, _f, _f, _f,
-                      _f, _f, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i, _vp],
+                      _f, _f, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i, _vp, _i, _vp, _vp],
     "cnr_param_prep": [_vp, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp],
     "cnr_render_loss_workspace_bytes": [_i, _i],
     "cnr_render_loss": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp,

@@ -3,6 +3,7 @@
 // per-workgroup record format and its fixed-order reduction.
 #pragma once
 #include "fused_common.h"
+#include "records_common.h"
 
 namespace {   // internal linkage: each backward translation unit gets its own copy (incl. the device table)
 using namespace fz;
@@ -17,7 +18,7 @@ constexpr int ST_E2 = 112;  // [32][half0: 24 | half1: 24] = 96 B + 16 B pad
 constexpr int E1IMG_BYTES = 32 * ST_E1 + 128;
 constexpr int E2IMG_BYTES = 32 * ST_E2 + 128;
 constexpr int HIMG_BYTES = 32 * ST_H + 64;
-constexpr int ROWS_LDS = 4;  // rows_per_class <= 4: dbiasrows accumulate in wave-private LDS
+using cnr_rec::ROWS_LDS;
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -105,7 +106,8 @@ __device__ __forceinline__ int block_index(int kind, int o, int c) {
   }
 }
 
-constexpr int REC_FLOATS = ((TRUNK + 126 + ROWS_LDS * 128 + 255) / 256) * 256;  // one workgroup's record
+using cnr_rec::REC_FLOATS;
+using cnr_rec::rec_entry_written;
 
 // sum over the 32 lanes of each wave half with DPP row operations (6 VALU ops; __shfl_xor lowers to
 // ds_bpermute, ~80 dependent cycles each): afterwards lane 31 holds the sum of lanes 0..31, lane 63 of 32..63
@@ -140,13 +142,6 @@ __global__ void fill_param_src_kernel() {
 // 4 quarters of the workgroup range; each quarter keeps 8 loads in flight, the quarters are combined through LDS in
 // a fixed order.  Entries no launch writes (latent-layer biases, padding, unused row sums) are skipped, so the
 // workspace needs no clearing.
-__device__ __forceinline__ bool rec_entry_written(int i, int rows_per_class) {
-  if (i < TRUNK)
-    return !((i >= OFF_S1_B && i < OFF_S1_B + 32) || (i >= OFF_CAT_B && i < OFF_CAT_B + 32) ||
-             (i >= OFF_S2_B && i < OFF_S2_B + 32) || (i >= OFF_T1_B && i < OFF_T1_B + 32));
-  if (i < TRUNK + 126) return true;
-  return rows_per_class <= ROWS_LDS && (i - (TRUNK + 126)) < rows_per_class * 128;
-}
 __global__ __launch_bounds__(256) void reduce_records_kernel(const float* __restrict__ records, int nwg,
                                                              float* __restrict__ dtrunk, float* __restrict__ dB,
                                                              float* __restrict__ dbiasrows, int rows_per_class,
@@ -160,16 +155,7 @@ __global__ __launch_bounds__(256) void reduce_records_kernel(const float* __rest
   if (live) {
     const int per = (nwg + 3) / 4, w0 = q * per, w1 = min(nwg, w0 + per);
     const float* r = records + (size_t)c * nwg * REC_FLOATS + i;
-    float a[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) a[u] = 0.0f;
-    int w = w0;
-    for (; w + 7 < w1; w += 8) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) a[u] += r[(size_t)(w + u) * REC_FLOATS];
-    }
-    for (; w < w1; ++w) a[0] += r[(size_t)w * REC_FLOATS];
-    s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    s = cnr_rec::record_range_sum(r, w0, w1);
   }
   part[q][e] = s;
   __syncthreads();
@@ -177,7 +163,7 @@ __global__ __launch_bounds__(256) void reduce_records_kernel(const float* __rest
     const float v = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
     if (i < TRUNK) dtrunk[(size_t)c * st_trunk + i] += v;
     else if (i < TRUNK + 63) atomicAdd(&dB[(size_t)c * st_B + (i - TRUNK)], v);        // two addends per element
-    else if (i < TRUNK + 126) atomicAdd(&dB[(size_t)c * 63 + (i - TRUNK - 63)], v);
+    else if (i < TRUNK + 126) atomicAdd(&dB[(size_t)c * st_B + (i - TRUNK - 63)], v);
     else dbiasrows[(size_t)c * rows_per_class * 128 + (i - (TRUNK + 126))] += v;
   }
 }

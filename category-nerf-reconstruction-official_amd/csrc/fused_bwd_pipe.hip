@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_pipe_kernel(
     const float* __restrict__ biasrows, const int* __restrict__ ray_row, float inv_scale,
     const float* __restrict__ d_sigma, const float* __restrict__ d_rgb, float gscale,
     float* __restrict__ records, float* __restrict__ dbiasrows, int N, int S, int R, int rows_per_class,
-    int64_t B_stride) {
+    int64_t B_stride, long long* __restrict__ rows_fix) {
   constexpr int NDW = 4 - NCH;
   constexpr int NW = NBLOCKS / NDW;  // accumulator blocks per dW wave
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -616,8 +616,16 @@ __global__ __launch_bounds__(256, 1) void field_bwd_pipe_kernel(
     const float* rs = region + RS_REGION * 1024;  // [m][feature]
     for (int i = threadIdx.x; i < 32; i += 256) rec[OFF_ES_B + i] = rs[16 * 32 + i] * inv_gs;
     for (int i = threadIdx.x; i < 16; i += 256) rec[OFF_R0_B + i] = rs[17 * 32 + i] * inv_gs;
-    for (int i = threadIdx.x; i < rows_per_class * 128; i += 256)   // dbiasrows [row][latent slot][feature]
-      rec[TRUNK + 126 + i] = rs[(((i >> 5) & 3) * 4 + (i >> 7)) * 32 + (i & 31)] * inv_gs;
+    for (int i = threadIdx.x; i < rows_per_class * 128; i += 256) {  // dbiasrows [row][latent slot][feature]
+      const float v = rs[(((i >> 5) & 3) * 4 + (i >> 7)) * 32 + (i & 31)] * inv_gs;
+      rec[TRUNK + 126 + i] = v;
+      // the same sums as 2^-40 fixed point: integer atomics add in any order to the same result, so the consumer
+      // (cnr_step_tail) has them without waiting for the record reduction
+      if (rows_fix)
+        atomicAdd(reinterpret_cast<unsigned long long*>(
+                      rows_fix + ((size_t)(blockIdx.x % cnr_rec::ROWS_FIX_COPIES) * gridDim.y + c) * rows_per_class * 128 + i),
+                  (unsigned long long)__double2ll_rn((double)v * cnr_rec::ROWS_FIX_SCALE));
+    }
   }
 }
 }  // namespace
@@ -628,22 +636,33 @@ extern "C" int cnr_pipe_read_stamps(long long* host) {
 }
 #endif
 
+// workgroups (= records) per class of a cnr_field_bwd_pipe launch: what a caller that reduces the records itself needs
+extern "C" int cnr_field_bwd_pipe_blocks(int R, int S, int chain_waves, int max_blocks) {
+  if (R <= 0 || S <= 0 || (chain_waves != 2 && chain_waves != 3)) return 0;
+  const int64_t ntiles = ((int64_t)R * S + 31) / 32;
+  int64_t blocks = (ntiles + chain_waves - 1) / chain_waves;
+  const int64_t cap = max_blocks > 0 ? max_blocks : 256;
+  return (int)(blocks > cap ? cap : blocks);
+}
+
 extern "C" int cnr_field_bwd_pipe(const float* pts, const float* B, const void* packed, const float* biasrows,
                                   const int* ray_row, float scale, const float* d_sigma, const float* d_rgb,
                                   float grad_scale, float* dtrunk, float* dB, float* dbiasrows, int C, int R, int S,
                                   int rows_per_class, int max_blocks, int chain_waves, void* workspace,
                                   int64_t workspace_bytes, int64_t B_stride, int64_t dtrunk_stride, int64_t dB_stride,
-                                  void* stream) {
+                                  long long* rows_fix, int skip_reduce, void* stream) {
   if (!pts || !B || !packed || !biasrows || !d_sigma || !d_rgb || !dtrunk || !dB || !dbiasrows || !workspace)
     return CNR_E_ARG;
   if (C <= 0 || R <= 0 || S <= 0 || !(scale > 0.f) || !(grad_scale > 0.f)) return CNR_E_ARG;
   if (chain_waves != 2 && chain_waves != 3) return CNR_E_ARG;
   // the pipeline keeps per-object row sums in one accumulator block: class-major rows, at most ROWS_LDS per class.
   // Everything else (one row per ray, many objects) takes the block-split kernels.
-  if (ray_row == nullptr || rows_per_class < 1 || rows_per_class > ROWS_LDS)
+  if (ray_row == nullptr || rows_per_class < 1 || rows_per_class > ROWS_LDS) {
+    if (rows_fix || skip_reduce) return CNR_E_ARG;   // those two need the pipelined kernel's per-object rows
     return cnr_field_bwd(pts, B, packed, biasrows, ray_row, scale, d_sigma, d_rgb, grad_scale, dtrunk, dB, dbiasrows, C,
                          R, S, rows_per_class, max_blocks, workspace, workspace_bytes, B_stride, dtrunk_stride, dB_stride,
                          stream);
+  }
   if (S > 240) return CNR_E_SHAPE;
   if (((uintptr_t)packed & 15) != 0 || ((uintptr_t)biasrows & 15) != 0 || ((uintptr_t)workspace & 15) != 0)
     return CNR_E_ALIGN;
@@ -674,10 +693,11 @@ extern "C" int cnr_field_bwd_pipe(const float* pts, const float* B, const void* 
   hipLaunchKernelGGL((field_bwd_pipe_kernel<NCH>), grid, dim3(256), p_lds_total<NCH>(), (hipStream_t)stream,  \
                      pts, B, (const unsigned char*)packed, biasrows, ray_row, 1.0f / scale, d_sigma, d_rgb,   \
                      grad_scale, (float*)workspace, dbiasrows, (int)N, S, R, rows_per_class,                    \
-                     B_stride > 0 ? B_stride : (int64_t)63)
+                     B_stride > 0 ? B_stride : (int64_t)63, rows_fix)
   if (chain_waves == 3) CNR_LAUNCH_PIPE(3); else CNR_LAUNCH_PIPE(2);
 #undef CNR_LAUNCH_PIPE
   CNR_LAUNCH_CHECK();
+  if (skip_reduce) return CNR_OK;   // the caller reduces the records itself (cnr_step_tail)
   hipLaunchKernelGGL(reduce_records_kernel, dim3(REC_FLOATS / 64, (unsigned)C), dim3(256), 0, (hipStream_t)stream,
                      (const float*)workspace, (int)blocks, dtrunk, dB, dbiasrows, rows_per_class,
                      dtrunk_stride > 0 ? dtrunk_stride : (int64_t)TRUNK, dB_stride > 0 ? dB_stride : (int64_t)63);

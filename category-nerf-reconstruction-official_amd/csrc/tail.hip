@@ -8,11 +8,17 @@
 //     element); the trunk entries the latent path adds to are finished by the AdamW blocks themselves
 //     (latent_trunk_term: n_obj multiply-adds from dbiasrows and zl);
 //   * the epilogue blocks only read the render-loss partials, the depth pool and the CURRENT state.
-// grid: [ do_latent ? NL latent blocks per class : 0 ] [ NA AdamW blocks over the flat (C, P) buffer ] [ C epilogue ].
+//   * (records != NULL) the fixed-order reduction of the field backward's records moves in as well: a block sums 64
+//     record entries over all workgroups and applies AdamW to them at once; the latent path takes its input, the
+//     per-object bias-row sums, from a fixed-point table the field backward filled with integer atomics (order-free,
+//     hence still bitwise reproducible) instead of waiting for that reduction.
+// grid: [ do_latent ? NL latent blocks per class : 0 ] [ NA AdamW blocks over the flat (C, P) buffer, or with records
+//        NR = REC_FLOATS / 64 reduce-and-update blocks per class ] [ C epilogue ].
 // With do_latent = 0 (the gradient was completed by cnr_latent_bwd, e.g. before a multi-GPU all-reduce) the AdamW
 // blocks cover every parameter and nothing else changes.
 #include "adamw_common.h"
 #include "latent_common.h"
+#include "records_common.h"
 #include "render_common.h"
 
 namespace {
@@ -21,12 +27,15 @@ using namespace cnr;
 struct TailArgs {
   const float* theta_in; float* theta_out; float* grad; float* m; float* v;
   FlatLayout lay; int64_t off_B; int C;
-  const float* zl; const float* dbiasrows; float reg_scale;
+  const float* zl; float* dbiasrows; float reg_scale;
   float lr, b1, b2, eps, wd;
   const int64_t* state_cur; int64_t* state_next; int64_t add_rows;
   const float* partials; int nb; float* losses; int32_t* flags;
   const float* depth; int64_t pool_rows; const int* perm; int R; float* max_bound;
   int do_latent, NL, NA;
+  // optional: the field backward's per-workgroup records (nwg per class) are reduced HERE, and the per-object
+  // bias-row sums come from the fixed-point table the field backward accumulated with integer atomics
+  const float* records; int nwg; const long long* rows_fix; int NR;
 };
 
 __device__ __forceinline__ void adam_one(const TailArgs& a, int64_t e, float g, float step_size, float inv_bc2_sqrt) {
@@ -47,6 +56,18 @@ struct AdamSink {  // latent-path gradient element -> gradient buffer (kept for 
   }
 };
 
+// this class's (n_obj,4,32) bias-row gradient as floats in LDS, from the fixed-point table
+__device__ __forceinline__ void load_rows_fix(const TailArgs& a, int c, float* dst) {
+  const int n = a.lay.n_obj * 128;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    long long t = 0;
+#pragma unroll
+    for (int k = 0; k < cnr_rec::ROWS_FIX_COPIES; ++k) t += a.rows_fix[((size_t)k * a.C + c) * n + i];
+    dst[i] = (float)((double)t * (1.0 / cnr_rec::ROWS_FIX_SCALE));
+  }
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
   extern __shared__ float sm[];
   const int C = a.C, P = (int)a.lay.stride;
@@ -60,12 +81,56 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
   if (b < nlat) {  // ---- latent backward of class c + AdamW on what it produces
     const int c = b / a.NL, blk = b % a.NL;
     AdamSink sink{a, (int64_t)c * P, step_size, inv_bc2_sqrt};
-    latent_bwd_block(a.theta_in + (int64_t)c * P, a.lay, a.zl + (int64_t)c * a.lay.n_obj * 128,
-                     a.dbiasrows + (int64_t)c * a.lay.n_obj * 128, a.reg_scale, sm, sink, blk, a.NL, false);
+    const float* dbr = a.dbiasrows + (int64_t)c * a.lay.n_obj * 128;
+    float* scratch = sm;
+    if (a.rows_fix) {  // rows from the fixed-point table (block 0 of the class also publishes them as floats)
+      float* rows = sm;
+      load_rows_fix(a, c, rows);
+      if (blk == 0)
+        for (int i = threadIdx.x; i < a.lay.n_obj * 128; i += 256) a.dbiasrows[(int64_t)c * a.lay.n_obj * 128 + i] = rows[i];
+      dbr = rows;
+      scratch = sm + a.lay.n_obj * 128;
+    }
+    latent_bwd_block(a.theta_in + (int64_t)c * P, a.lay, a.zl + (int64_t)c * a.lay.n_obj * 128, dbr, a.reg_scale,
+                     scratch, sink, blk, a.NL, false);
     return;
   }
   b -= nlat;
-  if (b < a.NA) {  // ---- AdamW over the flat buffer; with do_latent only the trunk and B ranges (+ the latent-path term)
+  if (a.records) {  // ---- reduce 64 record entries of class c over all workgroups, finish the gradient, AdamW
+    if (b < a.NR * C) {
+      const int c = b / a.NR, blk = b % a.NR;
+      float* rows = sm;                    // [n_obj * 128] bias-row gradient of the class
+      float* part = sm + a.lay.n_obj * 128;  // [4][64] (+ [4][64] for the second dB addend)
+      // only blocks that hold a latent-conditioned layer's weights or biases need the rows (block-uniform test)
+      const int lo = blk * 64, hi = lo + 64;
+      auto hits = [&](int off, int len) { return lo < off + len && hi > off; };
+      if (hits(OFF_S1_W, 1056) || hits(OFF_CAT_W, 32 * (32 + E1) + 32) || hits(OFF_S2_W, 1056) || hits(OFF_T1_W, 1056))
+        load_rows_fix(a, c, rows);
+      const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+      const int i = blk * 64 + e;
+      // trunk entries and the first dB half own an output; the second dB half is the other addend of the first
+      const bool owner = i < TRUNK + 63;
+      float s0 = 0.0f, s1 = 0.0f;
+      if (owner) {
+        const int per = (a.nwg + 3) / 4, w0 = q * per, w1 = min(a.nwg, w0 + per);
+        const float* r = a.records + (size_t)c * a.nwg * cnr_rec::REC_FLOATS + i;
+        if (cnr_rec::rec_entry_written(i, a.lay.n_obj)) s0 = cnr_rec::record_range_sum(r, w0, w1);
+        if (i >= TRUNK) s1 = cnr_rec::record_range_sum(r + 63, w0, w1);
+      }
+      part[q * 64 + e] = s0; part[256 + q * 64 + e] = s1;
+      __syncthreads();
+      if (q == 0 && owner) {
+        float g = (part[e] + part[64 + e]) + (part[128 + e] + part[192 + e]);
+        if (i >= TRUNK) g += (part[256 + e] + part[320 + e]) + (part[384 + e] + part[448 + e]);
+        const int64_t idx = (int64_t)c * P + (i < TRUNK ? i : a.off_B + (i - TRUNK));
+        if (i < TRUNK) g += latent_trunk_term(i, a.zl + (int64_t)c * a.lay.n_obj * 128, rows, a.lay.n_obj);
+        a.grad[idx] = g;
+        adam_one(a, idx, g, step_size, inv_bc2_sqrt);
+      }
+      return;
+    }
+    b -= a.NR * C;
+  } else if (b < a.NA) {  // ---- AdamW over the flat buffer; with do_latent only the trunk and B ranges (+ the latent-path term)
     const int64_t n = (int64_t)C * P;
     for (int64_t e = (int64_t)b * 256 + threadIdx.x; e < n; e += (int64_t)a.NA * 256) {
       const int c = (int)(e / P), q = (int)(e - (int64_t)c * P);
@@ -82,8 +147,9 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
       adam_one(a, e, g, step_size, inv_bc2_sqrt);
     }
     return;
+  } else {
+    b -= a.NA;
   }
-  b -= a.NA;
   // ---- epilogue of class b: loss values + flags, next slice's max depth, next step state (class 0)
   const int c = b, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   float* red = sm;
@@ -107,16 +173,19 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
 
 extern "C" int cnr_step_tail(const float* theta_in, float* theta_out, float* grad, float* exp_avg, float* exp_avg_sq,
                              int64_t class_stride, int64_t off_B, int64_t off_latW, int64_t off_latb, int64_t off_shape,
-                             int64_t off_tex, int L, int n_obj, int C, const float* zl, const float* dbiasrows,
+                             int64_t off_tex, int L, int n_obj, int C, const float* zl, float* dbiasrows,
                              float reg_scale, int do_latent, float lr, float beta1, float beta2, float eps,
                              float weight_decay, const int64_t* state_cur, int64_t* state_next, int64_t add_rows,
                              const void* rl_workspace, float* losses, int32_t* flags, const float* depth,
-                             int64_t pool_rows, const int* perm, float* next_max_bound, int R, void* stream) {
+                             int64_t pool_rows, const int* perm, float* next_max_bound, int R, const void* records,
+                             int nwg, const long long* rows_fix, void* stream) {
   if (!theta_in || !theta_out || theta_in == theta_out || !grad || !exp_avg || !exp_avg_sq || class_stride <= 0 ||
       L <= 0 || n_obj <= 0 || C <= 0 || !state_cur || !state_next || state_cur == state_next || !rl_workspace ||
       !losses || !flags || R <= 0)
     return CNR_E_ARG;
   if (do_latent && (!zl || !dbiasrows)) return CNR_E_ARG;
+  if (records && (!do_latent || !rows_fix || nwg <= 0 || n_obj > cnr_rec::ROWS_LDS)) return CNR_E_ARG;
+  if (rows_fix && !do_latent) return CNR_E_ARG;
   if (n_obj > 64) return CNR_E_SHAPE;
   if (next_max_bound && (!depth || pool_rows < R)) return CNR_E_ARG;
   TailArgs a{};
@@ -136,8 +205,9 @@ extern "C" int cnr_step_tail(const float* theta_in, float* theta_out, float* gra
   int64_t na = (n + 255) / 256;
   if (na > 2048) na = 2048;
   a.NA = (int)na;
-  const unsigned grid = (unsigned)((a.do_latent ? a.NL * C : 0) + a.NA + C);
-  const size_t lds = (size_t)(n_obj * 128 + 2 * n_obj + 8) * sizeof(float);
+  a.records = (const float*)records; a.nwg = nwg; a.rows_fix = rows_fix; a.NR = cnr_rec::REC_FLOATS / 64;
+  const unsigned grid = (unsigned)((a.do_latent ? a.NL * C : 0) + (records ? a.NR * C : a.NA) + C);
+  const size_t lds = (size_t)(2 * n_obj * 128 + 2 * n_obj + 520) * sizeof(float);
   hipLaunchKernelGGL(tail_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
   CNR_LAUNCH_CHECK();
   return CNR_OK;

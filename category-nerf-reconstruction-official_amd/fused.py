@@ -90,7 +90,13 @@ class FusedCategoryTrainer:
         self.theta2 = torch.stack([theta0, theta0.clone()])
         self.parity = 0
         # gradient of the flat parameters and of the per-object bias rows in ONE allocation: one fill per step
-        self._gbuf = torch.zeros(self.theta.numel() + n_cls * n_obj * 128, device=self.device)
+        # ... plus (single GPU, <= 4 objects per class) the int64 fixed-point table of the per-object bias-row sums
+        # that the field backward fills with integer atomics for cnr_step_tail
+        n_th, n_db = self.theta.numel(), n_cls * n_obj * 128
+        self.fused_tail = process_group is None and n_obj <= 4 and ops.FIELD_BWD_VARIANT.startswith("pipe")
+        fix_off = (n_th + n_db + 3) // 4 * 4                      # 16-byte aligned
+        self._gbuf = torch.zeros(fix_off + (2 * 8 * n_db if self.fused_tail else 0), device=self.device)  # 8 copies
+        self.rows_fix = self._gbuf[fix_off:].view(torch.int64) if self.fused_tail else None
         self.grad = self._gbuf[:self.theta.numel()].view_as(self.theta)
         self.exp_avg = torch.zeros_like(self.theta)
         self.exp_avg_sq = torch.zeros_like(self.theta)
@@ -115,7 +121,9 @@ class FusedCategoryTrainer:
         self.bufs = {}
         self.losses = torch.zeros(3, n_cls, device=self.device)
         self.flags = torch.zeros(n_cls, device=self.device, dtype=torch.int32)
-        self.dbias = self._gbuf[self.theta.numel():].view(n_cls * n_obj, 4, 32)
+        self.dbias = self._gbuf[n_th:n_th + n_db].view(n_cls * n_obj, 4, 32)
+        self._nwg = int(_C.load().cnr_field_bwd_pipe_blocks(self.R, self.S, int(ops.FIELD_BWD_VARIANT[-1]), self.bwd_blocks)) \
+            if self.fused_tail else 0
         self.use_graph = use_graph
         self.split_graph = bool(split_graph)     # the two-graph form of the distributed step, for single-GPU tests
         self.graphs = {}                         # parity -> captured graph (or (front, back) pair)
@@ -188,14 +196,16 @@ class FusedCategoryTrainer:
         # fused backward: dtrunk, dB, dbiasrows straight into the flat gradient buffer views
         ops.field_bwd(b["pts"], Bc, packed, brows, ray_row, self.scale, o["dsig"], o["drgb"], self.grad_scale,
                       g_trunk, g_B, self.dbias, C, R, S, n_obj, self.bwd_blocks, o["bwd_ws"],
-                      B_stride=P, dtrunk_stride=P, dB_stride=P)
+                      B_stride=P, dtrunk_stride=P, dB_stride=P, rows_fix=self.rows_fix, skip_reduce=self.fused_tail)
         self._reg = 0.0005 * inv_w               # code regulariser scale: loss.py:5-15, train.py:165-167
         if self.pg is not None:                  # data parallel: the all-reduce needs the complete gradient first
             _C.call("cnr_latent_bwd", self.theta, *lat_args, zl, self.dbias, self._reg, self.grad)
 
     def _step_back(self):
-        """Last launch (cnr_step_tail): latent backward + code regulariser (single GPU; with a process group it ran
-        before the all-reduce), AdamW out of place into the other parameter copy, and the epilogue (loss values +
+        """Last launch (cnr_step_tail): the fixed-order reduction of the field backward's records (single GPU, <= 4
+        objects per class; otherwise cnr_field_bwd_pipe did it), latent backward + code regulariser (single GPU; with a
+        process group it ran before the all-reduce), AdamW out of place into the other parameter copy, and the
+        epilogue (loss values +
         flags from the render kernel's partials, the next slice's max depth, next step state into the other state
         copy) -- side by side in one grid."""
         C, R, o, par, lay = self.C, self.R, self.bufs, self.parity, self.lay
@@ -203,7 +213,8 @@ class FusedCategoryTrainer:
                 lay.total, lay.B[0], lay.latW[0], lay.latb[0], lay.shape[0], lay.tex[0], self.L, self.n_obj, C,
                 o["zl"], self.dbias, self._reg, 0 if self.pg is not None else 1, self.lr, 0.9, 0.999, 1e-8, self.wd,
                 self.d_state2[par], self.d_state2[1 - par], R, o["rl_ws"], self.losses, self.flags,
-                self.pool["depth"], self.pool_rows, self.perm, self.max_bound, R)
+                self.pool["depth"], self.pool_rows, self.perm, self.max_bound, R,
+                o["bwd_ws"] if self.fused_tail else None, self._nwg if self.fused_tail else 0, self.rows_fix)
 
     def step(self):
         """One train step.  Returns nothing; ``self.losses`` (3,C) / ``self.flags`` (C,) hold the device-side

@@ -365,7 +365,8 @@ FIELD_BWD_VARIANT = os.environ.get("CNR_FIELD_BWD", "pipe3")
 
 
 def field_bwd(pts, B, packed, biasrows, ray_row, scale, d_sig, d_rgb, grad_scale, dtrunk, dB, dbiasrows, C, R, S,
-              rows_per_class, max_blocks, workspace, variant=None, B_stride=0, dtrunk_stride=0, dB_stride=0):
+              rows_per_class, max_blocks, workspace, variant=None, B_stride=0, dtrunk_stride=0, dB_stride=0,
+              rows_fix=None, skip_reduce=False):
     """strides (floats, 0 = dense): B / dtrunk / dB may be views into a flat (C, P) buffer, see cnr_hip.h"""
     v = variant or FIELD_BWD_VARIANT
     if v == "split":
@@ -375,7 +376,7 @@ def field_bwd(pts, B, packed, biasrows, ray_row, scale, d_sig, d_rgb, grad_scale
     elif v in ("pipe2", "pipe3"):
         _C.call("cnr_field_bwd_pipe", pts, B, packed, biasrows, ray_row, scale, d_sig, d_rgb, grad_scale, dtrunk,
                 dB, dbiasrows, C, R, S, rows_per_class, max_blocks, int(v[-1]), workspace, workspace.numel(), int(B_stride),
-                int(dtrunk_stride), int(dB_stride))
+                int(dtrunk_stride), int(dB_stride), rows_fix, int(bool(skip_reduce)))
     else:
         raise ValueError(f"unknown cnr_field_bwd variant {v!r}")
 

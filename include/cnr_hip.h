@@ -285,25 +285,36 @@ int cnr_adamw_epilogue(float* param, const float* grad, float* exp_avg, float* e
  * the AdamW blocks.  do_latent = 0: grad already holds the complete gradient (cnr_latent_bwd ran, e.g. before a
  * multi-GPU all-reduce) and only AdamW + epilogue run.  grad is updated to the complete gradient either way.
  * Layout arguments as cnr_latent_bwd (trunk at offset 0 of a class row, B at off_B); rl_workspace etc. as
- * cnr_step_epilogue. */
+ * cnr_step_epilogue.
+ * records != NULL (with do_latent, n_obj <= 4): the launch ALSO replaces the record reduction of
+ * cnr_field_bwd_pipe(..., skip_reduce = 1): `records` is that call's workspace, nwg =
+ * cnr_field_bwd_pipe_blocks(...), and rows_fix the (8, C, n_obj, 4, 32) int64 table that call accumulated (2^-40 fixed
+ * point, integer atomics: any order, same sum) -- zero it before every field backward.  dbiasrows then receives the
+ * float form of that table. */
 int cnr_step_tail(const float* theta_in, float* theta_out, float* grad, float* exp_avg, float* exp_avg_sq,
                   int64_t class_stride, int64_t off_B, int64_t off_latW, int64_t off_latb, int64_t off_shape,
-                  int64_t off_tex, int L, int n_obj, int C, const float* zl, const float* dbiasrows, float reg_scale,
+                  int64_t off_tex, int L, int n_obj, int C, const float* zl, float* dbiasrows, float reg_scale,
                   int do_latent, float lr, float beta1, float beta2, float eps, float weight_decay,
                   const int64_t* state_cur, int64_t* state_next, int64_t add_rows, const void* rl_workspace,
                   float* losses, int32_t* flags, const float* depth, int64_t pool_rows, const int* perm,
-                  float* next_max_bound, int R, void* stream);
+                  float* next_max_bound, int R, const void* records, int nwg, const long long* rows_fix,
+                  void* stream);
 
 /* Same contract and results as cnr_field_bwd, ONE field kernel + the record reduction: each workgroup is
  * `chain_waves` (2 or 3) waves that run forward recompute + data-gradient chain + PE backward for one 32-sample
  * tile each, plus 4 - chain_waves waves that own the weight-gradient accumulators and consume the chain waves'
  * per-layer images one workgroup barrier behind (csrc/fused_bwd_pipe.hip).  max_blocks / workspace as above. */
+/* rows_fix (optional): per-object bias-row sums also accumulated as 2^-40 fixed point into this (8, C, n_obj, 4, 32)
+ * int64 table (8 copies, a workgroup uses copy index & 7, to shorten the same-address atomic queues; caller zeroes it); skip_reduce != 0: stop after the field kernel, the caller reduces the nwg =
+ * cnr_field_bwd_pipe_blocks(R, S, chain_waves, max_blocks) records per class in `workspace` itself (cnr_step_tail). */
+int cnr_field_bwd_pipe_blocks(int R, int S, int chain_waves, int max_blocks);
 int cnr_field_bwd_pipe(const float* pts, const float* B, const void* packed, const float* biasrows,
                        const int* ray_row, float scale, const float* d_sigma, const float* d_rgb,
                        float grad_scale, float* dtrunk, float* dB, float* dbiasrows, int C, int R, int S,
                        int rows_per_class, int max_blocks, int chain_waves, void* workspace,
                        int64_t workspace_bytes, int64_t B_stride,
-                       int64_t dtrunk_stride, int64_t dB_stride, void* stream);
+                       int64_t dtrunk_stride, int64_t dB_stride, long long* rows_fix, int skip_reduce,
+                       void* stream);
 
 #ifdef __cplusplus
 }
