@@ -158,7 +158,7 @@ def main():
 
     # ---- roofline leg: the dominant kernel (fused backward) timed with HIP events on its launch stream ----
     bwd_name = "cnr_field_bwd" if cnr_amd.ops.FIELD_BWD_VARIANT == "split" else "cnr_field_bwd_pipe"
-    names = [bwd_name, "cnr_field_fwd", "cnr_step_prologue", "cnr_render_loss", "cnr_latent_bwd", "cnr_adamw_epilogue"]
+    names = [bwd_name, "cnr_field_fwd", "cnr_step_prologue", "cnr_render_loss", "cnr_step_tail"]
     tr.use_graph = False                                           # eager so that events bracket single launches
     cnr_amd._C.enable_kernel_timing(names)
     for _ in range(min(args.steps, 50)):
