@@ -158,7 +158,7 @@ def main():
 
     # ---- roofline leg: the dominant kernel (fused backward) timed with HIP events on its launch stream ----
     bwd_name = "cnr_field_bwd" if cnr_amd.ops.FIELD_BWD_VARIANT == "split" else "cnr_field_bwd_pipe"
-    names = [bwd_name, "cnr_field_fwd", "cnr_step_prologue", "cnr_render_loss", "cnr_step_tail"]
+    names = [bwd_name, "cnr_field_fwd", "cnr_field_fwd_render", "cnr_step_prologue", "cnr_render_loss", "cnr_step_tail"]
     tr.use_graph = False                                           # eager so that events bracket single launches
     cnr_amd._C.enable_kernel_timing(names)
     for _ in range(min(args.steps, 50)):
@@ -170,7 +170,7 @@ def main():
     # for its kernels (field kernel + reduce_records), and the one the roofline entry uses
     eager_bwd_ms = avg[bwd_name]
     avg[bwd_name] = tr.time_field_bwd(50)
-    dom = max((bwd_name, "cnr_field_fwd"), key=lambda k: avg[k])
+    dom = max((bwd_name, "cnr_field_fwd", "cnr_field_fwd_render"), key=lambda k: avg[k])
     # the backward call = the field kernel(s) (pipe: one launch; split: texture + geometry launches) + reduce_records:
     # its duration is the sum of those (rocprof lists them separately, profiles/).
     # algorithmic FLOP of that call: fwd = 27 422 / sample, bwd (recompute fwd + dX + dW) = 82 140

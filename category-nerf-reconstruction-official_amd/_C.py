@@ -51,16 +51,20 @@ SIGNATURES = {
     "cnr_adamw_epilogue": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64,
                            _vp, _vp, _i, _i, _vp],
     "cnr_step_tail": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _vp, _vp, _f, _i, _f, _f, _f,
-                      _f, _f, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i, _vp, _i, _vp, _vp],
+                      _f, _f, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i, _vp, _i, _vp, _i, _vp],
+    "cnr_field_fwd_render_blocks": [_i, _i],
+    "cnr_field_fwd_render_workspace_bytes": [_i, _i, _i],
+    "cnr_field_fwd_render": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp,
+                             _vp, _i, _i, _i, _i64, _vp, _i64, _vp],
     "cnr_param_prep": [_vp, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp],
     "cnr_render_loss_workspace_bytes": [_i, _i],
     "cnr_render_loss": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp,
                         _i64, _vp],
-    "cnr_render_loss_finish": [_vp, _vp, _vp, _i, _i, _vp],
+    "cnr_render_loss_finish": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "cnr_step_epilogue": [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i, _i, _vp],
 }
 _RESTYPE64 = {"cnr_pack_bytes", "cnr_field_bwd_workspace_bytes", "cnr_render_loss_workspace_bytes",
-              "cnr_dense_bwd_workspace_bytes"}
+              "cnr_dense_bwd_workspace_bytes", "cnr_field_fwd_render_workspace_bytes"}
 
 _lib = None
 _double = None

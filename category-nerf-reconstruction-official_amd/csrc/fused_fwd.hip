@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include "fused_common.h"
 #include "latent_common.h"
+#include "render_common.h"
 #include "sample_common.h"
 
 namespace {
@@ -132,6 +133,75 @@ __global__ __launch_bounds__(256) void param_prep_kernel(const float* __restrict
 
 namespace {
 
+// One 32-sample tile through PE + the ten layers: this lane's sample is (t0, t1, t2) (already / scale), brow its
+// ray's effective bias rows.  Returns the sigma logit BEFORE the x10 (valid in every lane) and leaves the three colour
+// logits in acc[0..2] of lane half 0.
+__device__ __forceinline__ float forward_tile(const unsigned char* smem, const float* cf, const float (&Bh)[33],
+                                              float t0, float t1, float t2, const float* __restrict__ brow, int lane,
+                                              int h, f16v& acc_out) {
+  h8 E1f[6], E2f[3];
+  pe_slots<false>(Bh, t0, t1, t2, h, E1f, E2f);
+
+  // L0 encoding_xyz
+  f16v acc = acc_init(cf + CF_B_XYZ, h);
+#pragma unroll
+  for (int s = 0; s < 6; ++s) acc = MFMA(lds_frag(smem, KK_XYZ + s, lane), E1f[s], acc);
+  h8 H0 = pack8(acc, 0, true), H1 = pack8(acc, 1, true);
+  // L1 shape_layer_1 (latent slot 0 folded into the bias row)
+  acc = acc_init(brow + 0 * 32, h);
+  acc = MFMA(lds_frag(smem, KK_S1 + 0, lane), H0, acc);
+  acc = MFMA(lds_frag(smem, KK_S1 + 1, lane), H1, acc);
+  H0 = pack8(acc, 0, true); H1 = pack8(acc, 1, true);
+  // L2 cat_layer: [a1 | e1]
+  acc = acc_init(brow + 1 * 32, h);
+  acc = MFMA(lds_frag(smem, KK_CAT + 0, lane), H0, acc);
+  acc = MFMA(lds_frag(smem, KK_CAT + 1, lane), H1, acc);
+#pragma unroll
+  for (int s = 0; s < 6; ++s) acc = MFMA(lds_frag(smem, KK_CAT + 2 + s, lane), E1f[s], acc);
+  H0 = pack8(acc, 0, true); H1 = pack8(acc, 1, true);
+  // L3 shape_layer_2
+  acc = acc_init(brow + 2 * 32, h);
+  acc = MFMA(lds_frag(smem, KK_S2 + 0, lane), H0, acc);
+  acc = MFMA(lds_frag(smem, KK_S2 + 1, lane), H1, acc);
+  H0 = pack8(acc, 0, true); H1 = pack8(acc, 1, true);
+  // L4 encoding_shape (no activation)
+  acc = acc_init(cf + CF_B_ES, h);
+  acc = MFMA(lds_frag(smem, KK_ES + 0, lane), H0, acc);
+  acc = MFMA(lds_frag(smem, KK_ES + 1, lane), H1, acc);
+  // sigma head in fp32 on the VALU: raw = w_sigma . y4 + b
+  float raw;
+  {
+    const f16v ws = acc_init(cf + CF_W_SG, h);
+    float part = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) part = fmaf(ws[i], acc[i], part);
+    raw = part + __shfl_xor(part, 32, 64) + cf[CF_B_SG];
+  }
+  H0 = pack8(acc, 0, false); H1 = pack8(acc, 1, false);
+  // L6 encoding_viewdir: [y4 | e2]
+  acc = acc_init(cf + CF_B_VD, h);
+  acc = MFMA(lds_frag(smem, KK_VD + 0, lane), H0, acc);
+  acc = MFMA(lds_frag(smem, KK_VD + 1, lane), H1, acc);
+#pragma unroll
+  for (int s = 0; s < 3; ++s) acc = MFMA(lds_frag(smem, KK_VD + 2 + s, lane), E2f[s], acc);
+  H0 = pack8(acc, 0, true); H1 = pack8(acc, 1, true);
+  // L7 texture_layer_1
+  acc = acc_init(brow + 3 * 32, h);
+  acc = MFMA(lds_frag(smem, KK_T1 + 0, lane), H0, acc);
+  acc = MFMA(lds_frag(smem, KK_T1 + 1, lane), H1, acc);
+  H0 = pack8(acc, 0, true); H1 = pack8(acc, 1, true);
+  // L8 rgb.0 (16 outputs = rows 0..15 = registers 0..7)
+  acc = acc_init(cf + CF_B_R0, h);
+  acc = MFMA(lds_frag(smem, KK_R0 + 0, lane), H0, acc);
+  acc = MFMA(lds_frag(smem, KK_R0 + 1, lane), H1, acc);
+  H0 = pack8(acc, 0, true);
+  // L9 rgb.2 (3 outputs = rows 0..2 = registers 0..2 of half 0)
+  acc = acc_init(cf + CF_B_R2, h);
+  acc = MFMA(lds_frag(smem, KK_R2, lane), H0, acc);
+  acc_out = acc;
+  return raw;
+}
+
 __global__ __launch_bounds__(256, 4) void field_fwd_kernel(
     const float* __restrict__ pts, const float* __restrict__ Bdir, const unsigned char* __restrict__ packed,
     const float* __restrict__ biasrows, const int* __restrict__ ray_row, float inv_scale,
@@ -173,65 +243,8 @@ __global__ __launch_bounds__(256, 4) void field_fwd_kernel(
     const int64_t row = ray_row ? (int64_t)ray_row[ray] : ray;
     const float* brow = biasrows + row * (CNR_NLAT * 32);
 
-    h8 E1f[6], E2f[3];
-    pe_slots<false>(Bh, t0, t1, t2, h, E1f, E2f);
-
-    // L0 encoding_xyz
-    f16v acc = acc_init(cf + CF_B_XYZ, h);
-#pragma unroll
-    for (int s = 0; s < 6; ++s) acc = MFMA(lds_frag(smem, KK_XYZ + s, lane), E1f[s], acc);
-    h8 H0 = pack8(acc, 0, true), H1 = pack8(acc, 1, true);
-    // L1 shape_layer_1 (latent slot 0 folded into the bias row)
-    acc = acc_init(brow + 0 * 32, h);
-    acc = MFMA(lds_frag(smem, KK_S1 + 0, lane), H0, acc);
-    acc = MFMA(lds_frag(smem, KK_S1 + 1, lane), H1, acc);
-    H0 = pack8(acc, 0, true); H1 = pack8(acc, 1, true);
-    // L2 cat_layer: [a1 | e1]
-    acc = acc_init(brow + 1 * 32, h);
-    acc = MFMA(lds_frag(smem, KK_CAT + 0, lane), H0, acc);
-    acc = MFMA(lds_frag(smem, KK_CAT + 1, lane), H1, acc);
-#pragma unroll
-    for (int s = 0; s < 6; ++s) acc = MFMA(lds_frag(smem, KK_CAT + 2 + s, lane), E1f[s], acc);
-    H0 = pack8(acc, 0, true); H1 = pack8(acc, 1, true);
-    // L3 shape_layer_2
-    acc = acc_init(brow + 2 * 32, h);
-    acc = MFMA(lds_frag(smem, KK_S2 + 0, lane), H0, acc);
-    acc = MFMA(lds_frag(smem, KK_S2 + 1, lane), H1, acc);
-    H0 = pack8(acc, 0, true); H1 = pack8(acc, 1, true);
-    // L4 encoding_shape (no activation)
-    acc = acc_init(cf + CF_B_ES, h);
-    acc = MFMA(lds_frag(smem, KK_ES + 0, lane), H0, acc);
-    acc = MFMA(lds_frag(smem, KK_ES + 1, lane), H1, acc);
-    // sigma head in fp32 on the VALU: raw = w_sigma . y4 + b
-    float raw;
-    {
-      const f16v ws = acc_init(cf + CF_W_SG, h);
-      float part = 0.0f;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) part = fmaf(ws[i], acc[i], part);
-      raw = part + __shfl_xor(part, 32, 64) + cf[CF_B_SG];
-    }
-    H0 = pack8(acc, 0, false); H1 = pack8(acc, 1, false);
-    // L6 encoding_viewdir: [y4 | e2]
-    acc = acc_init(cf + CF_B_VD, h);
-    acc = MFMA(lds_frag(smem, KK_VD + 0, lane), H0, acc);
-    acc = MFMA(lds_frag(smem, KK_VD + 1, lane), H1, acc);
-#pragma unroll
-    for (int s = 0; s < 3; ++s) acc = MFMA(lds_frag(smem, KK_VD + 2 + s, lane), E2f[s], acc);
-    H0 = pack8(acc, 0, true); H1 = pack8(acc, 1, true);
-    // L7 texture_layer_1
-    acc = acc_init(brow + 3 * 32, h);
-    acc = MFMA(lds_frag(smem, KK_T1 + 0, lane), H0, acc);
-    acc = MFMA(lds_frag(smem, KK_T1 + 1, lane), H1, acc);
-    H0 = pack8(acc, 0, true); H1 = pack8(acc, 1, true);
-    // L8 rgb.0 (16 outputs = rows 0..15 = registers 0..7)
-    acc = acc_init(cf + CF_B_R0, h);
-    acc = MFMA(lds_frag(smem, KK_R0 + 0, lane), H0, acc);
-    acc = MFMA(lds_frag(smem, KK_R0 + 1, lane), H1, acc);
-    H0 = pack8(acc, 0, true);
-    // L9 rgb.2 (3 outputs = rows 0..2 = registers 0..2 of half 0)
-    acc = acc_init(cf + CF_B_R2, h);
-    acc = MFMA(lds_frag(smem, KK_R2, lane), H0, acc);
+    f16v acc;
+    const float raw = forward_tile(smem, cf, Bh, t0, t1, t2, brow, lane, h, acc);
     if (live && h == 0) {
       sigmas[gs] = raw * 10.0f;
       float* o = rgbs + gs * 3;
@@ -239,6 +252,175 @@ __global__ __launch_bounds__(256, 4) void field_fwd_kernel(
       o[1] = 1.0f / (1.0f + __expf(-acc[1]));
       o[2] = 1.0f / (1.0f + __expf(-acc[2]));
     }
+  }
+}
+
+// a8-a15 for the fused trainer in ONE launch: the field forward of every sample of a ray, the alpha composite, the
+// loss gradient w.r.t. the ray's renders and the composite backward, with the per-sample sigma / colour never leaving
+// registers (cnr_field_fwd + cnr_render_loss write and re-read 16 B per sample between two launches).  A wave owns
+// whole rays: K = S / 32 consecutive tiles, lane (half 0) = sample; the exclusive-cumprod runs as a 32-lane scan per
+// tile with the transmittance carried from tile to tile, the backward's suffix sums the other way.  Same expressions as
+// render_loss.hip; sums over lanes run over 32-lane tiles instead of 64-lane chunks, so the results agree to summation
+// order, not bitwise.  grid (blocks, C); block b of class c writes loss partial (c, b) -- nb = gridDim.x for
+// finish_class.
+template <int K>
+__global__ __launch_bounds__(256, 2) void field_fwd_render_kernel(
+    const float* __restrict__ pts, const float* __restrict__ Bdir, const unsigned char* __restrict__ packed,
+    const float* __restrict__ biasrows, const int* __restrict__ ray_row, float inv_scale, const float* __restrict__ z,
+    const float* __restrict__ gt_depth, const float* __restrict__ gt_rgb, const uint8_t* __restrict__ labels,
+    const uint8_t* __restrict__ depth_mask, float color_scaling, float opacity_scaling, float grad_scale,
+    float* __restrict__ d_sigmas, float* __restrict__ d_colors, float* __restrict__ depth_out,
+    float* __restrict__ var_out, float* __restrict__ rgb_out, float* __restrict__ opacity_out, int C, int R,
+    int64_t B_stride, float* __restrict__ partials) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ float cnt[12];
+  constexpr int S = 32 * K;
+  const int c = blockIdx.y;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, h = lane >> 5, col = lane & 31;
+  {
+    const unsigned char* src = packed + (size_t)c * PK_BYTES;
+    for (int i = threadIdx.x * 16; i < PK_OFF_BWD; i += 256 * 16)
+      *reinterpret_cast<f4*>(smem + i) = *reinterpret_cast<const f4*>(src + i);
+    float* Bl = reinterpret_cast<float*>(smem + PK_OFF_BWD);
+    for (int i = threadIdx.x; i < 66; i += 256) {
+      const int hh = i / 33, k = i % 33, d = k / 3;
+      Bl[i] = (hh == 1 && d == 10) ? 0.0f : Bdir[(size_t)c * B_stride + (11 * hh + d) * 3 + (k % 3)];
+    }
+  }
+  // ---- mask counts of every class (the empty-mask rule of render_rays.py:67-72 couples the classes) ---------------
+  bool empty_d = false, empty_c = false, empty_o = false;
+  float nd = 0.f, nc = 0.f, no = 0.f;
+  for (int cc = 0; cc < C; ++cc) {
+    float a = 0.f, b = 0.f, d = 0.f;
+    for (int r = threadIdx.x; r < R; r += 256) {
+      const uint8_t lab = labels[(size_t)cc * R + r];
+      const bool mo = lab != 0, ms = lab != 2, md = depth_mask[(size_t)cc * R + r] != 0;
+      a += (md && mo) ? 1.f : 0.f; b += mo ? 1.f : 0.f; d += ms ? 1.f : 0.f;
+    }
+    a = cnr::wave_sum(a); b = cnr::wave_sum(b); d = cnr::wave_sum(d);
+    __syncthreads();
+    if (lane == 0) { cnt[wv] = a; cnt[4 + wv] = b; cnt[8 + wv] = d; }
+    __syncthreads();
+    a = (cnt[0] + cnt[1]) + (cnt[2] + cnt[3]); b = (cnt[4] + cnt[5]) + (cnt[6] + cnt[7]);
+    d = (cnt[8] + cnt[9]) + (cnt[10] + cnt[11]);
+    empty_d |= (a == 0.f); empty_c |= (b == 0.f); empty_o |= (d == 0.f);
+    if (cc == c) { nd = a; nc = b; no = d; }
+  }
+  __syncthreads();
+  const float wd = empty_d ? 0.f : 1.0f / (nd + 1e-10f);
+  const float wc = empty_c ? 0.f : 1.0f / (nc + 1e-10f);
+  const float wo = empty_o ? 0.f : 1.0f / (no + 1e-10f);
+  const float* cf = reinterpret_cast<const float*>(smem + PK_OFF_CONST);
+  float Bh[33];
+  {
+    const float* Bl = reinterpret_cast<const float*>(smem + PK_OFF_BWD) + 33 * h;
+#pragma unroll
+    for (int i = 0; i < 33; ++i) Bh[i] = Bl[i];
+  }
+  auto sgn = [](float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); };
+  // 32-lane scans on lane half 0 (half 1 holds the neutral element, so the 64-lane shuffles below are 32-lane scans)
+  auto incl_prod32 = [&](float v) {
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) { const float p = __shfl_up(v, o, 64); if (col >= o && h == 0) v *= p; }
+    return v;
+  };
+  auto incl_suffix32 = [&](float v) {
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) { const float p = __shfl_down(v, o, 64); if (col + o < 32 && h == 0) v += p; }
+    return v;
+  };
+  float ld = 0.f, lc = 0.f, lo = 0.f;
+  for (int r = blockIdx.x * 4 + wv; r < R; r += gridDim.x * 4) {
+    asm volatile("" ::: "memory");
+    const int64_t ray = (int64_t)c * R + r;
+    const int64_t row = ray_row ? (int64_t)ray_row[ray] : ray;
+    const float* brow = biasrows + row * (CNR_NLAT * 32);
+    float occ[K], T[K], zz[K], c0[K], c1[K], c2[K];
+    float carry = 1.0f, sd = 0.f, so = 0.f, sr = 0.f, sg = 0.f, sb = 0.f;
+#pragma unroll
+    for (int t = 0; t < K; ++t) {
+      // (unrolled: occ[t] ... stay in registers; the clobber keeps the K copies of the forward from sharing -- and
+      //  keeping alive -- each other's weight-fragment loads)
+      asm volatile("" ::: "memory");
+      const int64_t gs = ray * S + t * 32 + col;
+      const float* pp = pts + gs * 3;
+      f16v acc;
+      const float raw = forward_tile(smem, cf, Bh, pp[0] * inv_scale, pp[1] * inv_scale, pp[2] * inv_scale, brow, lane,
+                                     h, acc);
+      // composite of this tile (lane half 0 = the 32 samples; half 1 neutral)
+      occ[t] = h == 0 ? 1.0f / (1.0f + expf(-(raw * 10.0f))) : 0.0f;
+      c0[t] = 1.0f / (1.0f + __expf(-acc[0])); c1[t] = 1.0f / (1.0f + __expf(-acc[1]));
+      c2[t] = 1.0f / (1.0f + __expf(-acc[2]));
+      zz[t] = z[gs];
+      const float f = h == 0 ? (1.0f - occ[t] + 1e-10f) : 1.0f;
+      const float incl = incl_prod32(f);
+      float excl = __shfl_up(incl, 1, 64);
+      if (col == 0) excl = 1.0f;
+      T[t] = carry * excl;
+      const float term = occ[t] * T[t];
+      sd += term * zz[t]; so += term; sr += term * c0[t]; sg += term * c1[t]; sb += term * c2[t];
+      carry *= __shfl(incl, 31, 64);
+    }
+    sd = cnr::wave_sum(sd); so = cnr::wave_sum(so);
+    sr = cnr::wave_sum(sr); sg = cnr::wave_sum(sg); sb = cnr::wave_sum(sb);
+    float sv = 0.f;
+#pragma unroll
+    for (int t = 0; t < K; ++t) { const float dz = zz[t] - sd; sv += occ[t] * T[t] * dz * dz; }
+    sv = cnr::wave_sum(sv);
+    if (lane == 0) {
+      if (depth_out) depth_out[ray] = sd;
+      if (var_out) var_out[ray] = sv;
+      if (opacity_out) opacity_out[ray] = so;
+      if (rgb_out) { rgb_out[ray * 3 + 0] = sr; rgb_out[ray * 3 + 1] = sg; rgb_out[ray * 3 + 2] = sb; }
+    }
+    // ---- losses of this ray and their gradients w.r.t. its renders (loss.hip, same expressions) --------------------
+    const uint8_t lab = labels[ray];
+    const bool mo = lab != 0, ms = lab != 2, md = (depth_mask[ray] != 0) && mo;
+    const float fd = md ? 1.f : 0.f, fo = mo ? 1.f : 0.f, fs = ms ? 1.f : 0.f;
+    const float rd = sd - gt_depth[ray];
+    const float info = 1.0f / (sqrtf(sv) + 1e-4f);
+    const float rc0 = sr - gt_rgb[ray * 3 + 0], rc1 = sg - gt_rgb[ray * 3 + 1], rc2 = sb - gt_rgb[ray * 3 + 2];
+    const float ro = so - fo;
+    ld += fabsf(rd) * fd * info;
+    lc += (fabsf(rc0) + fabsf(rc1) + fabsf(rc2)) * fo;
+    lo += fabsf(ro) * fs;
+    const float dD = grad_scale * sgn(rd) * fd * info * wd;
+    const float dR = grad_scale * color_scaling * sgn(rc0) * fo * wc;
+    const float dG = grad_scale * color_scaling * sgn(rc1) * fo * wc;
+    const float dBl = grad_scale * color_scaling * sgn(rc2) * fo * wc;
+    const float dO = grad_scale * opacity_scaling * sgn(ro) * fs * wo;
+    // ---- composite backward, last tile first, suffix sum carried across tiles ---------------------------------------
+    float suf_carry = 0.0f;
+#pragma unroll
+    for (int t = K - 1; t >= 0; --t) {
+      const float term = occ[t] * T[t];
+      const float g = dD * zz[t] + dR * c0[t] + dG * c1[t] + dBl * c2[t] + dO;
+      const float tg = h == 0 ? term * g : 0.0f;
+      const float incl_suf = incl_suffix32(tg);
+      const float suf = (incl_suf - tg) + suf_carry;
+      if (h == 0) {
+        const int64_t gs = ray * S + t * 32 + col;
+        const float f = 1.0f - occ[t] + 1e-10f;
+        const float docc = T[t] * g - suf / f;
+        d_sigmas[gs] = docc * occ[t] * (1.0f - occ[t]);
+        float* dc = d_colors + gs * 3;
+        dc[0] = term * dR; dc[1] = term * dG; dc[2] = term * dBl;
+      }
+      suf_carry += __shfl(incl_suf, 0, 64);
+    }
+  }
+  // ---- loss values: block partials for finish_class -------------------------------------------------------------------
+  __syncthreads();
+  if (lane == 0) { cnt[wv] = ld; cnt[4 + wv] = lc; cnt[8 + wv] = lo; }
+  __syncthreads();
+  const int nb = gridDim.x;
+  if (threadIdx.x < 3)
+    partials[((size_t)c * nb + blockIdx.x) * 3 + threadIdx.x] =
+        (cnt[threadIdx.x * 4] + cnt[threadIdx.x * 4 + 1]) + (cnt[threadIdx.x * 4 + 2] + cnt[threadIdx.x * 4 + 3]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    float* hdr = partials + (size_t)C * nb * 3 + (size_t)c * 4;
+    hdr[0] = wd; hdr[1] = wc; hdr[2] = wo;
+    hdr[3] = (float)((empty_d ? 2 : 0) | (empty_c ? 4 : 0) | (empty_o ? 8 : 0));
   }
 }
 }  // namespace
@@ -250,6 +432,49 @@ extern "C" int cnr_pack_weights(const float* trunk, void* packed, int C, void* s
   if (((uintptr_t)packed & 15) != 0) return CNR_E_ALIGN;
   dim3 grid(fz::NKK_FWD + fz::NKK_BWD + 1, (unsigned)C);
   hipLaunchKernelGGL(pack_kernel, grid, dim3(256), 0, (hipStream_t)stream, trunk, (unsigned char*)packed);
+  CNR_LAUNCH_CHECK();
+  return CNR_OK;
+}
+
+// blocks per class of cnr_field_fwd_render (= loss partials per class: what cnr_render_loss_finish / cnr_step_tail
+// need to know), 0 when the shape is not supported (S must be 32, 64, 96 or 128)
+extern "C" int cnr_field_fwd_render_blocks(int R, int S) {
+  if (R <= 0 || (S != 32 && S != 64 && S != 96 && S != 128)) return 0;
+  const int64_t b = ((int64_t)R + 3) / 4;
+  return (int)(b > 2048 ? 2048 : b);
+}
+extern "C" int64_t cnr_field_fwd_render_workspace_bytes(int C, int R, int S) {
+  const int nb = cnr_field_fwd_render_blocks(R, S);
+  return nb ? ((int64_t)C * nb * 3 + (int64_t)C * 4) * (int64_t)sizeof(float) : 0;
+}
+
+extern "C" int cnr_field_fwd_render(const float* pts, const float* B, const void* packed, const float* biasrows,
+                                    const int* ray_row, float scale, const float* z, const float* gt_depth,
+                                    const float* gt_rgb, const uint8_t* labels, const uint8_t* depth_mask,
+                                    float color_scaling, float opacity_scaling, float grad_scale, float* d_sigmas,
+                                    float* d_colors, float* depth, float* var, float* rgb, float* opacity, int C, int R,
+                                    int S, int64_t B_stride, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!pts || !B || !packed || !biasrows || !z || !gt_depth || !gt_rgb || !labels || !depth_mask || !d_sigmas ||
+      !d_colors || !workspace || C <= 0 || R <= 0 || !(scale > 0.f))
+    return CNR_E_ARG;
+  const int nb = cnr_field_fwd_render_blocks(R, S);
+  if (!nb) return CNR_E_SHAPE;
+  if (workspace_bytes < cnr_field_fwd_render_workspace_bytes(C, R, S)) return CNR_E_ARG;
+  if (((uintptr_t)packed & 15) != 0 || ((uintptr_t)biasrows & 15) != 0) return CNR_E_ALIGN;
+  const size_t lds = (size_t)fz::PK_OFF_BWD + 66 * sizeof(float) + 8;
+  dim3 grid((unsigned)nb, (unsigned)C);
+#define CNR_FFR(KK)                                                                                                 \
+  hipLaunchKernelGGL((field_fwd_render_kernel<KK>), grid, dim3(256), lds, (hipStream_t)stream, pts, B,               \
+                     (const unsigned char*)packed, biasrows, ray_row, 1.0f / scale, z, gt_depth, gt_rgb, labels,     \
+                     depth_mask, color_scaling, opacity_scaling, grad_scale, d_sigmas, d_colors, depth, var, rgb,    \
+                     opacity, C, R, B_stride > 0 ? B_stride : (int64_t)63, (float*)workspace)
+  switch (S / 32) {
+    case 1: CNR_FFR(1); break;
+    case 2: CNR_FFR(2); break;
+    case 3: CNR_FFR(3); break;
+    default: CNR_FFR(4); break;
+  }
+#undef CNR_FFR
   CNR_LAUNCH_CHECK();
   return CNR_OK;
 }

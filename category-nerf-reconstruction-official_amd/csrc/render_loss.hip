@@ -343,10 +343,10 @@ extern "C" int cnr_render_loss(const float* sigmas, const float* colors, const f
 }
 
 extern "C" int cnr_render_loss_finish(const void* workspace, float* losses, int32_t* flags, int C, int R,
-                                      void* stream) {
+                                      int rl_blocks, void* stream) {
   if (!workspace || !losses || !flags || C <= 0 || R <= 0) return CNR_E_ARG;
   const int rpb = rl_rays_per_block(C, R);
-  const int nb = (R + rpb - 1) / rpb;
+  const int nb = rl_blocks > 0 ? rl_blocks : (R + rpb - 1) / rpb;
   hipLaunchKernelGGL(render_loss_finish_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, (const float*)workspace,
                      nb, losses, flags, C);
   CNR_LAUNCH_CHECK();

@@ -178,7 +178,7 @@ extern "C" int cnr_step_tail(const float* theta_in, float* theta_out, float* gra
                              float weight_decay, const int64_t* state_cur, int64_t* state_next, int64_t add_rows,
                              const void* rl_workspace, float* losses, int32_t* flags, const float* depth,
                              int64_t pool_rows, const int* perm, float* next_max_bound, int R, const void* records,
-                             int nwg, const long long* rows_fix, void* stream) {
+                             int nwg, const long long* rows_fix, int rl_blocks, void* stream) {
   if (!theta_in || !theta_out || theta_in == theta_out || !grad || !exp_avg || !exp_avg_sq || class_stride <= 0 ||
       L <= 0 || n_obj <= 0 || C <= 0 || !state_cur || !state_next || state_cur == state_next || !rl_workspace ||
       !losses || !flags || R <= 0)
@@ -195,7 +195,8 @@ extern "C" int cnr_step_tail(const float* theta_in, float* theta_out, float* gra
   a.lr = lr; a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.wd = weight_decay;
   a.state_cur = state_cur; a.state_next = state_next; a.add_rows = add_rows;
   const int rpb = cnr_rl::rl_rays_per_block(C, R);
-  a.partials = (const float*)rl_workspace; a.nb = (R + rpb - 1) / rpb; a.losses = losses; a.flags = flags;
+  a.partials = (const float*)rl_workspace; a.nb = rl_blocks > 0 ? rl_blocks : (R + rpb - 1) / rpb;
+  a.losses = losses; a.flags = flags;
   a.depth = depth; a.pool_rows = pool_rows; a.perm = perm; a.R = R; a.max_bound = next_max_bound;
   a.do_latent = do_latent ? 1 : 0;
   const int64_t nlat_out = (int64_t)4 * 32 * L + 128 + (int64_t)2 * n_obj * L;

@@ -74,7 +74,8 @@ class FusedCategoryTrainer:
     """C classes x n_obj objects, R rays per class per step, S = n1 + n2 samples per ray."""
 
     def __init__(self, cfg, n_cls, n_obj, pools, rays_per_step, device, seed=0, generator=None,
-                 grad_scale=None, bwd_blocks=0, process_group=None, use_graph=True, split_graph=False):
+                 grad_scale=None, bwd_blocks=0, process_group=None, use_graph=True, split_graph=False,
+                 fuse_render=True):
         self.cfg, self.C, self.n_obj, self.R = cfg, n_cls, n_obj, rays_per_step
         self.device = torch.device(device)
         self.n1, self.n2 = cfg.n_bins_cam2surface, cfg.n_bins
@@ -124,6 +125,8 @@ class FusedCategoryTrainer:
         self.dbias = self._gbuf[n_th:n_th + n_db].view(n_cls * n_obj, 4, 32)
         self._nwg = int(_C.load().cnr_field_bwd_pipe_blocks(self.R, self.S, int(ops.FIELD_BWD_VARIANT[-1]), self.bwd_blocks)) \
             if self.fused_tail else 0
+        # forward + render/loss in one launch where the shape allows (S a multiple of 32 up to 128), else two launches
+        self._rl_blocks = int(_C.load().cnr_field_fwd_render_blocks(self.R, self.S)) if fuse_render else 0
         self.use_graph = use_graph
         self.split_graph = bool(split_graph)     # the two-graph form of the distributed step, for single-GPU tests
         self.graphs = {}                         # parity -> captured graph (or (front, back) pair)
@@ -163,7 +166,9 @@ class FusedCategoryTrainer:
             for name, shape in (("depth", (C, R)), ("var", (C, R)), ("rgb", (C, R, 3)), ("opa", (C, R)),
                                 ("dsig", (C, R, S)), ("drgb", (C, R, S, 3))):
                 o[name] = torch.empty(*shape, **kw)
-            o["rl_ws"] = torch.zeros(_C.render_loss_workspace_bytes(C, R), device=self.device, dtype=torch.uint8)
+            o["rl_ws"] = torch.zeros(max(_C.render_loss_workspace_bytes(C, R),
+                                         int(_C.load().cnr_field_fwd_render_workspace_bytes(C, R, S))),
+                                     device=self.device, dtype=torch.uint8)
             o["bwd_ws"] = torch.empty(_C.field_bwd_workspace_bytes(C, self.bwd_blocks), device=self.device,
                                       dtype=torch.uint8)
         zl, brows, packed = o["zl"], o["brows"], o["packed"]
@@ -185,14 +190,20 @@ class FusedCategoryTrainer:
                               self.max_bound,
                               self.pool["indices"], self.perm)
         ray_row = b["ray_row"]
-        # a8 + a9 fused forward
-        sig, rgb = o["sig"], o["rgbs"]
-        _C.call("cnr_field_fwd", b["pts"], Bc, packed, brows, ray_row, self.scale, sig, rgb, C, R, S, P)
-        # a11-a15 in one launch: composite, losses, their gradient, composite backward
         inv_w = 1.0 / self.world
-        _C.call("cnr_render_loss", sig, rgb, b["z"], b["gt_depth"], b["gt_rgb"], b["labels"], b["depth_mask"],
-                5.0, 10.0, inv_w, o["dsig"], o["drgb"], o["depth"], o["var"], o["rgb"], o["opa"], C, R, S,
-                o["rl_ws"], o["rl_ws"].numel())
+        if self._rl_blocks:
+            # a8-a15 in one launch (S = 32 k): field forward, composite, losses, their gradient, composite backward;
+            # sigma / colour per sample never leave registers
+            _C.call("cnr_field_fwd_render", b["pts"], Bc, packed, brows, ray_row, self.scale, b["z"], b["gt_depth"],
+                    b["gt_rgb"], b["labels"], b["depth_mask"], 5.0, 10.0, inv_w, o["dsig"], o["drgb"], o["depth"],
+                    o["var"], o["rgb"], o["opa"], C, R, S, P, o["rl_ws"], o["rl_ws"].numel())
+        else:
+            # a8 + a9 fused forward, then a11-a15 in one launch
+            sig, rgb = o["sig"], o["rgbs"]
+            _C.call("cnr_field_fwd", b["pts"], Bc, packed, brows, ray_row, self.scale, sig, rgb, C, R, S, P)
+            _C.call("cnr_render_loss", sig, rgb, b["z"], b["gt_depth"], b["gt_rgb"], b["labels"], b["depth_mask"],
+                    5.0, 10.0, inv_w, o["dsig"], o["drgb"], o["depth"], o["var"], o["rgb"], o["opa"], C, R, S,
+                    o["rl_ws"], o["rl_ws"].numel())
         # fused backward: dtrunk, dB, dbiasrows straight into the flat gradient buffer views
         ops.field_bwd(b["pts"], Bc, packed, brows, ray_row, self.scale, o["dsig"], o["drgb"], self.grad_scale,
                       g_trunk, g_B, self.dbias, C, R, S, n_obj, self.bwd_blocks, o["bwd_ws"],
@@ -214,7 +225,8 @@ class FusedCategoryTrainer:
                 o["zl"], self.dbias, self._reg, 0 if self.pg is not None else 1, self.lr, 0.9, 0.999, 1e-8, self.wd,
                 self.d_state2[par], self.d_state2[1 - par], R, o["rl_ws"], self.losses, self.flags,
                 self.pool["depth"], self.pool_rows, self.perm, self.max_bound, R,
-                o["bwd_ws"] if self.fused_tail else None, self._nwg if self.fused_tail else 0, self.rows_fix)
+                o["bwd_ws"] if self.fused_tail else None, self._nwg if self.fused_tail else 0, self.rows_fix,
+                self._rl_blocks)
 
     def step(self):
         """One train step.  Returns nothing; ``self.losses`` (3,C) / ``self.flags`` (C,) hold the device-side

@@ -227,6 +227,21 @@ int cnr_param_prep(const float* theta, int64_t class_stride, int64_t off_trunk, 
                    int64_t off_shape, int64_t off_tex, int L, int n_obj, int C, void* packed, float* zl,
                    float* biasrows, float* zero_buf, int64_t zero_count, void* stream);
 
+/* cnr_field_fwd and cnr_render_loss in ONE launch for S in {32, 64, 96, 128}: a wave owns whole rays (S / 32
+ * consecutive tiles), composites them in registers and writes d_sigmas / d_colors (and the optional renders) instead of
+ * sigmas / colours.  Arguments as the two calls; results agree with them to fp32 summation order (lane sums run over
+ * 32-lane tiles here).  workspace >= cnr_field_fwd_render_workspace_bytes(C, R, S): per-block loss partials for
+ * cnr_render_loss_finish / cnr_step_tail, which must be told rl_blocks = cnr_field_fwd_render_blocks(R, S).
+ * Returns CNR_E_SHAPE for any other S (use the two calls). */
+int cnr_field_fwd_render_blocks(int R, int S);
+int64_t cnr_field_fwd_render_workspace_bytes(int C, int R, int S);
+int cnr_field_fwd_render(const float* pts, const float* B, const void* packed, const float* biasrows,
+                         const int* ray_row, float scale, const float* z, const float* gt_depth, const float* gt_rgb,
+                         const uint8_t* labels, const uint8_t* depth_mask, float color_scaling, float opacity_scaling,
+                         float grad_scale, float* d_sigmas, float* d_colors, float* depth, float* var, float* rgb,
+                         float* opacity, int C, int R, int S, int64_t B_stride, void* workspace,
+                         int64_t workspace_bytes, void* stream);
+
 /* cnr_param_prep and cnr_sample_rays side by side in ONE launch (same arguments, in that order; max_bound must be
  * given here): the sampler needs the ray pool and the step state only, so the first node of the fused trainer's step
  * runs it beside the parameter-only jobs instead of after them. */
@@ -258,7 +273,8 @@ int cnr_render_loss(const float* sigmas, const float* colors, const float* z, co
                     float opacity_scaling, float grad_scale, float* d_sigmas, float* d_colors, float* depth,
                     float* var, float* rgb, float* opacity, int C, int R, int S, void* workspace,
                     int64_t workspace_bytes, void* stream);
-int cnr_render_loss_finish(const void* workspace, float* losses, int32_t* flags, int C, int R, void* stream);
+int cnr_render_loss_finish(const void* workspace, float* losses, int32_t* flags, int C, int R, int rl_blocks,
+                           void* stream);   /* rl_blocks: partials per class, 0 = cnr_render_loss's own count */
 /* Last node of the fused trainer's captured step, one launch: cnr_render_loss_finish, then (next_max_bound !=
  * NULL) cnr_sample_maxdepth for the NEXT step's slice [cursor + add_rows, + R) of the (C,pool_rows) depth pool,
  * then cnr_step_advance(d_state, add_rows).  The next step's cnr_sample_rays reads next_max_bound. */
@@ -290,7 +306,8 @@ int cnr_adamw_epilogue(float* param, const float* grad, float* exp_avg, float* e
  * cnr_field_bwd_pipe(..., skip_reduce = 1): `records` is that call's workspace, nwg =
  * cnr_field_bwd_pipe_blocks(...), and rows_fix the (8, C, n_obj, 4, 32) int64 table that call accumulated (2^-40 fixed
  * point, integer atomics: any order, same sum) -- zero it before every field backward.  dbiasrows then receives the
- * float form of that table. */
+ * float form of that table.
+ * rl_blocks: loss partials per class in rl_workspace; 0 = cnr_render_loss's own block count. */
 int cnr_step_tail(const float* theta_in, float* theta_out, float* grad, float* exp_avg, float* exp_avg_sq,
                   int64_t class_stride, int64_t off_B, int64_t off_latW, int64_t off_latb, int64_t off_shape,
                   int64_t off_tex, int L, int n_obj, int C, const float* zl, float* dbiasrows, float reg_scale,
@@ -298,7 +315,7 @@ int cnr_step_tail(const float* theta_in, float* theta_out, float* grad, float* e
                   const int64_t* state_cur, int64_t* state_next, int64_t add_rows, const void* rl_workspace,
                   float* losses, int32_t* flags, const float* depth, int64_t pool_rows, const int* perm,
                   float* next_max_bound, int R, const void* records, int nwg, const long long* rows_fix,
-                  void* stream);
+                  int rl_blocks, void* stream);
 
 /* Same contract and results as cnr_field_bwd, ONE field kernel + the record reduction: each workgroup is
  * `chain_waves` (2 or 3) waves that run forward recompute + data-gradient chain + PE backward for one 32-sample

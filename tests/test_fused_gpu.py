@@ -261,3 +261,49 @@ def test_fused_backward_vs_fp32_reference(cnr, dev, name, bwd_variant):
     assert rel_l2(out["B"].grad, g.t("grad_B")) < 0.15
     assert rel_l2(out["shape"].grad, g.t("grad_shape_codes")) < 0.15
     assert rel_l2(out["tex"].grad, g.t("grad_texture_codes")) < 0.15
+
+
+@pytest.mark.parametrize("C,R,S,L", [(1, 2048, 64, 256), (2, 333, 32, 32), (1, 500, 128, 256), (1, 64, 96, 32)])
+def test_forward_render_one_launch_equals_two(cnr, dev, C, R, S, L):
+    """cnr_field_fwd_render == cnr_field_fwd -> cnr_render_loss: same f16 forward, same composite expressions; lane
+    sums run over 32-lane tiles instead of 64-lane chunks, hence agreement to fp32 summation order: 1e-6 on the
+    renders, 1e-5 on d colour, 1e-3 on d sigma (d occ_i = T_i g_i - suffix_i / f_i cancels to ~1e-4 of its terms on
+    opaque rays, so the last bit of the suffix sum shows), flags equal, loss values 1e-5."""
+    _C = cnr._C
+    n_obj = 4
+    gen = torch.Generator().manual_seed(R + S)
+    theta, lay = cnr.fused.init_params(C, L, n_obj, gen, dev)
+    v = lay.views(theta)
+    packed = cnr.ops.pack_weights(v["trunk"].contiguous())
+    B = v["B"].contiguous()
+    brows = (torch.randn(C * n_obj, 4, 32, generator=gen) * 0.1).to(dev)
+    ray_row = (torch.randint(0, n_obj, (C, R), generator=gen) + torch.arange(C)[:, None] * n_obj).to(torch.int32).to(dev)
+    pts = (torch.rand(C, R, S, 3, generator=gen) * 2 - 1).to(dev)
+    z = (torch.rand(C, R, S, generator=gen).sort(dim=-1).values * 4 + 0.1).to(dev)
+    gt_d, gt_c = (torch.rand(C, R, generator=gen) * 4).to(dev), torch.rand(C, R, 3, generator=gen).to(dev)
+    labels = torch.randint(0, 3, (C, R), generator=gen).to(torch.uint8).to(dev)
+    dmask = (torch.rand(C, R, generator=gen) > 0.2).to(torch.uint8).to(dev)
+    f = lambda *s: torch.empty(*s, device=dev)
+    sig, rgb = cnr.ops.field_fwd(pts, B, packed, brows, ray_row, 2.0)
+    ws = torch.zeros(_C.render_loss_workspace_bytes(C, R), device=dev, dtype=torch.uint8)
+    ds0, dc0, d0, v0, r0, o0 = f(C, R, S), f(C, R, S, 3), f(C, R), f(C, R), f(C, R, 3), f(C, R)
+    _C.call("cnr_render_loss", sig, rgb, z, gt_d, gt_c, labels, dmask, 5.0, 10.0, 1.0, ds0, dc0, d0, v0, r0, o0, C, R, S,
+            ws, ws.numel())
+    l0, f0 = f(3, C), torch.empty(C, device=dev, dtype=torch.int32)
+    _C.call("cnr_render_loss_finish", ws, l0, f0, C, R, 0)
+
+    nb = int(_C.load().cnr_field_fwd_render_blocks(R, S))
+    assert nb > 0
+    ws1 = torch.zeros(int(_C.load().cnr_field_fwd_render_workspace_bytes(C, R, S)), device=dev, dtype=torch.uint8)
+    ds1, dc1, d1, v1, r1, o1 = f(C, R, S), f(C, R, S, 3), f(C, R), f(C, R), f(C, R, 3), f(C, R)
+    _C.call("cnr_field_fwd_render", pts, B, packed, brows, ray_row, 2.0, z, gt_d, gt_c, labels, dmask, 5.0, 10.0, 1.0,
+            ds1, dc1, d1, v1, r1, o1, C, R, S, 0, ws1, ws1.numel())
+    l1, f1 = f(3, C), torch.empty(C, device=dev, dtype=torch.int32)
+    _C.call("cnr_render_loss_finish", ws1, l1, f1, C, R, nb)
+    assert rel_l2(d1, d0) < 1e-6 and rel_l2(r1, r0) < 1e-6 and rel_l2(o1, o0) < 1e-6 and rel_l2(v1, v0) < 1e-5
+    assert rel_l2(dc1, dc0) < 1e-5 and rel_l2(ds1, ds0) < 1e-3
+    assert torch.equal(f1, f0) and rel_l2(l1, l0) < 1e-5
+    # unsupported S is refused, not mis-computed
+    with pytest.raises(cnr._C.CnrError):
+        _C.call("cnr_field_fwd_render", pts, B, packed, brows, ray_row, 2.0, z, gt_d, gt_c, labels, dmask, 5.0, 10.0, 1.0,
+                ds1, dc1, d1, v1, r1, o1, C, R, 48, 0, ws1, ws1.numel())
