@@ -34,20 +34,31 @@ __device__ __forceinline__ void latent_fwd_block(const float* __restrict__ th, c
 #pragma unroll
   for (int q = 0; q < 4; ++q) tw[q] = trunk[w_off + o2 * ld + p2 * 4 + q];
   const float tb = trunk[b_off + o2];
-  float acc[8];
+  // all 4 + 32 loads of a wave (its code slice and the matching slices of its 8 weight rows) are issued before the
+  // first use: one memory round trip instead of one per output (L <= 256 unrolled; longer codes take the loop)
+  float cv[4], acc[8], lb[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) lb[i] = th[lay.latb + k * 32 + wv + 4 * i];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const int l = lane + 64 * j; cv[j] = l < lay.L ? code[l] : 0.0f; }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int o = wv + 4 * i;
     const float* w = th + lay.latW + ((int64_t)k * 32 + o) * lay.L;
+    float wl[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int l = lane + 64 * j; wl[j] = l < lay.L ? w[l] : 0.0f; }
     float a = 0.0f;
-    for (int l = lane; l < lay.L; l += 64) a = fmaf(code[l], w[l], a);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a = fmaf(cv[j], wl[j], a);
+    for (int l = lane + 256; l < lay.L; l += 64) a = fmaf(code[l], w[l], a);
     acc[i] = a;
   }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int o = wv + 4 * i;
     const float a = wave_sum(acc[i]);
-    if (lane == 0) zs[o] = fmaxf(a + th[lay.latb + k * 32 + o], 0.0f);
+    if (lane == 0) zs[o] = fmaxf(a + lb[i], 0.0f);
   }
   __syncthreads();
   {  // 32 outputs x 32 inputs on 256 threads: 8 lanes per output, 4 inputs each, then an 8-lane sum
@@ -96,8 +107,12 @@ __device__ __forceinline__ void latent_bwd_block(const float* __restrict__ th, c
     for (int t = wv; t < 2 * n_obj; t += 4) {
       const int ob = t % n_obj;
       const float* code = th + (t < n_obj ? lay.shape : lay.tex) + (int64_t)ob * L;
-      float s = 0.0f;
-      for (int l = lane; l < L; l += 64) s = fmaf(code[l], code[l], s);
+      float s = 0.0f, cv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const int l = lane + 64 * j; cv[j] = l < L ? code[l] : 0.0f; }   // loads in flight together
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s = fmaf(cv[j], cv[j], s);
+      for (int l = lane + 256; l < L; l += 64) s = fmaf(code[l], code[l], s);
       s = wave_sum(s);
       if (lane == 0) (t < n_obj ? inv_s : inv_t)[ob] = reg_scale / sqrtf(s);
     }
@@ -118,8 +133,15 @@ __device__ __forceinline__ void latent_bwd_block(const float* __restrict__ th, c
     } else if (t < n1) {
       const int i = t - n0, k = i / (32 * L), r = i % (32 * L), o = r / L, l = r % L;
       float s = 0.0f;
-      for (int ob = 0; ob < n_obj; ++ob)
-        s = fmaf(dpre[(ob * 4 + k) * 32 + o], th[(k == 3 ? lay.tex : lay.shape) + (int64_t)ob * L + l], s);
+      const float* cbase = th + (k == 3 ? lay.tex : lay.shape) + l;
+      for (int ob0 = 0; ob0 < n_obj; ob0 += 4) {   // four objects' loads in flight together (same addition order)
+        float cv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) cv[u] = ob0 + u < n_obj ? cbase[(int64_t)(ob0 + u) * L] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (ob0 + u < n_obj) s = fmaf(dpre[((ob0 + u) * 4 + k) * 32 + o], cv[u], s);
+      }
       sink.latent_set(lay.latW + i, s);
     } else if (t < n2) {
       const int i = t - n1;
