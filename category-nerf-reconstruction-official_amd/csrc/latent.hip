@@ -25,6 +25,7 @@ struct GradStoreSink {
   float* g;  // this class's gradient row
   __device__ __forceinline__ void trunk_add(int idx, float v) const { g[idx] += v; }
   __device__ __forceinline__ void latent_set(int64_t idx, float v) const { g[idx] = v; }
+  __device__ __forceinline__ void prefetch(int64_t) const {}
 };
 __global__ __launch_bounds__(256) void latent_bwd_kernel(const float* __restrict__ theta, FlatLayout lay,
                                                          const float* __restrict__ zl,

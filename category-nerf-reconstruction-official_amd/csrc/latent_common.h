@@ -82,7 +82,8 @@ __device__ __forceinline__ void latent_fwd_block(const float* __restrict__ th, c
 // `sm` (n_obj * 128 + 2 n_obj floats of LDS), then takes its grid-stride share of the concatenated output space
 //   [ d Wt_k[:, :32] and d bt_k : 4*32*33 | d Wl : 4*32*L | d bl : 128 | d shape codes : n_obj*L | d tex codes : n_obj*L ]
 // and hands each value to the sink: trunk_add(index in the class row, v) for the first group (skipped when
-// with_trunk is false), latent_set(index, v) for the rest.  reg_scale * code / ||code|| (src/loss.py:5-15) is
+// with_trunk is false), latent_set(index, v) for the rest -- after prefetch(index) at the start of the element's work,
+// where a sink that needs more than the gradient (AdamW: parameter and moments) can put its loads in flight.  reg_scale * code / ||code|| (src/loss.py:5-15) is
 // included in the code gradients.
 template <class Sink>
 __device__ __forceinline__ void latent_bwd_block(const float* __restrict__ th, const FlatLayout& lay,
@@ -132,6 +133,7 @@ __device__ __forceinline__ void latent_bwd_block(const float* __restrict__ th, c
       sink.trunk_add(j < 32 ? w_off + o * ld + j : b_off + o, s);
     } else if (t < n1) {
       const int i = t - n0, k = i / (32 * L), r = i % (32 * L), o = r / L, l = r % L;
+      sink.prefetch(lay.latW + i);
       float s = 0.0f;
       const float* cbase = th + (k == 3 ? lay.tex : lay.shape) + l;
       for (int ob0 = 0; ob0 < n_obj; ob0 += 4) {   // four objects' loads in flight together (same addition order)
@@ -145,16 +147,19 @@ __device__ __forceinline__ void latent_bwd_block(const float* __restrict__ th, c
       sink.latent_set(lay.latW + i, s);
     } else if (t < n2) {
       const int i = t - n1;
+      sink.prefetch(lay.latb + i);
       float s = 0.0f;
       for (int ob = 0; ob < n_obj; ++ob) s += dpre[ob * 128 + i];
       sink.latent_set(lay.latb + i, s);
     } else if (t < n3) {
       const int i = t - n2, ob = i / L, l = i % L;
+      sink.prefetch(lay.shape + i);
       float s = 0.0f;
       for (int ko = 0; ko < 96; ++ko) s = fmaf(dpre[ob * 128 + ko], th[lay.latW + (int64_t)ko * L + l], s);
       sink.latent_set(lay.shape + i, s + inv_s[ob] * th[lay.shape + i]);
     } else {
       const int i = t - n3, ob = i / L, l = i % L;
+      sink.prefetch(lay.tex + i);
       float s = 0.0f;
       for (int o = 0; o < 32; ++o) s = fmaf(dpre[ob * 128 + 96 + o], th[lay.latW + (int64_t)(96 + o) * L + l], s);
       sink.latent_set(lay.tex + i, s + inv_t[ob] * th[lay.tex + i]);

@@ -49,10 +49,20 @@ __device__ __forceinline__ void adam_one(const TailArgs& a, int64_t e, float g, 
 
 struct AdamSink {  // latent-path gradient element -> gradient buffer (kept for inspection) + AdamW, same thread
   const TailArgs& a; int64_t row0; float step_size, inv_bc2_sqrt;
+  mutable float p0, m0, v0;  // parameter and moments of the element in work, loaded while its gradient is computed
   __device__ __forceinline__ void trunk_add(int, float) const {}
-  __device__ __forceinline__ void latent_set(int64_t idx, float v) const {
-    a.grad[row0 + idx] = v;
-    adam_one(a, row0 + idx, v, step_size, inv_bc2_sqrt);
+  __device__ __forceinline__ void prefetch(int64_t idx) const {
+    p0 = a.theta_in[row0 + idx]; m0 = a.m[row0 + idx]; v0 = a.v[row0 + idx];
+  }
+  __device__ __forceinline__ void latent_set(int64_t idx, float g) const {
+    const int64_t e = row0 + idx;
+    a.grad[e] = g;
+    float pi = p0 * (1.0f - a.lr * a.wd);
+    const float mi = m0 + (g - m0) * (1.0f - a.b1);
+    const float vi = v0 * a.b2 + (1.0f - a.b2) * g * g;
+    const float denom = sqrtf(vi) * inv_bc2_sqrt + a.eps;
+    pi -= step_size * (mi / denom);
+    a.theta_out[e] = pi; a.m[e] = mi; a.v[e] = vi;
   }
 };
 
@@ -111,6 +121,9 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
       // trunk entries and the first dB half own an output; the second dB half is the other addend of the first
       const bool owner = i < TRUNK + 63;
       float s0 = 0.0f, s1 = 0.0f;
+      const int64_t idx = (int64_t)c * P + (i < TRUNK ? i : a.off_B + (i - TRUNK));
+      float p0 = 0.f, m0 = 0.f, v0 = 0.f;
+      if (q == 0 && owner) { p0 = a.theta_in[idx]; m0 = a.m[idx]; v0 = a.v[idx]; }   // in flight under the record sum
       if (owner) {
         const int per = (a.nwg + 3) / 4, w0 = q * per, w1 = min(a.nwg, w0 + per);
         const float* r = a.records + (size_t)c * a.nwg * cnr_rec::REC_FLOATS + i;
@@ -122,10 +135,14 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
       if (q == 0 && owner) {
         float g = (part[e] + part[64 + e]) + (part[128 + e] + part[192 + e]);
         if (i >= TRUNK) g += (part[256 + e] + part[320 + e]) + (part[384 + e] + part[448 + e]);
-        const int64_t idx = (int64_t)c * P + (i < TRUNK ? i : a.off_B + (i - TRUNK));
         if (i < TRUNK) g += latent_trunk_term(i, a.zl + (int64_t)c * a.lay.n_obj * 128, rows, a.lay.n_obj);
         a.grad[idx] = g;
-        adam_one(a, idx, g, step_size, inv_bc2_sqrt);
+        float pi = p0 * (1.0f - a.lr * a.wd);
+        const float mi = m0 + (g - m0) * (1.0f - a.b1);
+        const float vi = v0 * a.b2 + (1.0f - a.b2) * g * g;
+        const float denom = sqrtf(vi) * inv_bc2_sqrt + a.eps;
+        pi -= step_size * (mi / denom);
+        a.theta_out[idx] = pi; a.m[idx] = mi; a.v[idx] = vi;
       }
       return;
     }
