@@ -199,6 +199,11 @@ def main():
                       "rays_per_gpu": C * R, "samples_per_ray": S, "parallelism": f"dp{world}",
                       "hipgraph": ("one graph per state parity" if world == 1 else "two graphs around the all-reduce, per state parity") if not args.no_graph else False, "n_cu": info["n_cu"]},
            "roofline": roofline}
+    if world > 1:   # outside the timed region: every rank must hold bitwise identical parameters after the run
+        try:
+            out["config"]["params_in_sync"] = bool(cnr_amd.parallel.params_in_sync(tr.theta.contiguous(), pg))
+        except Exception as e:      # never lose the bench line over the check
+            out["config"]["params_in_sync"] = f"check failed: {e}"
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline((C, R, n1, n2, L, n_obj), args.cpu_seconds)
