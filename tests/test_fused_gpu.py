@@ -90,6 +90,23 @@ def test_fused_forward_full_size(cnr, dev, C, R, S, L, wscale):
     bar = NORTH_STAR_TOL if wscale == 1.0 else 1e-2
     for k, v in errs.items():
         assert v < bar, (k, v)
+    # the same renders out of the ONE-launch forward + render path the trainer runs (cnr_field_fwd_render)
+    _C = cnr._C
+    mlp_d = {k: d(v) for k, v in mlp.items()}
+    trunk = trunk_blob(cnr, mlp_d)
+    packed = cnr.ops.pack_weights(trunk)
+    brows = cnr.ops.bias_rows(trunk, latent_rows(cnr, mlp_d, d(shape), d(tex))).reshape(C * n_obj, 4, 32)
+    ray_row = (d(idx) + torch.arange(C, device=dev)[:, None] * n_obj).to(torch.int32).contiguous()
+    f = lambda *sh: torch.empty(*sh, device=dev)
+    ws = torch.zeros(int(_C.load().cnr_field_fwd_render_workspace_bytes(C, R, S)), device=dev, dtype=torch.uint8)
+    ds, dc, dep1, var1, rgb1, opa1 = f(C, R, S), f(C, R, S, 3), f(C, R), f(C, R), f(C, R, 3), f(C, R)
+    lab, dm = torch.ones(C, R, device=dev, dtype=torch.uint8), torch.ones(C, R, device=dev, dtype=torch.uint8)
+    _C.call("cnr_field_fwd_render", d(pts), d(B).contiguous(), packed, brows, ray_row, 2.0, d(z), f(C, R).zero_(),
+            f(C, R, 3).zero_(), lab, dm, 5.0, 10.0, 1.0, ds, dc, dep1, var1, rgb1, opa1, C, R, S, 0, ws, ws.numel())
+    errs1 = dict(depth=rel_l2(dep1, depth), rgb=rel_l2(rgb1, rgb), opacity=rel_l2(opa1, opa))
+    print("   one-launch forward + render: " + " ".join(f"{k}={v:.2e}" for k, v in errs1.items()))
+    for k, v in errs1.items():
+        assert v < bar, (k, v)
 
 
 # ---- fused backward ----------------------------------------------------------------------------------
