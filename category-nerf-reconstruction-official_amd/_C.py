@@ -35,7 +35,9 @@ SIGNATURES = {
     "cnr_adamw_step": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i64, _f, _vp, _vp],
     "cnr_pack_bytes": [],
     "cnr_pack_weights": [_vp, _vp, _i, _vp],
-    "cnr_field_fwd": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i64, _vp],
+    "cnr_field_fwd": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i64, _vp, _vp],
+    "cnr_pack_lo_bytes": [],
+    "cnr_pack_weights_lo": [_vp, _vp, _i, _vp],
     "cnr_field_bwd": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i64, _i64, _i64,
                       _i64, _vp],
     "cnr_field_bwd_pipe": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i64, _i64, _i64, _i64, _vp, _i, _vp],
@@ -55,7 +57,7 @@ SIGNATURES = {
     "cnr_field_fwd_render_blocks": [_i, _i],
     "cnr_field_fwd_render_workspace_bytes": [_i, _i, _i],
     "cnr_field_fwd_render": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp,
-                             _vp, _i, _i, _i, _i64, _vp, _i64, _vp],
+                             _vp, _i, _i, _i, _i64, _vp, _i64, _vp, _vp],
     "cnr_param_prep": [_vp, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp],
     "cnr_render_loss_workspace_bytes": [_i, _i],
     "cnr_render_loss": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp,
@@ -63,7 +65,7 @@ SIGNATURES = {
     "cnr_render_loss_finish": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "cnr_step_epilogue": [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i, _i, _vp],
 }
-_RESTYPE64 = {"cnr_pack_bytes", "cnr_field_bwd_workspace_bytes", "cnr_render_loss_workspace_bytes",
+_RESTYPE64 = {"cnr_pack_bytes", "cnr_pack_lo_bytes", "cnr_field_bwd_workspace_bytes", "cnr_render_loss_workspace_bytes",
               "cnr_dense_bwd_workspace_bytes", "cnr_field_fwd_render_workspace_bytes"}
 
 _lib = None

@@ -92,6 +92,18 @@ __device__ __forceinline__ void pack_block(const float* __restrict__ Wt, unsigne
     }
   }
 }
+// residual fragments W - f16(W) (forward orientation only) for the split-weight forward: W x = f16(W) x + lo x, two
+// MFMAs per fragment, removes the weight-rounding share of the f16 error
+__global__ __launch_bounds__(256) void pack_lo_kernel(const float* __restrict__ trunk, unsigned char* __restrict__ lo) {
+  const int c = blockIdx.y, kk = blockIdx.x;
+  const float* Wt = trunk + (size_t)c * TRUNK;
+  _Float16* out = reinterpret_cast<_Float16*>(lo + ((size_t)c * NKK_FWD + kk) * FRAG_BYTES);
+  for (int e = threadIdx.x; e < 64 * 8; e += 256) {
+    const int lane = e >> 3, j = e & 7, r = lane & 31, h = lane >> 5;
+    const float v = fwd_elem(Wt, kk, r, h, j);
+    out[lane * 8 + j] = (_Float16)(v - (float)(_Float16)v);
+  }
+}
 __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ trunk, unsigned char* __restrict__ packed) {
   const int c = blockIdx.y;
   pack_block(trunk + (size_t)c * TRUNK, packed + (size_t)c * PK_BYTES, blockIdx.x);
@@ -133,10 +145,19 @@ __global__ __launch_bounds__(256) void param_prep_kernel(const float* __restrict
 
 namespace {
 
-// One 32-sample tile through PE + the ten layers: this lane's sample is (t0, t1, t2) (already / scale), brow its
+// One 32-sample tile through PE + the ten layers (SPLIT: every weight fragment as f16(W) + f16(W - f16(W))): this lane's sample is (t0, t1, t2) (already / scale), brow its
 // ray's effective bias rows.  Returns the sigma logit BEFORE the x10 (valid in every lane) and leaves the three colour
 // logits in acc[0..2] of lane half 0.
-__device__ __forceinline__ float forward_tile(const unsigned char* smem, const float* cf, const float (&Bh)[33],
+// one weight fragment times one operand fragment: hi part, and in SPLIT mode the residual part on top
+template <bool SPLIT>
+__device__ __forceinline__ f16v mma2(const unsigned char* smem, const unsigned char* smem_lo, int kk, int lane,
+                                     const h8& x, f16v acc) {
+  acc = MFMA(lds_frag(smem, kk, lane), x, acc);
+  if (SPLIT) acc = MFMA(lds_frag(smem_lo, kk, lane), x, acc);
+  return acc;
+}
+template <bool SPLIT>
+__device__ __forceinline__ float forward_tile(const unsigned char* smem, const unsigned char* smem_lo, const float* cf, const float (&Bh)[33],
                                               float t0, float t1, float t2, const float* __restrict__ brow, int lane,
                                               int h, f16v& acc_out) {
   h8 E1f[6], E2f[3];
@@ -145,29 +166,29 @@ __device__ __forceinline__ float forward_tile(const unsigned char* smem, const f
   // L0 encoding_xyz
   f16v acc = acc_init(cf + CF_B_XYZ, h);
 #pragma unroll
-  for (int s = 0; s < 6; ++s) acc = MFMA(lds_frag(smem, KK_XYZ + s, lane), E1f[s], acc);
+  for (int s = 0; s < 6; ++s) acc = mma2<SPLIT>(smem, smem_lo, KK_XYZ + s, lane, E1f[s], acc);
   h8 H0 = pack8(acc, 0, true), H1 = pack8(acc, 1, true);
   // L1 shape_layer_1 (latent slot 0 folded into the bias row)
   acc = acc_init(brow + 0 * 32, h);
-  acc = MFMA(lds_frag(smem, KK_S1 + 0, lane), H0, acc);
-  acc = MFMA(lds_frag(smem, KK_S1 + 1, lane), H1, acc);
+  acc = mma2<SPLIT>(smem, smem_lo, KK_S1 + 0, lane, H0, acc);
+  acc = mma2<SPLIT>(smem, smem_lo, KK_S1 + 1, lane, H1, acc);
   H0 = pack8(acc, 0, true); H1 = pack8(acc, 1, true);
   // L2 cat_layer: [a1 | e1]
   acc = acc_init(brow + 1 * 32, h);
-  acc = MFMA(lds_frag(smem, KK_CAT + 0, lane), H0, acc);
-  acc = MFMA(lds_frag(smem, KK_CAT + 1, lane), H1, acc);
+  acc = mma2<SPLIT>(smem, smem_lo, KK_CAT + 0, lane, H0, acc);
+  acc = mma2<SPLIT>(smem, smem_lo, KK_CAT + 1, lane, H1, acc);
 #pragma unroll
-  for (int s = 0; s < 6; ++s) acc = MFMA(lds_frag(smem, KK_CAT + 2 + s, lane), E1f[s], acc);
+  for (int s = 0; s < 6; ++s) acc = mma2<SPLIT>(smem, smem_lo, KK_CAT + 2 + s, lane, E1f[s], acc);
   H0 = pack8(acc, 0, true); H1 = pack8(acc, 1, true);
   // L3 shape_layer_2
   acc = acc_init(brow + 2 * 32, h);
-  acc = MFMA(lds_frag(smem, KK_S2 + 0, lane), H0, acc);
-  acc = MFMA(lds_frag(smem, KK_S2 + 1, lane), H1, acc);
+  acc = mma2<SPLIT>(smem, smem_lo, KK_S2 + 0, lane, H0, acc);
+  acc = mma2<SPLIT>(smem, smem_lo, KK_S2 + 1, lane, H1, acc);
   H0 = pack8(acc, 0, true); H1 = pack8(acc, 1, true);
   // L4 encoding_shape (no activation)
   acc = acc_init(cf + CF_B_ES, h);
-  acc = MFMA(lds_frag(smem, KK_ES + 0, lane), H0, acc);
-  acc = MFMA(lds_frag(smem, KK_ES + 1, lane), H1, acc);
+  acc = mma2<SPLIT>(smem, smem_lo, KK_ES + 0, lane, H0, acc);
+  acc = mma2<SPLIT>(smem, smem_lo, KK_ES + 1, lane, H1, acc);
   // sigma head in fp32 on the VALU: raw = w_sigma . y4 + b
   float raw;
   {
@@ -180,36 +201,46 @@ __device__ __forceinline__ float forward_tile(const unsigned char* smem, const f
   H0 = pack8(acc, 0, false); H1 = pack8(acc, 1, false);
   // L6 encoding_viewdir: [y4 | e2]
   acc = acc_init(cf + CF_B_VD, h);
-  acc = MFMA(lds_frag(smem, KK_VD + 0, lane), H0, acc);
-  acc = MFMA(lds_frag(smem, KK_VD + 1, lane), H1, acc);
+  acc = mma2<SPLIT>(smem, smem_lo, KK_VD + 0, lane, H0, acc);
+  acc = mma2<SPLIT>(smem, smem_lo, KK_VD + 1, lane, H1, acc);
 #pragma unroll
-  for (int s = 0; s < 3; ++s) acc = MFMA(lds_frag(smem, KK_VD + 2 + s, lane), E2f[s], acc);
+  for (int s = 0; s < 3; ++s) acc = mma2<SPLIT>(smem, smem_lo, KK_VD + 2 + s, lane, E2f[s], acc);
   H0 = pack8(acc, 0, true); H1 = pack8(acc, 1, true);
   // L7 texture_layer_1
   acc = acc_init(brow + 3 * 32, h);
-  acc = MFMA(lds_frag(smem, KK_T1 + 0, lane), H0, acc);
-  acc = MFMA(lds_frag(smem, KK_T1 + 1, lane), H1, acc);
+  acc = mma2<SPLIT>(smem, smem_lo, KK_T1 + 0, lane, H0, acc);
+  acc = mma2<SPLIT>(smem, smem_lo, KK_T1 + 1, lane, H1, acc);
   H0 = pack8(acc, 0, true); H1 = pack8(acc, 1, true);
   // L8 rgb.0 (16 outputs = rows 0..15 = registers 0..7)
   acc = acc_init(cf + CF_B_R0, h);
-  acc = MFMA(lds_frag(smem, KK_R0 + 0, lane), H0, acc);
-  acc = MFMA(lds_frag(smem, KK_R0 + 1, lane), H1, acc);
+  acc = mma2<SPLIT>(smem, smem_lo, KK_R0 + 0, lane, H0, acc);
+  acc = mma2<SPLIT>(smem, smem_lo, KK_R0 + 1, lane, H1, acc);
   H0 = pack8(acc, 0, true);
   // L9 rgb.2 (3 outputs = rows 0..2 = registers 0..2 of half 0)
   acc = acc_init(cf + CF_B_R2, h);
-  acc = MFMA(lds_frag(smem, KK_R2, lane), H0, acc);
+  acc = mma2<SPLIT>(smem, smem_lo, KK_R2, lane, H0, acc);
   acc_out = acc;
   return raw;
 }
 
+constexpr int LDS_LO_OFF = (PK_OFF_BWD + 66 * 4 + 8 + 15) / 16 * 16;  // residual fragments behind the [2][33] B rows
+// stage the residual fragments of class c (split-weight mode)
+__device__ __forceinline__ void stage_lo(unsigned char* smem, const unsigned char* __restrict__ packed_lo, int c) {
+  const unsigned char* src = packed_lo + (size_t)c * NKK_FWD * FRAG_BYTES;
+  for (int i = threadIdx.x * 16; i < NKK_FWD * FRAG_BYTES; i += 256 * 16)
+    *reinterpret_cast<f4*>(smem + LDS_LO_OFF + i) = *reinterpret_cast<const f4*>(src + i);
+}
+
+template <bool SPLIT>
 __global__ __launch_bounds__(256, 4) void field_fwd_kernel(
     const float* __restrict__ pts, const float* __restrict__ Bdir, const unsigned char* __restrict__ packed,
     const float* __restrict__ biasrows, const int* __restrict__ ray_row, float inv_scale,
     float* __restrict__ sigmas, float* __restrict__ rgbs, int64_t N /* samples per class */, int S, int R,
-    int64_t B_stride) {
+    int64_t B_stride, const unsigned char* __restrict__ packed_lo) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int c = blockIdx.y;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, h = lane >> 5, col = lane & 31;
+  if (SPLIT) stage_lo(smem, packed_lo, c);
   // stage forward fragments + constants + this class's direction matrix into LDS
   {
     const unsigned char* src = packed + (size_t)c * PK_BYTES;
@@ -244,7 +275,7 @@ __global__ __launch_bounds__(256, 4) void field_fwd_kernel(
     const float* brow = biasrows + row * (CNR_NLAT * 32);
 
     f16v acc;
-    const float raw = forward_tile(smem, cf, Bh, t0, t1, t2, brow, lane, h, acc);
+    const float raw = forward_tile<SPLIT>(smem, smem + LDS_LO_OFF, cf, Bh, t0, t1, t2, brow, lane, h, acc);
     if (live && h == 0) {
       sigmas[gs] = raw * 10.0f;
       float* o = rgbs + gs * 3;
@@ -263,7 +294,7 @@ __global__ __launch_bounds__(256, 4) void field_fwd_kernel(
 // render_loss.hip; sums over lanes run over 32-lane tiles instead of 64-lane chunks, so the results agree to summation
 // order, not bitwise.  grid (blocks, C); block b of class c writes loss partial (c, b) -- nb = gridDim.x for
 // finish_class.
-template <int K>
+template <int K, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void field_fwd_render_kernel(
     const float* __restrict__ pts, const float* __restrict__ Bdir, const unsigned char* __restrict__ packed,
     const float* __restrict__ biasrows, const int* __restrict__ ray_row, float inv_scale, const float* __restrict__ z,
@@ -271,9 +302,10 @@ __global__ __launch_bounds__(256, 2) void field_fwd_render_kernel(
     const uint8_t* __restrict__ depth_mask, float color_scaling, float opacity_scaling, float grad_scale,
     float* __restrict__ d_sigmas, float* __restrict__ d_colors, float* __restrict__ depth_out,
     float* __restrict__ var_out, float* __restrict__ rgb_out, float* __restrict__ opacity_out, int C, int R,
-    int64_t B_stride, float* __restrict__ partials) {
+    int64_t B_stride, float* __restrict__ partials, const unsigned char* __restrict__ packed_lo) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ float cnt[12];
+  if (SPLIT) stage_lo(smem, packed_lo, blockIdx.y);
   constexpr int S = 32 * K;
   const int c = blockIdx.y;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, h = lane >> 5, col = lane & 31;
@@ -345,8 +377,8 @@ __global__ __launch_bounds__(256, 2) void field_fwd_render_kernel(
       const int64_t gs = ray * S + t * 32 + col;
       const float* pp = pts + gs * 3;
       f16v acc;
-      const float raw = forward_tile(smem, cf, Bh, pp[0] * inv_scale, pp[1] * inv_scale, pp[2] * inv_scale, brow, lane,
-                                     h, acc);
+      const float raw = forward_tile<SPLIT>(smem, smem + LDS_LO_OFF, cf, Bh, pp[0] * inv_scale, pp[1] * inv_scale,
+                                            pp[2] * inv_scale, brow, lane, h, acc);
       // composite of this tile (lane half 0 = the 32 samples; half 1 neutral)
       occ[t] = h == 0 ? 1.0f / (1.0f + expf(-(raw * 10.0f))) : 0.0f;
       c0[t] = 1.0f / (1.0f + __expf(-acc[0])); c1[t] = 1.0f / (1.0f + __expf(-acc[1]));
@@ -453,7 +485,8 @@ extern "C" int cnr_field_fwd_render(const float* pts, const float* B, const void
                                     const float* gt_rgb, const uint8_t* labels, const uint8_t* depth_mask,
                                     float color_scaling, float opacity_scaling, float grad_scale, float* d_sigmas,
                                     float* d_colors, float* depth, float* var, float* rgb, float* opacity, int C, int R,
-                                    int S, int64_t B_stride, void* workspace, int64_t workspace_bytes, void* stream) {
+                                    int S, int64_t B_stride, void* workspace, int64_t workspace_bytes,
+                                    const void* packed_lo, void* stream) {
   if (!pts || !B || !packed || !biasrows || !z || !gt_depth || !gt_rgb || !labels || !depth_mask || !d_sigmas ||
       !d_colors || !workspace || C <= 0 || R <= 0 || !(scale > 0.f))
     return CNR_E_ARG;
@@ -461,18 +494,33 @@ extern "C" int cnr_field_fwd_render(const float* pts, const float* B, const void
   if (!nb) return CNR_E_SHAPE;
   if (workspace_bytes < cnr_field_fwd_render_workspace_bytes(C, R, S)) return CNR_E_ARG;
   if (((uintptr_t)packed & 15) != 0 || ((uintptr_t)biasrows & 15) != 0) return CNR_E_ALIGN;
-  const size_t lds = (size_t)fz::PK_OFF_BWD + 66 * sizeof(float) + 8;
+  const size_t lds = packed_lo ? (size_t)LDS_LO_OFF + fz::NKK_FWD * fz::FRAG_BYTES
+                               : (size_t)fz::PK_OFF_BWD + 66 * sizeof(float) + 8;
   dim3 grid((unsigned)nb, (unsigned)C);
-#define CNR_FFR(KK)                                                                                                 \
-  hipLaunchKernelGGL((field_fwd_render_kernel<KK>), grid, dim3(256), lds, (hipStream_t)stream, pts, B,               \
-                     (const unsigned char*)packed, biasrows, ray_row, 1.0f / scale, z, gt_depth, gt_rgb, labels,     \
-                     depth_mask, color_scaling, opacity_scaling, grad_scale, d_sigmas, d_colors, depth, var, rgb,    \
-                     opacity, C, R, B_stride > 0 ? B_stride : (int64_t)63, (float*)workspace)
-  switch (S / 32) {
-    case 1: CNR_FFR(1); break;
-    case 2: CNR_FFR(2); break;
-    case 3: CNR_FFR(3); break;
-    default: CNR_FFR(4); break;
+#define CNR_FFR(KK, SP)                                                                                             \
+  do {                                                                                                              \
+    if (SP) (void)hipFuncSetAttribute((const void*)field_fwd_render_kernel<KK, SP>,                                 \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
+    hipLaunchKernelGGL((field_fwd_render_kernel<KK, SP>), grid, dim3(256), lds, (hipStream_t)stream, pts, B,         \
+                       (const unsigned char*)packed, biasrows, ray_row, 1.0f / scale, z, gt_depth, gt_rgb, labels,   \
+                       depth_mask, color_scaling, opacity_scaling, grad_scale, d_sigmas, d_colors, depth, var, rgb,  \
+                       opacity, C, R, B_stride > 0 ? B_stride : (int64_t)63, (float*)workspace,                      \
+                       (const unsigned char*)packed_lo);                                                            \
+  } while (0)
+  if (packed_lo) {
+    switch (S / 32) {
+      case 1: CNR_FFR(1, true); break;
+      case 2: CNR_FFR(2, true); break;
+      case 3: CNR_FFR(3, true); break;
+      default: CNR_FFR(4, true); break;
+    }
+  } else {
+    switch (S / 32) {
+      case 1: CNR_FFR(1, false); break;
+      case 2: CNR_FFR(2, false); break;
+      case 3: CNR_FFR(3, false); break;
+      default: CNR_FFR(4, false); break;
+    }
   }
 #undef CNR_FFR
   CNR_LAUNCH_CHECK();
@@ -533,9 +581,19 @@ extern "C" int cnr_step_prologue(
   return CNR_OK;
 }
 
+extern "C" int64_t cnr_pack_lo_bytes() { return (int64_t)fz::NKK_FWD * fz::FRAG_BYTES; }
+extern "C" int cnr_pack_weights_lo(const float* trunk, void* packed_lo, int C, void* stream) {
+  if (!trunk || !packed_lo || C <= 0) return CNR_E_ARG;
+  if (((uintptr_t)packed_lo & 15) != 0) return CNR_E_ALIGN;
+  hipLaunchKernelGGL(pack_lo_kernel, dim3(fz::NKK_FWD, (unsigned)C), dim3(256), 0, (hipStream_t)stream, trunk,
+                     (unsigned char*)packed_lo);
+  CNR_LAUNCH_CHECK();
+  return CNR_OK;
+}
+
 extern "C" int cnr_field_fwd(const float* pts, const float* B, const void* packed, const float* biasrows,
                              const int* ray_row, float scale, float* sigmas, float* rgbs, int C, int R, int S,
-                             int64_t B_stride, void* stream) {
+                             int64_t B_stride, const void* packed_lo, void* stream) {
   if (!pts || !B || !packed || !biasrows || !sigmas || !rgbs || C <= 0 || R <= 0 || S <= 0 || !(scale > 0.f))
     return CNR_E_ARG;
   if (((uintptr_t)packed & 15) != 0 || ((uintptr_t)biasrows & 15) != 0) return CNR_E_ALIGN;
@@ -544,11 +602,23 @@ extern "C" int cnr_field_fwd(const float* pts, const float* B, const void* packe
   int64_t blocks = (ntiles + 3) / 4;
   static const int64_t cap = getenv("CNR_FWD_BLOCKS") ? atoll(getenv("CNR_FWD_BLOCKS")) : 2048;
   if (blocks > cap) blocks = cap;
-  const size_t lds = (size_t)fz::PK_OFF_BWD + 66 * sizeof(float) + 8;
+  const size_t lds = packed_lo ? (size_t)LDS_LO_OFF + fz::NKK_FWD * fz::FRAG_BYTES
+                               : (size_t)fz::PK_OFF_BWD + 66 * sizeof(float) + 8;
   dim3 grid((unsigned)blocks, (unsigned)C);
-  hipLaunchKernelGGL(field_fwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, pts, B,
-                     (const unsigned char*)packed, biasrows, ray_row, 1.0f / scale, sigmas, rgbs, N, S, R,
-                     B_stride > 0 ? B_stride : (int64_t)63);
+  if (packed_lo) {
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void*)field_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr = true;
+    }
+    hipLaunchKernelGGL(field_fwd_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, pts, B,
+                       (const unsigned char*)packed, biasrows, ray_row, 1.0f / scale, sigmas, rgbs, N, S, R,
+                       B_stride > 0 ? B_stride : (int64_t)63, (const unsigned char*)packed_lo);
+  } else {
+    hipLaunchKernelGGL(field_fwd_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, pts, B,
+                       (const unsigned char*)packed, biasrows, ray_row, 1.0f / scale, sigmas, rgbs, N, S, R,
+                       B_stride > 0 ? B_stride : (int64_t)63, (const unsigned char*)nullptr);
+  }
   CNR_LAUNCH_CHECK();
   return CNR_OK;
 }

@@ -12,6 +12,7 @@ texture_latent_layer_1 (include/cnr_hip.h).  ``state_dicts()`` exports reference
 (src/scene_cateogries.py:548-571 checkpoint keys).
 """
 import math
+import os
 
 import torch
 
@@ -75,7 +76,7 @@ class FusedCategoryTrainer:
 
     def __init__(self, cfg, n_cls, n_obj, pools, rays_per_step, device, seed=0, generator=None,
                  grad_scale=None, bwd_blocks=0, process_group=None, use_graph=True, split_graph=False,
-                 fuse_render=True):
+                 fuse_render=True, split_weights=None):
         self.cfg, self.C, self.n_obj, self.R = cfg, n_cls, n_obj, rays_per_step
         self.device = torch.device(device)
         self.n1, self.n2 = cfg.n_bins_cam2surface, cfg.n_bins
@@ -125,6 +126,10 @@ class FusedCategoryTrainer:
         self.dbias = self._gbuf[n_th:n_th + n_db].view(n_cls * n_obj, 4, 32)
         self._nwg = int(_C.load().cnr_field_bwd_pipe_blocks(self.R, self.S, int(ops.FIELD_BWD_VARIANT[-1]), self.bwd_blocks)) \
             if self.fused_tail else 0
+        # split-weight forward (f16(W) + f16(W - f16(W)), two MFMAs per fragment): occupancy error 6.7e-4 -> 3.9e-4 at
+        # configs[1] for +2.7 us per step; off by default, CNR_SPLIT_WEIGHTS=1 or split_weights=True turns it on
+        self.split_weights = bool(int(os.environ.get("CNR_SPLIT_WEIGHTS", "0"))) if split_weights is None \
+            else bool(split_weights)
         # forward + render/loss in one launch where the shape allows (S a multiple of 32 up to 128), else two launches
         self._rl_blocks = int(_C.load().cnr_field_fwd_render_blocks(self.R, self.S)) if fuse_render else 0
         self.use_graph = use_graph
@@ -190,17 +195,23 @@ class FusedCategoryTrainer:
                               self.max_bound,
                               self.pool["indices"], self.perm)
         ray_row = b["ray_row"]
+        lo = None
+        if self.split_weights:
+            if "packed_lo" not in o:
+                o["packed_lo"] = torch.empty(C, int(_C.load().cnr_pack_lo_bytes()), device=self.device, dtype=torch.uint8)
+            lo = o["packed_lo"]
+            _C.call("cnr_pack_weights_lo", v["trunk"] if C == 1 else v["trunk"].contiguous(), lo, C)
         inv_w = 1.0 / self.world
         if self._rl_blocks:
             # a8-a15 in one launch (S = 32 k): field forward, composite, losses, their gradient, composite backward;
             # sigma / colour per sample never leave registers
             _C.call("cnr_field_fwd_render", b["pts"], Bc, packed, brows, ray_row, self.scale, b["z"], b["gt_depth"],
                     b["gt_rgb"], b["labels"], b["depth_mask"], 5.0, 10.0, inv_w, o["dsig"], o["drgb"], o["depth"],
-                    o["var"], o["rgb"], o["opa"], C, R, S, P, o["rl_ws"], o["rl_ws"].numel())
+                    o["var"], o["rgb"], o["opa"], C, R, S, P, o["rl_ws"], o["rl_ws"].numel(), lo)
         else:
             # a8 + a9 fused forward, then a11-a15 in one launch
             sig, rgb = o["sig"], o["rgbs"]
-            _C.call("cnr_field_fwd", b["pts"], Bc, packed, brows, ray_row, self.scale, sig, rgb, C, R, S, P)
+            _C.call("cnr_field_fwd", b["pts"], Bc, packed, brows, ray_row, self.scale, sig, rgb, C, R, S, P, lo)
             _C.call("cnr_render_loss", sig, rgb, b["z"], b["gt_depth"], b["gt_rgb"], b["labels"], b["depth_mask"],
                     5.0, 10.0, inv_w, o["dsig"], o["drgb"], o["depth"], o["var"], o["rgb"], o["opa"], C, R, S,
                     o["rl_ws"], o["rl_ws"].numel())

@@ -381,13 +381,22 @@ def field_bwd(pts, B, packed, biasrows, ray_row, scale, d_sig, d_rgb, grad_scale
         raise ValueError(f"unknown cnr_field_bwd variant {v!r}")
 
 
-def field_fwd(pts, B, packed, biasrows, ray_row, scale):
-    """pts (C,R,S,3) -> sigmas (C,R,S), rgbs (C,R,S,3); biasrows (rows,4,32) flat over classes."""
+def pack_weights_lo(trunk):
+    """residual fragments W - f16(W) for the split-weight forward: (C, cnr_pack_lo_bytes()) uint8"""
+    C = trunk.shape[0]
+    lo = torch.empty(C, int(_C.load().cnr_pack_lo_bytes()), device=trunk.device, dtype=torch.uint8)
+    _C.call("cnr_pack_weights_lo", trunk.contiguous(), lo, C)
+    return lo
+
+
+def field_fwd(pts, B, packed, biasrows, ray_row, scale, packed_lo=None):
+    """pts (C,R,S,3) -> sigmas (C,R,S), rgbs (C,R,S,3); biasrows (rows,4,32) flat over classes.
+    packed_lo (pack_weights_lo): split-weight mode, f16(W) + f16(W - f16(W))."""
     C, R, S, _ = pts.shape
     sig = torch.empty(C, R, S, device=pts.device, dtype=torch.float32)
     rgb = torch.empty(C, R, S, 3, device=pts.device, dtype=torch.float32)
     _C.call("cnr_field_fwd", pts.contiguous(), B.contiguous(), packed, biasrows.contiguous(), ray_row,
-            float(scale), sig, rgb, C, R, S, 0)
+            float(scale), sig, rgb, C, R, S, 0, packed_lo)
     return sig, rgb
 
 

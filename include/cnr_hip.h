@@ -166,12 +166,20 @@ int cnr_pack_weights(const float* trunk, void* packed, int C, void* stream);
 
 /* pts (C,R,S,3), B (C,21,3), packed (C,cnr_pack_bytes()), biasrows (rows,4,32) -> sigmas (C,R,S) = raw*10,
  * rgbs (C,R,S,3).  f16 MFMA operands / fp32 accumulate, fp32 PE, fp32 sigma head.  Any S. */
+/* Split-weight forward (packed_lo != NULL in cnr_field_fwd / cnr_field_fwd_render): every weight fragment is used as
+ * f16(W) + f16(W - f16(W)), two MFMAs, which removes the weight-rounding share of the f16 error (activations stay
+ * f16).  packed_lo: (C, cnr_pack_lo_bytes()) from cnr_pack_weights_lo(trunk (C,13892), ...).  The backward kernels
+ * recompute with f16(W) alone. */
+int64_t cnr_pack_lo_bytes(void);
+int cnr_pack_weights_lo(const float* trunk, void* packed_lo, int C, void* stream);
+
 /* Class strides (floats; 0 = dense): B_stride between the (21,3) direction matrices of consecutive classes,
  * dtrunk_stride / dB_stride between the per-class gradient blocks -- so that B, dtrunk and dB may be views of a flat
  * (C, P) parameter / gradient buffer (the fused trainer's layout) with no gather or scatter copies. */
 int cnr_field_fwd(const float* pts, const float* B, const void* packed, const float* biasrows,
                   const int* ray_row, float scale, float* sigmas, float* rgbs, int C, int R, int S,
-                  int64_t B_stride, void* stream);
+                  int64_t B_stride, const void* packed_lo,
+                  void* stream);
 
 /* Backward of cnr_field_fwd (recomputes the forward per tile): d_sigma (C,R,S) = dL/dsigmas,
  * d_rgb (C,R,S,3) -> dtrunk (C,13892), dB (C,21,3), dbiasrows (rows,4,32); all three ACCUMULATED
@@ -240,7 +248,7 @@ int cnr_field_fwd_render(const float* pts, const float* B, const void* packed, c
                          const uint8_t* labels, const uint8_t* depth_mask, float color_scaling, float opacity_scaling,
                          float grad_scale, float* d_sigmas, float* d_colors, float* depth, float* var, float* rgb,
                          float* opacity, int C, int R, int S, int64_t B_stride, void* workspace,
-                         int64_t workspace_bytes, void* stream);
+                         int64_t workspace_bytes, const void* packed_lo, void* stream);
 
 /* cnr_param_prep and cnr_sample_rays side by side in ONE launch (same arguments, in that order; max_bound must be
  * given here): the sampler needs the ray pool and the step state only, so the first node of the fused trainer's step

@@ -203,3 +203,23 @@ def test_prologue_and_epilogue_launches_equal_their_parts(cnr, dev):
     for x, y in zip(*outs):
         assert torch.equal(x, y)
     assert outs[1][6].tolist() == [4 * R, 8, 12]
+
+
+def test_split_weight_trainer_runs_and_tracks_default(cnr, dev):
+    """split_weights=True (forward with f16(W) + f16(W - f16(W))): same trajectory as the default trainer to the f16
+    level (the losses of the first steps agree to 2e-3), graph capture included."""
+    cfg = cnr.cfg.synthetic_config(device=str(dev), latent_dim=256, n_bins_cam2surface=8, n_bins=56)
+    out = []
+    for sw in (False, True):
+        gen = torch.Generator().manual_seed(31)
+        pools = [cnr.scene_cateogries.synthetic_pool(16 * 256, 4, gen, "cpu")]
+        torch.cuda.manual_seed(77)
+        tr = cnr.fused.FusedCategoryTrainer(cfg, 1, 4, pools, 256, dev, seed=3, generator=gen, split_weights=sw)
+        hist = []
+        for _ in range(6):
+            tr.step()
+            hist.append(tr.losses.clone())
+        torch.cuda.synchronize()
+        out.append(torch.stack(hist).cpu())
+    assert torch.isfinite(out[1]).all()
+    assert rel_l2(out[1], out[0]) < 2e-3 and not torch.equal(out[1], out[0])

@@ -33,7 +33,7 @@ def run(C, R, S, blocks, iters=50):
         for _ in range(iters): fn()
         b.record(); torch.cuda.synchronize()
         return a.elapsed_time(b) / iters * 1e3
-    fwd = t(lambda: _C.call("cnr_field_fwd", pts, B, packed, brows, ray_row, 2.0, sig, rgb, C, R, S, 0))
+    fwd = t(lambda: _C.call("cnr_field_fwd", pts, B, packed, brows, ray_row, 2.0, sig, rgb, C, R, S, 0, None))
     n = C * R * S
     line = f"C{C} R{R} S{S} blocks{blocks}: fwd {fwd:8.1f} us ({n*27422/fwd/1e6:7.1f} TF)"
     ref = None

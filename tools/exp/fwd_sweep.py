@@ -13,7 +13,7 @@ for R, S in ((2048, 64), (8192, 128)):
     pts = torch.rand(C, R, S, 3, device=dev) * 2 - 1
     ray_row = torch.randint(0, n_obj, (C, R), device=dev).to(torch.int32)
     sig = torch.empty(C, R, S, device=dev); rgb = torch.empty(C, R, S, 3, device=dev)
-    fn = lambda: _C.call("cnr_field_fwd", pts, B, packed, brows, ray_row, 2.0, sig, rgb, C, R, S, 0)
+    fn = lambda: _C.call("cnr_field_fwd", pts, B, packed, brows, ray_row, 2.0, sig, rgb, C, R, S, 0, None)
     for _ in range(5): fn()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -23,6 +23,6 @@ dtrunk = torch.zeros(C, 13892, device=dev); dB = torch.zeros(C, 21, 3, device=de
 wsp = torch.empty(_C.field_bwd_workspace_bytes(C, 0), device=dev, dtype=torch.uint8)
 sig = torch.empty(C, R, S, device=dev); rgb = torch.empty(C, R, S, 3, device=dev)
 for _ in range(10):
-    _C.call("cnr_field_fwd", pts, B, packed, brows, ray_row, 2.0, sig, rgb, C, R, S, 0)
+    _C.call("cnr_field_fwd", pts, B, packed, brows, ray_row, 2.0, sig, rgb, C, R, S, 0, None)
     ops.field_bwd(pts, B, packed, brows, ray_row, 2.0, dsig, drgb, 2048.0, dtrunk, dB, dbr, C, R, S, n_obj, blocks, wsp)
 torch.cuda.synchronize()
