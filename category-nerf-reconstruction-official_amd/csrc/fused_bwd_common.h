@@ -4,6 +4,7 @@
 #pragma once
 #include "fused_common.h"
 #include "records_common.h"
+#include <type_traits>
 
 namespace {   // internal linkage: each backward translation unit gets its own copy (incl. the device table)
 using namespace fz;
@@ -43,6 +44,31 @@ __device__ __forceinline__ void load_h(const unsigned char* img, h8& f0, h8& f1,
   f0.hi = *reinterpret_cast<const h4*>(base + 16);
   f1.lo = *reinterpret_cast<const h4*>(base + 32);
   f1.hi = *reinterpret_cast<const h4*>(base + 48);
+}
+// Swizzled form of the same image for the 8-wave kernels: unpadded 64-byte rows, the 8-byte chunk c of row r stored at
+// chunk c ^ ((r >> 1) & 7).  A transposing read's 32-lane half covers 4 consecutive rows x 64 B = all 64 banks once
+// (the padded form wraps after 3.5 rows: 2-way), and a ds_write_b64's 16-lane group (16 rows, one logical chunk)
+// lands on 16 different bank pairs of the 32 store banks.
+constexpr int HSIMG_BYTES = 32 * 64;
+__device__ __forceinline__ void stage_hs(unsigned char* img, const h8& f0, const h8& f1, int col, int h) {
+  unsigned char* row = img + col * 64;
+  const int sw = (col >> 1) & 7;
+  *reinterpret_cast<h4*>(row + (((0 + h) ^ sw) << 3)) = f0.lo;
+  *reinterpret_cast<h4*>(row + (((2 + h) ^ sw) << 3)) = f0.hi;
+  *reinterpret_cast<h4*>(row + (((4 + h) ^ sw) << 3)) = f1.lo;
+  *reinterpret_cast<h4*>(row + (((6 + h) ^ sw) << 3)) = f1.hi;
+}
+__device__ __forceinline__ h8 tr_frag_hs(const unsigned char* img, int s, int lane) {
+  const int i = lane & 15, g16 = lane >> 4, q = i >> 2, p = i & 3, hh = g16 >> 1;
+  const int r = 16 * s + 8 * hh + q, chunk = 4 * (g16 & 1) + p;
+  typedef __attribute__((address_space(3))) s4v* lds_s4;
+  const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(img + r * 64 + ((chunk ^ ((r >> 1) & 7)) << 3)));
+  const s4v hi =
+      __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(img + (r + 4) * 64 + ((chunk ^ (((r + 4) >> 1) & 7)) << 3)));
+  h8 out;
+  out.lo = __builtin_bit_cast(h4, lo);
+  out.hi = __builtin_bit_cast(h4, hi);
+  return out;
 }
 // transposing read: operand fragment (feature = col0 + (lane & 31), k = sample 16 s + 8 h + j)
 __device__ __forceinline__ h8 tr_frag(const unsigned char* img, int stride, int col0, int s, int lane) {
@@ -166,6 +192,40 @@ __global__ __launch_bounds__(256) void reduce_records_kernel(const float* __rest
     else if (i < TRUNK + 126) atomicAdd(&dB[(size_t)c * st_B + (i - TRUNK - 63)], v);
     else dbiasrows[(size_t)c * rows_per_class * 128 + (i - (TRUNK + 126))] += v;
   }
+}
+
+// ---- shared by the pipelined kernels (fused_bwd_pipe.hip, fused_bwd_pipe8.hip) ------------------------------------
+template <int V> using IC = std::integral_constant<int, V>;
+enum Step { ST_R2, ST_R0, ST_T1, ST_VD, ST_ES, ST_S2, ST_CAT, ST_S1, ST_XYZ, NSTEPS };
+
+// f16 pack of the 8 accumulator registers of k-step s, zeroed where the (post-ReLU, hence non-negative) activation
+// is zero.  Three packed-integer VALU ops per register pair -- min(act, 1) per half, times 0xFFFF, and -- written as
+// inline asm: from the portable vector form hipcc builds a compare / select / shift / permute sequence per element
+// (9 instructions and VCC wait states per pair; these masks are on every backward step's critical path).
+typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+// 0xFFFF per half where the activation is non-zero.  Only depends on the forward: the backward steps compute the
+// mask of the NEXT step before their barrier, so that after the barrier a step is MFMA -> cvt -> and -> store.
+__device__ __forceinline__ u4v relu_mask(const h8& act) {
+  const u4v av = __builtin_bit_cast(u4v, act);
+  u4v m;
+  const unsigned int ones = 0x00010001u;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    unsigned int t;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(t) : "v"(av[i]), "s"(ones));
+    asm("v_pk_mul_lo_u16 %0, %1, -1" : "=v"(t) : "v"(t));
+    m[i] = t;
+  }
+  return m;
+}
+__device__ __forceinline__ h8 pack8_and(const f16v& a, int s, const u4v& m) {
+  return __builtin_bit_cast(h8, (u4v)(__builtin_bit_cast(u4v, pack8(a, s, false)) & m));
+}
+__device__ __forceinline__ h8 pack8_masked(const f16v& a, int s, const h8& act) { return pack8_and(a, s, relu_mask(act)); }
+__device__ __forceinline__ void role_barrier() {  // every wave of the workgroup executes the same number of these
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
 }  // namespace

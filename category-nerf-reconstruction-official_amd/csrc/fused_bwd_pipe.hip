@@ -12,7 +12,6 @@
 // Synchronisation is s_barrier only (10 per iteration, both roles run the same trip count): no flags, no polling.
 // The two roles are separate loops (the register allocator then sees max(roles), not their sum).
 #include "fused_bwd_common.h"
-#include <type_traits>
 
 namespace {
 
@@ -44,43 +43,11 @@ __device__ long long g_pipe_stamps[160];
 #endif
 #define PSYNC() do { PSTAMP(); role_barrier(); PSTAMP(); } while (0)
 
-template <int V> using IC = std::integral_constant<int, V>;
-enum Step { ST_R2, ST_R0, ST_T1, ST_VD, ST_ES, ST_S2, ST_CAT, ST_S1, ST_XYZ, NSTEPS };
-
-// f16 pack of the 8 accumulator registers of k-step s, zeroed where the (post-ReLU, hence non-negative) activation
-// is zero.  Three packed-integer VALU ops per register pair -- min(act, 1) per half, times 0xFFFF, and -- written as
-// inline asm: from the portable vector form hipcc builds a compare / select / shift / permute sequence per element
-// (9 instructions and VCC wait states per pair; these masks are on every backward step's critical path).
-typedef unsigned int u4v __attribute__((ext_vector_type(4)));
-// 0xFFFF per half where the activation is non-zero.  Only depends on the forward: the backward steps compute the
-// mask of the NEXT step before their barrier, so that after the barrier a step is MFMA -> cvt -> and -> store.
-__device__ __forceinline__ u4v relu_mask(const h8& act) {
-  const u4v av = __builtin_bit_cast(u4v, act);
-  u4v m;
-  const unsigned int ones = 0x00010001u;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    unsigned int t;
-    asm("v_pk_min_u16 %0, %1, %2" : "=v"(t) : "v"(av[i]), "s"(ones));
-    asm("v_pk_mul_lo_u16 %0, %1, -1" : "=v"(t) : "v"(t));
-    m[i] = t;
-  }
-  return m;
-}
-__device__ __forceinline__ h8 pack8_and(const f16v& a, int s, const u4v& m) {
-  return __builtin_bit_cast(h8, (u4v)(__builtin_bit_cast(u4v, pack8(a, s, false)) & m));
-}
-__device__ __forceinline__ h8 pack8_masked(const f16v& a, int s, const h8& act) { return pack8_and(a, s, relu_mask(act)); }
 // (Tried: the chain role's MFMAs as inline asm in VGPR form -- a 512-register kernel gets AGPR-form MFMAs, which costs
 //  the chain role 16 v_accvgpr_read per layer.  With each layer's chain as one asm statement and hand-written wait
 //  states it passed the parity tests and gained 2 % (288.8 -> 282.8 us at 8192 x 128): not worth carrying hazard
 //  rules the compiler cannot check.  The chain role is bound by per-step dependent latency -- MFMA result -> mask /
 //  pack -> image store -> barrier, ~700 cycles for ~40 instructions -- not by instruction count.)
-__device__ __forceinline__ void role_barrier() {  // every wave of the workgroup executes the same number of these
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
 
 template <int NCH>
 __global__ __launch_bounds__(256, 1) void field_bwd_pipe_kernel(
@@ -637,8 +604,16 @@ extern "C" int cnr_pipe_read_stamps(long long* host) {
 #endif
 
 // workgroups (= records) per class of a cnr_field_bwd_pipe launch: what a caller that reduces the records itself needs
+// the 8-wave kernel (4 chain + 4 dW waves) lives in fused_bwd_pipe8.hip
+extern "C" int cnr_field_bwd_pipe8_launch(const float* pts, const float* B, const void* packed, const float* biasrows,
+                                          const int* ray_row, float scale, const float* d_sigma, const float* d_rgb,
+                                          float grad_scale, int C, int R, int S, int rows_per_class, int blocks,
+                                          void* workspace, int64_t B_stride, long long* rows_fix, void* stream);
+
+static bool pipe_waves_ok(int chain_waves) { return chain_waves == 2 || chain_waves == 3 || chain_waves == 4; }
+
 extern "C" int cnr_field_bwd_pipe_blocks(int R, int S, int chain_waves, int max_blocks) {
-  if (R <= 0 || S <= 0 || (chain_waves != 2 && chain_waves != 3)) return 0;
+  if (R <= 0 || S <= 0 || !pipe_waves_ok(chain_waves)) return 0;
   const int64_t ntiles = ((int64_t)R * S + 31) / 32;
   int64_t blocks = (ntiles + chain_waves - 1) / chain_waves;
   const int64_t cap = max_blocks > 0 ? max_blocks : 256;
@@ -654,7 +629,7 @@ extern "C" int cnr_field_bwd_pipe(const float* pts, const float* B, const void* 
   if (!pts || !B || !packed || !biasrows || !d_sigma || !d_rgb || !dtrunk || !dB || !dbiasrows || !workspace)
     return CNR_E_ARG;
   if (C <= 0 || R <= 0 || S <= 0 || !(scale > 0.f) || !(grad_scale > 0.f)) return CNR_E_ARG;
-  if (chain_waves != 2 && chain_waves != 3) return CNR_E_ARG;
+  if (!pipe_waves_ok(chain_waves)) return CNR_E_ARG;
   // the pipeline keeps per-object row sums in one accumulator block: class-major rows, at most ROWS_LDS per class.
   // Everything else (one row per ray, many objects) takes the block-split kernels.
   if (ray_row == nullptr || rows_per_class < 1 || rows_per_class > ROWS_LDS) {
@@ -675,6 +650,17 @@ extern "C" int cnr_field_bwd_pipe(const float* pts, const float* B, const void* 
   if (blocks > cap) blocks = cap;
   const int64_t need = (int64_t)C * blocks * REC_FLOATS * (int64_t)sizeof(float);
   if (workspace_bytes < need) return CNR_E_ARG;
+  if (chain_waves == 4) {  // the 8-wave kernel
+    const int rc = cnr_field_bwd_pipe8_launch(pts, B, packed, biasrows, ray_row, scale, d_sigma, d_rgb, grad_scale, C, R, S,
+                                              rows_per_class, (int)blocks, workspace, B_stride, rows_fix, stream);
+    if (rc != CNR_OK) return rc;
+    if (skip_reduce) return CNR_OK;
+    hipLaunchKernelGGL(reduce_records_kernel, dim3(REC_FLOATS / 64, (unsigned)C), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)workspace, (int)blocks, dtrunk, dB, dbiasrows, rows_per_class,
+                       dtrunk_stride > 0 ? dtrunk_stride : (int64_t)TRUNK, dB_stride > 0 ? dB_stride : (int64_t)63);
+    CNR_LAUNCH_CHECK();
+    return CNR_OK;
+  }
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t er;

@@ -1,0 +1,592 @@
+// Fused field backward, 8-wave pipeline: workgroup = 4 chain waves + 4 dW waves, one of each per SIMD (TWO waves per SIMD:
+// a chain wave's dependent latency -- MFMA result -> mask / pack -> image store -> barrier -- is covered by its SIMD
+// partner instead of idling the SIMD as in fused_bwd_pipe.hip's 3 + 1 form).
+// What it takes to fit eight waves into one CU:
+//   * 256 registers per wave: the 16 accumulator blocks are spread over the four dW waves (<= 5 each); a chain wave
+//     keeps a0 .. a7 in registers until their step stages them as the layer input (no parked images);
+//   * LDS: operand fragments 61 KB + 4 x 15.1 KB per chain wave (PE images 10.5 KB, ONE dPre / input slot of
+//     2 x 2 KB, row one-hot table) -- the slot is single-buffered behind TWO barriers per layer step:
+//        chain: store step j's images | A | MFMA + mask + pack of step j+1 (registers only) | B | store step j+1 ...
+//        dW   :                         A | read step j's images, MFMAs                    | B
+//   * the slot images are unpadded 64-byte rows with an XOR chunk swizzle (stage_hs / tr_frag_hs): conflict-free for
+//     the transposing reads and the b64 stores;
+//   * the next tile's inputs (pts, upstream gradients, object row) are fetched three steps before the iteration ends.
+// Every dW wave has one unit of work per layer step (block ownership table below), reads all four tiles' operands up
+// front (it has the registers for that) and runs the MFMAs as they land.
+// Measured (tools/exp/run_pipe_timed.py, 8192 x 128): iteration = 4 tiles = ~17.5 k cycles against 15.5 k for 3 tiles
+// in the 3 + 1 form; forward recompute ~5.3 k (the dW waves wait), nine layer steps at ~1.2 k each with chain and
+// dW about level.  6 chain + 2 dW waves was tried first: 2 dW waves with 8 blocks each are the critical path
+// (12.2 us per 6 tiles against 7.3 us per 4 here).
+// Same records, same results contract as cnr_field_bwd_pipe (chain_waves = 4 selects this kernel).
+#include "fused_bwd_common.h"
+
+namespace {
+#ifdef CNR_PIPE_STAMPS  // tools/exp only: cycle stamps of every wave of workgroup 0 (its last iteration)
+__device__ long long g_pipe8_stamps[8 * 48];
+#define P8STAMP() do { if (blockIdx.x == 0 && lane == 0) \
+    g_pipe8_stamps[wv * 48 + (pstamp_i++)] = (long long)__builtin_readcyclecounter(); } while (0)
+#define P8STAMP_RESET() int pstamp_i = 0
+#else
+#define P8STAMP() do {} while (0)
+#define P8STAMP_RESET() do {} while (0)
+#endif
+#define P8SYNC() do { P8STAMP(); role_barrier(); P8STAMP(); } while (0)
+constexpr int C8_E1 = 0, C8_E2 = C8_E1 + E1IMG_BYTES, C8_D = C8_E2 + E2IMG_BYTES, C8_X = C8_D + HSIMG_BYTES,
+              C8_SMALL = C8_X + HSIMG_BYTES, C8_BYTES = C8_SMALL + 512;
+constexpr int L8_BL = PK_BYTES, L8_BR = L8_BL + 272, L8_CHAIN = L8_BR + ROWS_LDS * 128 * 4;
+constexpr int RS8_REGION = NBLOCKS;
+constexpr int BK_RS = 100;  // pseudo kind of the row-sum block in the ownership tables
+__host__ __device__ constexpr int l8_total(int nch) {
+  return L8_CHAIN + nch * C8_BYTES > (RS8_REGION + 1) * 4096 ? L8_CHAIN + nch * C8_BYTES : (RS8_REGION + 1) * 4096;
+}
+static_assert(l8_total(4) <= 160 * 1024, "LDS budget");
+
+// Which dW wave owns a block kind, and the block's index among that wave's accumulators: at most 5 accumulators per
+// wave, one unit of work per wave and layer step (cat_layer: dW3 two)
+//     dW0: row sums, viewdir[y], xyz[e1 0..31]          dW1: rgb.0 (+ rgb.2 rows 16..18), texture_1, cat[y], viewdir[e2 0..31], xyz[e1 32..63]
+//     dW2: enc_shape, shape_2, cat[e1 0..31], viewdir[e2 32..], xyz[e1 64..]      dW3: shape_1, cat[e1 32..63], cat[e1 64..]
+template <int NDW> __host__ __device__ constexpr int owner8(int kind);
+template <int NDW> __host__ __device__ constexpr int local8(int kind);
+template <> __host__ __device__ constexpr int owner8<4>(int kind) {
+  return (kind == BK_RS || kind == BK_VD_Y || kind == BK_XYZ_E0) ? 0
+       : (kind == BK_R0 || kind == BK_T1 || kind == BK_CAT_Y || kind == BK_VD_E0 || kind == BK_XYZ_E1) ? 1
+       : (kind == BK_ES || kind == BK_S2 || kind == BK_CAT_E0 || kind == BK_VD_E1 || kind == BK_XYZ_E2) ? 2 : 3;
+}
+template <> __host__ __device__ constexpr int local8<4>(int kind) {
+  return kind == BK_RS ? 0 : kind == BK_VD_Y ? 1 : kind == BK_XYZ_E0 ? 2
+       : kind == BK_R0 ? 0 : kind == BK_T1 ? 1 : kind == BK_CAT_Y ? 2 : kind == BK_VD_E0 ? 3 : kind == BK_XYZ_E1 ? 4
+       : kind == BK_ES ? 0 : kind == BK_S2 ? 1 : kind == BK_CAT_E0 ? 2 : kind == BK_VD_E1 ? 3 : kind == BK_XYZ_E2 ? 4
+       : kind == BK_S1 ? 0 : kind == BK_CAT_E1 ? 1 : 2 /* BK_CAT_E2 */;
+}
+
+template <int NCH, int NDW>
+__global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
+    const float* __restrict__ pts, const float* __restrict__ Bdir, const unsigned char* __restrict__ packed,
+    const float* __restrict__ biasrows, const int* __restrict__ ray_row, float inv_scale,
+    const float* __restrict__ d_sigma, const float* __restrict__ d_rgb, float gscale, float* __restrict__ records,
+    int N, int S, int R, int rows_per_class, int64_t B_stride, long long* __restrict__ rows_fix) {
+  constexpr int NCHW = NCH, NTHR = (NCH + NDW) * 64, NACC = 5, LI_RS = local8<NDW>(BK_RS);
+  static_assert(NACC >= 4, "the chain role parks its partial sums in accumulators 0..3");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int c = blockIdx.y;
+  const int lane = threadIdx.x & 63, h = lane >> 5, col = lane & 31;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool is_chain = wv < NCHW;
+  const int dwid = wv - NCHW;
+  {
+    const unsigned char* src = packed + (size_t)c * PK_BYTES;
+    for (int i = threadIdx.x * 16; i < PK_BYTES; i += NTHR * 16)
+      *reinterpret_cast<f4*>(smem + i) = *reinterpret_cast<const f4*>(src + i);
+    float* Bl = reinterpret_cast<float*>(smem + L8_BL);
+    for (int i = threadIdx.x; i < 66; i += NTHR) {
+      const int hh = i / 33, k = i % 33, d = k / 3;
+      Bl[i] = (hh == 1 && d == 10) ? 0.0f : Bdir[(size_t)c * B_stride + (11 * hh + d) * 3 + (k % 3)];
+    }
+    float* br = reinterpret_cast<float*>(smem + L8_BR);  // host guarantees 1 <= rows_per_class <= ROWS_LDS
+    for (int i = threadIdx.x; i < rows_per_class * 128; i += NTHR) br[i] = biasrows[(size_t)c * rows_per_class * 128 + i];
+  }
+  __syncthreads();
+  const float* cf = reinterpret_cast<const float*>(smem + PK_OFF_CONST);
+  const unsigned char* bwf = smem + PK_OFF_BWD;
+  unsigned char* chain_base = smem + L8_CHAIN;
+  const float inv_gs = 1.0f / gscale;
+  const int slot_inv = (65536 + S - 1) / S;
+  const int ntiles = (N + 31) / 32;
+  const int tile_step = gridDim.x * NCHW;
+
+  // dW waves: 8 accumulator blocks.  Chain waves never touch them, so their persistent per-lane partial sums live
+  // in the same registers: dB (33 floats) in Wacc[0..2], d b_sigma in Wacc[2][15], d w_sigma in Wacc[3].
+  f16v Wacc[NACC];
+#pragma unroll
+  for (int b = 0; b < NACC; ++b) Wacc[b] = zero16();
+#define DBACC(i) Wacc[(i) >> 4][(i) & 15]
+#define DWS(i) Wacc[3][i]
+#define DBS Wacc[2][15]
+
+  if (is_chain) {
+    // ===================================================================================================
+    // chain role: one tile per iteration
+    // ===================================================================================================
+    unsigned char* cw = chain_base + wv * C8_BYTES;
+    unsigned char* E1img = cw + C8_E1;
+    unsigned char* E2img = cw + C8_E2;
+    unsigned char* Dimg = cw + C8_D;
+    unsigned char* Ximg = cw + C8_X;
+    _Float16* rowoh = reinterpret_cast<_Float16*>(cw + C8_SMALL);  // [5][32]: (object row of sample k == r), row 4 ones
+    const float* Bl_h = reinterpret_cast<const float*>(smem + L8_BL) + 33 * h;
+
+    // one lane's inputs of a tile; past the end: a dead tile (all-zero gradients, any valid row)
+    struct TileIn { float px, py, pz, dsg, dr0, dr1, dr2; int row; };
+    auto fetch = [&](int tile) {
+      const bool tile_ok = tile < ntiles;
+      const int tl = tile_ok ? tile : ntiles - 1;
+      const int n0 = tl * 32;
+      const int ray0 = (int)((unsigned)n0 / (unsigned)S);
+      const int kk = n0 - ray0 * S + col;
+      const int sl = (kk * slot_inv) >> 16;  // kk / S for kk < S + 32, S <= 240
+      const bool live = tile_ok && n0 + col < N;
+      const int nc = n0 + col < N ? n0 + col : N - 1;
+      const int rayc = n0 + col < N ? ray0 + sl : R - 1;
+      const int64_t gs = (int64_t)c * N + nc;
+      const float* pp = pts + gs * 3;
+      const int64_t ray = (int64_t)c * R + rayc;
+      TileIn t;
+      t.px = pp[0]; t.py = pp[1]; t.pz = pp[2];
+      t.row = ray_row ? ray_row[ray] : (int)ray;
+      t.dsg = live ? d_sigma[gs] : 0.0f;
+      t.dr0 = live ? d_rgb[gs * 3 + 0] : 0.0f;
+      t.dr1 = live ? d_rgb[gs * 3 + 1] : 0.0f;
+      t.dr2 = live ? d_rgb[gs * 3 + 2] : 0.0f;
+      return t;
+    };
+    TileIn cur = fetch(blockIdx.x * NCHW + wv), nxt = cur;
+    for (int tile = blockIdx.x * NCHW + wv, t0 = blockIdx.x * NCHW; t0 < ntiles; t0 += tile_step, tile += tile_step) {
+      asm volatile("" ::: "memory");
+      P8STAMP_RESET();
+      P8STAMP();
+      // ---- this lane's sample (fetched during the previous iteration's shape_layer_2 step) -------------------
+      const float t0x = cur.px * inv_scale, t1x = cur.py * inv_scale, t2x = cur.pz * inv_scale;
+      const int row = cur.row;
+      const float draw = fminf(fmaxf(cur.dsg * gscale, -8192.0f), 8192.0f) * 10.0f;  // sigmas = raw * 10 (src/model.py:75)
+      const float dr0 = cur.dr0 * gscale, dr1 = cur.dr1 * gscale, dr2 = cur.dr2 * gscale;
+      const float* brow_l = reinterpret_cast<const float*>(smem + L8_BR) + (row - c * rows_per_class) * 128;
+
+      auto pe_backward = [&](const f16v (&de)[3], int nblk, int band0, int nq) {
+        float pd[11], gpa[11];
+#pragma unroll
+        for (int d = 0; d < 11; ++d) {
+          pd[d] = Bl_h[3 * d] * t0x + Bl_h[3 * d + 1] * t1x + Bl_h[3 * d + 2] * t2x;
+          gpa[d] = 0.0f;
+        }
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+          if (b >= nblk) continue;
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) {
+            const int q = 16 * b + reg;
+            if (q < nq) {
+              const int band = band0 + q / 11, d = q % 11;
+              const float cs = __builtin_amdgcn_cosf(pd[d] * (0.5f * (float)(1 << band)));
+              gpa[d] = fmaf(de[b][reg] * cs, 3.14159265358979f * (float)(1 << band), gpa[d]);
+            }
+          }
+        }
+#pragma unroll
+        for (int d = 0; d < 11; ++d) {
+          DBACC(3 * d + 0) = fmaf(gpa[d], t0x, DBACC(3 * d + 0));
+          DBACC(3 * d + 1) = fmaf(gpa[d], t1x, DBACC(3 * d + 1));
+          DBACC(3 * d + 2) = fmaf(gpa[d], t2x, DBACC(3 * d + 2));
+        }
+      };
+
+      // ------------------------------- forward recompute --------------------------------------------
+      // (the previous iteration's last barrier has passed: every image of this wave is free)
+      h8 E1f[6], E2f[3];
+      {
+        float Bh[33];
+#pragma unroll
+        for (int i = 0; i < 33; ++i) Bh[i] = Bl_h[i];
+        pe_slots<true>(Bh, t0x, t1x, t2x, h, E1f, E2f);
+      }
+      h8 wq[8];
+      f16v acc, bq;
+#pragma unroll
+      for (int s = 0; s < 6; ++s) wq[s] = lds_frag(smem, KK_XYZ + s, lane);
+      acc = acc_init(cf + CF_B_XYZ, h);
+      {
+        const int rl = row - c * rows_per_class;
+        rowoh[(2 * h + 0) * 32 + col] = rl == 2 * h + 0 ? (_Float16)1 : (_Float16)0;
+        rowoh[(2 * h + 1) * 32 + col] = rl == 2 * h + 1 ? (_Float16)1 : (_Float16)0;
+        if (h == 0) rowoh[4 * 32 + col] = (_Float16)1;
+      }
+      {
+        unsigned char* b1 = E1img + col * ST_E1 + h * 96;
+#pragma unroll
+        for (int s = 0; s < 6; ++s) *reinterpret_cast<h8*>(b1 + 16 * s) = E1f[s];
+        unsigned char* b2 = E2img + col * ST_E2 + h * 48;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) *reinterpret_cast<h8*>(b2 + 16 * s) = E2f[s];
+      }
+#pragma unroll
+      for (int s = 0; s < 6; ++s) acc = MFMA(wq[s], E1f[s], acc);
+      wq[0] = lds_frag(smem, KK_S1 + 0, lane); wq[1] = lds_frag(smem, KK_S1 + 1, lane);
+      bq = acc_init(brow_l + 0 * 32, h);
+      const h8 A0a = pack8(acc, 0, true), A0b = pack8(acc, 1, true);
+      acc = MFMA(wq[0], A0a, bq);
+      acc = MFMA(wq[1], A0b, acc);
+#pragma unroll
+      for (int s = 0; s < 8; ++s) wq[s] = lds_frag(smem, KK_CAT + s, lane);
+      bq = acc_init(brow_l + 1 * 32, h);
+      const h8 A1a = pack8(acc, 0, true), A1b = pack8(acc, 1, true);
+      acc = MFMA(wq[0], A1a, bq);
+      acc = MFMA(wq[1], A1b, acc);
+#pragma unroll
+      for (int s = 0; s < 6; ++s) acc = MFMA(wq[2 + s], E1f[s], acc);
+      wq[0] = lds_frag(smem, KK_S2 + 0, lane); wq[1] = lds_frag(smem, KK_S2 + 1, lane);
+      bq = acc_init(brow_l + 2 * 32, h);
+      const h8 A2a = pack8(acc, 0, true), A2b = pack8(acc, 1, true);
+      acc = MFMA(wq[0], A2a, bq);
+      acc = MFMA(wq[1], A2b, acc);
+      wq[0] = lds_frag(smem, KK_ES + 0, lane); wq[1] = lds_frag(smem, KK_ES + 1, lane);
+      bq = acc_init(cf + CF_B_ES, h);
+      const h8 A3a = pack8(acc, 0, true), A3b = pack8(acc, 1, true);
+      acc = MFMA(wq[0], A3a, bq);
+      acc = MFMA(wq[1], A3b, acc);
+#pragma unroll
+      for (int s = 0; s < 5; ++s) wq[s] = lds_frag(smem, KK_VD + s, lane);
+      bq = acc_init(cf + CF_B_VD, h);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) DWS(i) = fmaf(draw, acc[i], DWS(i));  // d w_sigma += draw * y4
+      DBS += (h == 0) ? draw : 0.0f;
+      const h8 Y4a = pack8(acc, 0, false), Y4b = pack8(acc, 1, false);
+      acc = MFMA(wq[0], Y4a, bq);
+      acc = MFMA(wq[1], Y4b, acc);
+#pragma unroll
+      for (int s = 0; s < 3; ++s) acc = MFMA(wq[2 + s], E2f[s], acc);
+      wq[0] = lds_frag(smem, KK_T1 + 0, lane); wq[1] = lds_frag(smem, KK_T1 + 1, lane);
+      bq = acc_init(brow_l + 3 * 32, h);
+      const h8 A5a = pack8(acc, 0, true), A5b = pack8(acc, 1, true);
+      acc = MFMA(wq[0], A5a, bq);
+      acc = MFMA(wq[1], A5b, acc);
+      wq[0] = lds_frag(smem, KK_R0 + 0, lane); wq[1] = lds_frag(smem, KK_R0 + 1, lane);
+      bq = acc_init(cf + CF_B_R0, h);
+      const h8 A6a = pack8(acc, 0, true), A6b = pack8(acc, 1, true);
+      acc = MFMA(wq[0], A6a, bq);
+      acc = MFMA(wq[1], A6b, acc);
+      wq[0] = lds_frag(smem, KK_R2, lane);
+      wq[1] = lds_frag(bwf, KT_R2, lane);
+      bq = acc_init(cf + CF_B_R2, h);
+      const h8 A7a = pack8(acc, 0, true);
+      acc = MFMA(wq[0], A7a, bq);
+      h8 Wn0 = lds_frag(bwf, KT_R0, lane), Wn1;
+
+      // ---- step R2: dPre9 = drgb * rgb (1 - rgb) in rows 0..2 (registers 0..2 of half 0)
+      h8 D0 = zero8(), D1 = zero8();
+      {
+        const float r0 = 1.0f / (1.0f + __expf(-acc[0])), r1 = 1.0f / (1.0f + __expf(-acc[1])),
+                    r2 = 1.0f / (1.0f + __expf(-acc[2]));
+        if (h == 0) {
+          D0[0] = (_Float16)(dr0 * r0 * (1.0f - r0));
+          D0[1] = (_Float16)(dr1 * r1 * (1.0f - r1));
+          D0[2] = (_Float16)(dr2 * r2 * (1.0f - r2));
+        }
+      }
+      // staged into feature columns 16..18: dW0 accumulates rgb.2 into rows 16..18 of rgb.0's block
+      stage_hs(Dimg, D1, D0, col, h);
+      {
+        h8 one = zero8();
+        if (h == 0) one[0] = (_Float16)1;  // feature 16 of the a7 image := 1 -> d b(rgb.2)
+        stage_hs(Ximg, A7a, one, col, h);
+      }
+      acc = MFMA(wq[1], D0, zero16());  // d a7 (rows 0..15)
+      P8SYNC();                   // A(R2)
+      D0 = pack8_masked(acc, 0, A7a); D1 = zero8();
+      u4v Mn0 = relu_mask(A6a), Mn1 = relu_mask(A6b);
+      acc = MFMA(Wn0, D0, zero16());  // d a6
+      Wn0 = lds_frag(bwf, KT_T1 + 0, lane); Wn1 = lds_frag(bwf, KT_T1 + 1, lane);
+      P8SYNC();                   // B(R2)
+      // ---- step R0
+      stage_hs(Dimg, D0, D1, col, h);
+      stage_hs(Ximg, A6a, A6b, col, h);
+      P8SYNC();                   // A(R0)
+      D0 = pack8_and(acc, 0, Mn0); D1 = pack8_and(acc, 1, Mn1);
+      Mn0 = relu_mask(A5a); Mn1 = relu_mask(A5b);
+      acc = MFMA(Wn0, D0, zero16());
+      acc = MFMA(Wn1, D1, acc);  // d a5
+      Wn0 = lds_frag(bwf, KT_VD_Y + 0, lane); Wn1 = lds_frag(bwf, KT_VD_Y + 1, lane);
+      P8SYNC();                   // B(R0)
+      // ---- step T1
+      stage_hs(Dimg, D0, D1, col, h);
+      stage_hs(Ximg, A5a, A5b, col, h);
+      P8SYNC();                   // A(T1)
+      D0 = pack8_and(acc, 0, Mn0); D1 = pack8_and(acc, 1, Mn1);
+      acc = MFMA(Wn0, D0, zero16());
+      acc = MFMA(Wn1, D1, acc);  // d y4 from the colour branch
+      f16v de2[3];  // d e2 (two 16-slot blocks)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        de2[b] = MFMA(lds_frag(bwf, KT_VD_E + 2 * b + 0, lane), D0, zero16());
+        de2[b] = MFMA(lds_frag(bwf, KT_VD_E + 2 * b + 1, lane), D1, de2[b]);
+      }
+      Wn0 = lds_frag(bwf, KT_ES + 0, lane); Wn1 = lds_frag(bwf, KT_ES + 1, lane);
+      P8SYNC();                   // B(T1)
+      // ---- step VD : inputs [y4 | e2]
+      stage_hs(Dimg, D0, D1, col, h);
+      stage_hs(Ximg, Y4a, Y4b, col, h);
+      P8SYNC();                   // A(VD)
+      {  // + sigma head: d y4 += w_sigma * draw
+        const f16v wsg = acc_init(cf + CF_W_SG, h);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = fmaf(wsg[i], draw, acc[i]);
+      }
+      D0 = pack8(acc, 0, false); D1 = pack8(acc, 1, false);
+      Mn0 = relu_mask(A3a); Mn1 = relu_mask(A3b);
+      acc = MFMA(Wn0, D0, zero16());
+      acc = MFMA(Wn1, D1, acc);  // d a3
+      Wn0 = lds_frag(bwf, KT_S2 + 0, lane); Wn1 = lds_frag(bwf, KT_S2 + 1, lane);
+      de2[2] = de2[1];
+      pe_backward(de2, 2, 4, 22);  // bands 4 and 5 -> dB
+      P8SYNC();                   // B(VD)
+      // ---- step ES (no activation)
+      stage_hs(Dimg, D0, D1, col, h);
+      stage_hs(Ximg, A3a, A3b, col, h);
+      P8SYNC();                   // A(ES)
+      D0 = pack8_and(acc, 0, Mn0); D1 = pack8_and(acc, 1, Mn1);
+      Mn0 = relu_mask(A2a); Mn1 = relu_mask(A2b);
+      acc = MFMA(Wn0, D0, zero16());
+      acc = MFMA(Wn1, D1, acc);  // d a2
+      Wn0 = lds_frag(bwf, KT_CAT_Y + 0, lane); Wn1 = lds_frag(bwf, KT_CAT_Y + 1, lane);
+      P8SYNC();                   // B(ES)
+      // ---- step S2 : input a2
+      stage_hs(Dimg, D0, D1, col, h);
+      stage_hs(Ximg, A2a, A2b, col, h);
+      P8SYNC();                   // A(S2)
+      D0 = pack8_and(acc, 0, Mn0); D1 = pack8_and(acc, 1, Mn1);
+      Mn0 = relu_mask(A1a); Mn1 = relu_mask(A1b);
+      acc = MFMA(Wn0, D0, zero16());
+      acc = MFMA(Wn1, D1, acc);  // d a1
+      Wn0 = lds_frag(bwf, KT_S1 + 0, lane); Wn1 = lds_frag(bwf, KT_S1 + 1, lane);
+      const h8 Dc0 = D0, Dc1 = D1;  // dPre(cat): its d e1 part is formed together with encoding_xyz's
+      nxt = fetch(tile + tile_step);  // next iteration's inputs: their latency hides under the last three steps
+      P8SYNC();                   // B(S2)
+      // ---- step CAT : inputs [a1 | e1]
+      stage_hs(Dimg, D0, D1, col, h);
+      stage_hs(Ximg, A1a, A1b, col, h);
+      P8SYNC();                   // A(CAT)
+      D0 = pack8_and(acc, 0, Mn0); D1 = pack8_and(acc, 1, Mn1);
+      Mn0 = relu_mask(A0a); Mn1 = relu_mask(A0b);
+      acc = MFMA(Wn0, D0, zero16());
+      acc = MFMA(Wn1, D1, acc);  // d a0
+      f16v de[3];
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        de[b] = MFMA(lds_frag(bwf, KT_CAT_E + 2 * b + 0, lane), Dc0, zero16());
+        de[b] = MFMA(lds_frag(bwf, KT_CAT_E + 2 * b + 1, lane), Dc1, de[b]);
+      }
+      P8SYNC();                   // B(CAT)
+      // ---- step S1 : input a0
+      stage_hs(Dimg, D0, D1, col, h);
+      stage_hs(Ximg, A0a, A0b, col, h);
+      P8SYNC();                   // A(S1)
+      D0 = pack8_and(acc, 0, Mn0); D1 = pack8_and(acc, 1, Mn1);
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        de[b] = MFMA(lds_frag(bwf, KT_XYZ_E + 2 * b + 0, lane), D0, de[b]);
+        de[b] = MFMA(lds_frag(bwf, KT_XYZ_E + 2 * b + 1, lane), D1, de[b]);
+      }
+      P8SYNC();                   // B(S1)
+      // ---- step XYZ : input e1 (its image)
+      stage_hs(Dimg, D0, D1, col, h);
+      P8SYNC();                   // A(XYZ)
+      pe_backward(de, 3, 0, 44);        // d e1 -> dB, bands 0..3
+      cur = nxt;
+      P8SYNC();                   // B(XYZ): the dW waves are done with this tile's images
+    }
+  } else {
+    // ===================================================================================================
+    // dW role: 8 accumulator blocks per wave, six tiles per step
+    // ===================================================================================================
+    const int m_row = col < 16 ? (col & 3) : 4, m_grp = col < 16 ? (col >> 2) : (col - 12);
+    for (int t0 = blockIdx.x * NCHW; t0 < ntiles; t0 += tile_step) {
+      asm volatile("" ::: "memory");
+      P8STAMP_RESET();
+      P8STAMP();
+      // one layer step over the six tiles; KIND* = the block kinds of the step (X source: 0 = slot X image,
+      // 1 = E2 image, 2 = E1 image; col0 = first feature column), RS_GRP >= 0: row sums of the step (dW0)
+      auto consume = [&](auto dw_c, auto nx_c, auto k0_c, auto k1_c, auto k2_c, auto k3_c, auto grp_c) {
+        constexpr int DW = decltype(dw_c)::value, NX = decltype(nx_c)::value, RS_GRP = decltype(grp_c)::value;
+        constexpr int K0 = decltype(k0_c)::value, K1 = decltype(k1_c)::value, K2 = decltype(k2_c)::value,
+                      K3 = decltype(k3_c)::value;
+        // which of the step's blocks this dW wave owns, and their operand slots (all compile-time: the accumulator
+        // and fragment arrays must be indexed by constants)
+        constexpr bool OWN0 = NX > 0 && owner8<NDW>(K0) == DW, OWN1 = NX > 1 && owner8<NDW>(K1) == DW,
+                       OWN2 = NX > 2 && owner8<NDW>(K2) == DW, OWN3 = NX > 3 && owner8<NDW>(K3) == DW;
+        constexpr int SL0 = 0, SL1 = OWN0, SL2 = OWN0 + OWN1, SL3 = OWN0 + OWN1 + OWN2;
+        constexpr bool DO_RS = RS_GRP >= 0 && DW == owner8<NDW>(BK_RS);
+        if constexpr (!(OWN0 || OWN1 || OWN2 || OWN3 || DO_RS)) return;
+        // at most two owned blocks per wave and step; DEPTH tiles in flight (transposing reads are convergent: the
+        // compiler keeps them in source order, so the lookahead is spelled out): all four, the registers are there
+        constexpr int DEPTH = NCHW;
+        h8 fD[DEPTH][2], fX[DEPTH][2][2];
+        u4v fR[DEPTH][2];          // row one-hot operand of the row sums
+        auto load_blk = [&](int w, auto kind_c, auto slot_c) {
+          constexpr int kind = decltype(kind_c)::value, slot = decltype(slot_c)::value;
+          const unsigned char* cb = chain_base + w * C8_BYTES;
+          const unsigned char* ximg;
+          int stride = 0, col0 = 0;
+          if (kind == BK_VD_E0 || kind == BK_VD_E1) { ximg = cb + C8_E2; stride = ST_E2; col0 = kind == BK_VD_E1 ? 32 : 0; }
+          else if (kind == BK_CAT_E0 || kind == BK_XYZ_E0) { ximg = cb + C8_E1; stride = ST_E1; col0 = 0; }
+          else if (kind == BK_CAT_E1 || kind == BK_XYZ_E1) { ximg = cb + C8_E1; stride = ST_E1; col0 = 32; }
+          else if (kind == BK_CAT_E2 || kind == BK_XYZ_E2) { ximg = cb + C8_E1; stride = ST_E1; col0 = 64; }
+          else ximg = cb + C8_X;
+          if (stride == 0) {  // the step's input image (swizzled rows)
+            fX[w % DEPTH][slot][0] = tr_frag_hs(ximg, 0, lane);
+            fX[w % DEPTH][slot][1] = tr_frag_hs(ximg, 1, lane);
+          } else {            // a PE image
+            fX[w % DEPTH][slot][0] = tr_frag(ximg, stride, col0, 0, lane);
+            fX[w % DEPTH][slot][1] = tr_frag(ximg, stride, col0, 1, lane);
+          }
+        };
+        auto mma_blk = [&](int w, auto kind_c, auto slot_c) {
+          constexpr int li = local8<NDW>(decltype(kind_c)::value), slot = decltype(slot_c)::value;
+          Wacc[li] = MFMA(fD[w % DEPTH][0], fX[w % DEPTH][slot][0], Wacc[li]);
+          Wacc[li] = MFMA(fD[w % DEPTH][1], fX[w % DEPTH][slot][1], Wacc[li]);
+        };
+        auto load_tile = [&](int w) {
+          const unsigned char* cb = chain_base + w * C8_BYTES;
+          fD[w % DEPTH][0] = tr_frag_hs(cb + C8_D, 0, lane);
+          fD[w % DEPTH][1] = tr_frag_hs(cb + C8_D, 1, lane);
+          if constexpr (OWN0) load_blk(w, IC<K0>{}, IC<SL0>{});
+          if constexpr (OWN1) load_blk(w, IC<K1>{}, IC<SL1>{});
+          if constexpr (OWN2) load_blk(w, IC<K2>{}, IC<SL2>{});
+          if constexpr (OWN3) load_blk(w, IC<K3>{}, IC<SL3>{});
+          if constexpr (DO_RS) {
+            const _Float16* rowoh = reinterpret_cast<const _Float16*>(cb + C8_SMALL);
+            fR[w % DEPTH][0] = __builtin_bit_cast(u4v, *reinterpret_cast<const h8*>(rowoh + m_row * 32 + 0 + 8 * h));
+            fR[w % DEPTH][1] = __builtin_bit_cast(u4v, *reinterpret_cast<const h8*>(rowoh + m_row * 32 + 16 + 8 * h));
+          }
+        };
+#pragma unroll
+        for (int w = 0; w < DEPTH - 1 && w < NCHW; ++w) load_tile(w);
+#pragma unroll
+        for (int w = 0; w < NCHW; ++w) {
+          if (w + DEPTH - 1 < NCHW) load_tile(w + DEPTH - 1);
+          if constexpr (OWN0) mma_blk(w, IC<K0>{}, IC<SL0>{});
+          if constexpr (OWN1) mma_blk(w, IC<K1>{}, IC<SL1>{});
+          if constexpr (OWN2) mma_blk(w, IC<K2>{}, IC<SL2>{});
+          if constexpr (OWN3) mma_blk(w, IC<K3>{}, IC<SL3>{});
+          if constexpr (DO_RS) {
+            // RS[m][:] += sum over the tile's samples in m's group of dPre
+            const unsigned int lm = (m_grp == RS_GRP) ? 0xffffffffu : 0u;
+            Wacc[LI_RS] = MFMA(__builtin_bit_cast(h8, (u4v)(fR[w % DEPTH][0] & lm)), fD[w % DEPTH][0], Wacc[LI_RS]);
+            Wacc[LI_RS] = MFMA(__builtin_bit_cast(h8, (u4v)(fR[w % DEPTH][1] & lm)), fD[w % DEPTH][1], Wacc[LI_RS]);
+          }
+        }
+      };
+#define STEP8(NX, K0, K1, K2, K3, GRP)                                                                        \
+  P8SYNC();                                                                                             \
+  if (dwid == 0) consume(IC<0>{}, IC<NX>{}, IC<K0>{}, IC<K1>{}, IC<K2>{}, IC<K3>{}, IC<GRP>{});               \
+  else if (dwid == 1) consume(IC<1>{}, IC<NX>{}, IC<K0>{}, IC<K1>{}, IC<K2>{}, IC<K3>{}, IC<GRP>{});          \
+  else if (dwid == 2) consume(IC<2>{}, IC<NX>{}, IC<K0>{}, IC<K1>{}, IC<K2>{}, IC<K3>{}, IC<GRP>{});          \
+  else consume(IC<3>{}, IC<NX>{}, IC<K0>{}, IC<K1>{}, IC<K2>{}, IC<K3>{}, IC<GRP>{});                         \
+  P8SYNC();
+      STEP8(1, BK_R0, BK_R0, BK_R0, BK_R0, -1)                               // rgb.2 (rows 16..18 of rgb.0's block)
+      STEP8(1, BK_R0, BK_R0, BK_R0, BK_R0, 5)                                // rgb.0
+      STEP8(1, BK_T1, BK_T1, BK_T1, BK_T1, 3)                                // texture_layer_1
+      STEP8(3, BK_VD_Y, BK_VD_E0, BK_VD_E1, BK_VD_E1, -1)                    // encoding_viewdir
+      STEP8(1, BK_ES, BK_ES, BK_ES, BK_ES, 4)                                // encoding_shape
+      STEP8(1, BK_S2, BK_S2, BK_S2, BK_S2, 2)                                // shape_layer_2
+      STEP8(4, BK_CAT_Y, BK_CAT_E0, BK_CAT_E1, BK_CAT_E2, 1)                 // cat_layer
+      STEP8(1, BK_S1, BK_S1, BK_S1, BK_S1, 0)                                // shape_layer_1
+      STEP8(3, BK_XYZ_E0, BK_XYZ_E1, BK_XYZ_E2, BK_XYZ_E2, -1)               // encoding_xyz
+#undef STEP8
+    }
+  }
+
+  // ========================================= flush ====================================================
+  __syncthreads();
+  float* rec = records + ((size_t)c * gridDim.x + blockIdx.x) * REC_FLOATS;
+  if (is_chain) {
+    float* small = reinterpret_cast<float*>(chain_base + wv * C8_BYTES + C8_SMALL);  // [0..31] d w_sigma, [32] d b_sigma, [64..126] dB
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float v = half_sum_dpp(DWS(i));
+      if (col == 31) small[acc_row(i, h)] = v;
+    }
+    {
+      const float v = half_sum_dpp(DBS);  // zero in lane half 1
+      if (lane == 31) small[32] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 33; ++i) {
+      const float v = half_sum_dpp(DBACC(i));
+      const int d = i / 3;
+      if (col == 31 && !(h == 1 && d == 10)) small[64 + (11 * h + d) * 3 + (i % 3)] = v;
+    }
+  }
+  __syncthreads();
+  {
+    auto sum_chain = [&](int i) {
+      float v = 0.0f;
+#pragma unroll
+      for (int w = 0; w < NCHW; ++w) v += reinterpret_cast<const float*>(chain_base + w * C8_BYTES + C8_SMALL)[i];
+      return v;
+    };
+    for (int i = threadIdx.x; i < 63; i += NTHR) { rec[TRUNK + i] = sum_chain(64 + i) * inv_gs; rec[TRUNK + 63 + i] = 0.0f; }
+    for (int i = threadIdx.x; i < 32; i += NTHR) rec[OFF_SG_W + i] = sum_chain(i) * inv_gs;
+    if (threadIdx.x == 0) rec[OFF_SG_B] = sum_chain(32) * inv_gs;
+  }
+  __syncthreads();  // everything above has been read: the accumulator image may alias it
+  if (!is_chain) {
+    float* region = reinterpret_cast<float*>(smem);
+#define CNR_PSTORE8(KIND)                                                                     \
+  if (owner8<NDW>(KIND) == dwid) {                                                                 \
+    constexpr int li = local8<NDW>(KIND);                                                          \
+    _Pragma("unroll") for (int reg = 0; reg < 16; ++reg)                                      \
+        region[(KIND) * 1024 + acc_row(reg, h) * 32 + col] = Wacc[li][reg];                   \
+  }
+    if (dwid == owner8<NDW>(BK_RS)) {  // the row-sum block
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) region[RS8_REGION * 1024 + acc_row(reg, h) * 32 + col] = Wacc[LI_RS][reg];
+    }
+    if (dwid == owner8<NDW>(BK_R0)) {  // rgb.2 out of rows 16..31 of rgb.0's block
+#pragma unroll
+      for (int reg = 8; reg < 16; ++reg)
+        region[BK_R2 * 1024 + (acc_row(reg, h) - 16) * 32 + col] = Wacc[local8<NDW>(BK_R0)][reg];
+    }
+    CNR_PSTORE8(BK_R0) CNR_PSTORE8(BK_T1) CNR_PSTORE8(BK_VD_Y) CNR_PSTORE8(BK_VD_E0)
+    CNR_PSTORE8(BK_VD_E1) CNR_PSTORE8(BK_ES) CNR_PSTORE8(BK_S2) CNR_PSTORE8(BK_CAT_Y) CNR_PSTORE8(BK_CAT_E0)
+    CNR_PSTORE8(BK_CAT_E1) CNR_PSTORE8(BK_CAT_E2) CNR_PSTORE8(BK_S1) CNR_PSTORE8(BK_XYZ_E0) CNR_PSTORE8(BK_XYZ_E1)
+    CNR_PSTORE8(BK_XYZ_E2)
+#undef CNR_PSTORE8
+  }
+  __syncthreads();
+  {
+    const float* region = reinterpret_cast<const float*>(smem);
+    for (int j = threadIdx.x; j < TRUNK; j += NTHR) {  // coalesced record stores, LDS gather
+      const int src = g_param_src[j];
+      if (src >= 0) rec[j] = region[src] * inv_gs;
+    }
+    const float* rs = region + RS8_REGION * 1024;  // [m][feature]
+    for (int i = threadIdx.x; i < 32; i += NTHR) rec[OFF_ES_B + i] = rs[16 * 32 + i] * inv_gs;
+    for (int i = threadIdx.x; i < 16; i += NTHR) rec[OFF_R0_B + i] = rs[17 * 32 + i] * inv_gs;
+    for (int i = threadIdx.x; i < rows_per_class * 128; i += NTHR) {  // dbiasrows [row][latent slot][feature]
+      const float v = rs[(((i >> 5) & 3) * 4 + (i >> 7)) * 32 + (i & 31)] * inv_gs;
+      rec[TRUNK + 126 + i] = v;
+      if (rows_fix)
+        atomicAdd(reinterpret_cast<unsigned long long*>(
+                      rows_fix + ((size_t)(blockIdx.x % cnr_rec::ROWS_FIX_COPIES) * gridDim.y + c) * rows_per_class * 128 + i),
+                  (unsigned long long)__double2ll_rn((double)v * cnr_rec::ROWS_FIX_SCALE));
+    }
+  }
+}
+}  // namespace
+
+// launched by cnr_field_bwd_pipe (fused_bwd_pipe.hip) for chain_waves = 4: same argument checks, same records
+extern "C" int cnr_field_bwd_pipe8_launch(const float* pts, const float* B, const void* packed, const float* biasrows,
+                                          const int* ray_row, float scale, const float* d_sigma, const float* d_rgb,
+                                          float grad_scale, int C, int R, int S, int rows_per_class, int blocks,
+                                          void* workspace, int64_t B_stride, long long* rows_fix, void* stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t er = hipFuncSetAttribute((const void*)field_bwd_pipe8_kernel<4, 4>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, l8_total(4));
+    if (er != hipSuccess) return (int)er;
+    hipLaunchKernelGGL(build_param_src_kernel, dim3(16), dim3(256), 0, (hipStream_t)stream);
+    hipLaunchKernelGGL(fill_param_src_kernel, dim3(16), dim3(256), 0, (hipStream_t)stream);
+    attr_set = true;
+  }
+  const int64_t N = (int64_t)R * S;
+  hipLaunchKernelGGL((field_bwd_pipe8_kernel<4, 4>), dim3((unsigned)blocks, (unsigned)C), dim3(512), l8_total(4),
+                     (hipStream_t)stream, pts, B, (const unsigned char*)packed, biasrows, ray_row, 1.0f / scale, d_sigma,
+                     d_rgb, grad_scale, (float*)workspace, (int)N, S, R, rows_per_class,
+                     B_stride > 0 ? B_stride : (int64_t)63, rows_fix);
+  CNR_LAUNCH_CHECK();
+  return CNR_OK;
+}
+
+#ifdef CNR_PIPE_STAMPS
+extern "C" int cnr_pipe8_read_stamps(long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pipe8_stamps), sizeof(long long) * 8 * 48);
+}
+#endif

@@ -326,9 +326,11 @@ int cnr_step_tail(const float* theta_in, float* theta_out, float* grad, float* e
                   int rl_blocks, void* stream);
 
 /* Same contract and results as cnr_field_bwd, ONE field kernel + the record reduction: each workgroup is
- * `chain_waves` (2 or 3) waves that run forward recompute + data-gradient chain + PE backward for one 32-sample
- * tile each, plus 4 - chain_waves waves that own the weight-gradient accumulators and consume the chain waves'
- * per-layer images one workgroup barrier behind (csrc/fused_bwd_pipe.hip).  max_blocks / workspace as above. */
+ * `chain_waves` waves that run forward recompute + data-gradient chain + PE backward for one 32-sample tile each,
+ * plus the waves that own the weight-gradient accumulators and consume the chain waves' per-layer images behind a
+ * workgroup barrier.  chain_waves = 2 or 3: four waves per workgroup, 4 - chain_waves of them on the weight
+ * gradients (csrc/fused_bwd_pipe.hip); chain_waves = 4: eight waves, 4 + 4, two per SIMD (csrc/fused_bwd_pipe8.hip,
+ * the fastest form and the trainer's default).  max_blocks / workspace as above. */
 /* rows_fix (optional): per-object bias-row sums also accumulated as 2^-40 fixed point into this (8, C, n_obj, 4, 32)
  * int64 table (8 copies, a workgroup uses copy index & 7, to shorten the same-address atomic queues; caller zeroes it); skip_reduce != 0: stop after the field kernel, the caller reduces the nwg =
  * cnr_field_bwd_pipe_blocks(R, S, chain_waves, max_blocks) records per class in `workspace` itself (cnr_step_tail). */

@@ -123,7 +123,7 @@ def test_fused_forward_full_size(cnr, dev, C, R, S, L, wscale):
 
 
 # ---- fused backward ----------------------------------------------------------------------------------
-@pytest.fixture(params=["split", "pipe2", "pipe3"])
+@pytest.fixture(params=["split", "pipe2", "pipe3", "pipe4"])
 def bwd_variant(request, cnr, monkeypatch):
     """every cnr_field_bwd implementation must meet the same bars (ops.field_bwd dispatches on this)."""
     monkeypatch.setattr(cnr.ops, "FIELD_BWD_VARIANT", request.param)

@@ -37,7 +37,7 @@ def run(C, R, S, blocks, iters=50):
     n = C * R * S
     line = f"C{C} R{R} S{S} blocks{blocks}: fwd {fwd:8.1f} us ({n*27422/fwd/1e6:7.1f} TF)"
     ref = None
-    for variant in ("split", "pipe2", "pipe3"):
+    for variant in ("split", "pipe2", "pipe3", "pipe4"):
         dtrunk.zero_(); dB.zero_(); dbr.zero_()
         ops.field_bwd(pts, B, packed, brows, ray_row, 2.0, dsig, drgb, 2048.0, dtrunk, dB, dbr, C, R, S, n_obj, blocks,
                       wsp, variant=variant)
@@ -50,5 +50,5 @@ def run(C, R, S, blocks, iters=50):
     print(line, flush=True)
 
 
-for (C, R, S, blocks) in [(1, 2048, 64, 0), (1, 2048, 64, 128), (1, 2048, 64, 64), (1, 8192, 128, 0), (1, 8192, 128, 128), (1, 64, 32, 0), (1, 64, 32, 1)]:
+for (C, R, S, blocks) in [(1, 2048, 64, 0), (1, 2048, 64, 228), (1, 2048, 64, 171), (1, 2048, 64, 128), (1, 2048, 64, 64), (1, 8192, 128, 0), (1, 8192, 128, 128), (1, 64, 32, 0), (1, 64, 32, 1)]:
     run(C, R, S, blocks)

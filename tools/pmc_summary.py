@@ -18,7 +18,7 @@ fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "W
 R, S = int(sys.argv[4]), int(sys.argv[5])
 out = {"workload": f"tools/prof_one.py {R} {S} (1 class, {R} rays x {S} samples), rocprofv3 --pmc, one counter per "
                    "pass, KB per launch; FETCH_SIZE x2 (64 B counted per 128-B request on gfx950)", "kernels": {}}
-want = ("field_fwd_kernel", "field_bwd_pipe_kernel", "field_bwd_kernel", "reduce_records_kernel")
+want = ("field_fwd_kernel", "field_bwd_pipe8_kernel", "field_bwd_pipe_kernel", "field_bwd_kernel", "reduce_records_kernel")
 call = 0.0
 for name in sorted(set(fetch) | set(write)):
     short = next((w for w in want if w in name), None)

@@ -17,6 +17,15 @@ for n in ("2048x64", "8192x128"):
     out = os.path.join(P, "r01_pmc_traffic.json" if n == "2048x64" else f"r01_pmc_traffic_{n}.json")
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools/pmc_summary.py"), f"{src}/pmc_fetch_{n}/p_counter_collection.csv",
                            f"{src}/pmc_write_{n}/p_counter_collection.csv", out, R, S], stdout=subprocess.DEVNULL)
+# the bench line was printed on the GPU box before this collection's PMC passes existed there: its roofline.traffic is the
+# previous collection's figure -> replace it with this collection's (same command, same shape)
+bj = os.path.join(P, "r01_bench_2048x64.json")
+line = json.loads(open(bj).read())
+call = json.load(open(os.path.join(P, "r01_pmc_traffic.json")))
+key = line["roofline"]["kernel"] + "_call_hbm_bytes"
+if key in call:
+    line["roofline"]["traffic"] = call[key]
+    open(bj, "w").write(json.dumps(line) + "\n")
 sq = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools/pmc_sq_summary.py"),
                               f"{src}/pmc_sq_2048x64/p_counter_collection.csv", f"{src}/pmc_sq_8192x128/p_counter_collection.csv"])
 open(os.path.join(P, "r01_pmc_sq_mfma_busy.json"), "wb").write(sq)
