@@ -199,24 +199,24 @@ template <int V> using IC = std::integral_constant<int, V>;
 enum Step { ST_R2, ST_R0, ST_T1, ST_VD, ST_ES, ST_S2, ST_CAT, ST_S1, ST_XYZ, NSTEPS };
 
 // f16 pack of the 8 accumulator registers of k-step s, zeroed where the (post-ReLU, hence non-negative) activation
-// is zero.  Three packed-integer VALU ops per register pair -- min(act, 1) per half, times 0xFFFF, and -- written as
-// inline asm: from the portable vector form hipcc builds a compare / select / shift / permute sequence per element
-// (9 instructions and VCC wait states per pair; these masks are on every backward step's critical path).
+// is zero.  Two packed-integer VALU ops per register pair -- min(act, 1) per half, then 0 - that = 0xFFFF / 0 -- and an
+// AND.  Written with vector types and an OPAQUE constant: with a visible 1 the optimiser rewrites min/negate into a
+// compare + select per element (9 instructions and VCC wait states per pair; these masks are on every backward step's
+// critical path).  NOT inline-asm instructions: hipcc pads no hazards for an asm statement, and its register allocator
+// hands an asm output the register an MFMA issued just before is still reading as its A operand -- seen as run-to-run
+// different colour-branch gradients (25 % off) in one scheduling of the 8-wave kernel, while every test passed in the
+// others.
 typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+typedef unsigned short us8 __attribute__((ext_vector_type(8)));
 // 0xFFFF per half where the activation is non-zero.  Only depends on the forward: the backward steps compute the
 // mask of the NEXT step before their barrier, so that after the barrier a step is MFMA -> cvt -> and -> store.
 __device__ __forceinline__ u4v relu_mask(const h8& act) {
-  const u4v av = __builtin_bit_cast(u4v, act);
-  u4v m;
-  const unsigned int ones = 0x00010001u;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    unsigned int t;
-    asm("v_pk_min_u16 %0, %1, %2" : "=v"(t) : "v"(av[i]), "s"(ones));
-    asm("v_pk_mul_lo_u16 %0, %1, -1" : "=v"(t) : "v"(t));
-    m[i] = t;
-  }
-  return m;
+  unsigned int ones = 0x00010001u;
+  asm volatile("" : "+s"(ones));  // no instruction: only hides the value from the optimiser
+  const u4v o4 = {ones, ones, ones, ones};
+  const us8 one = __builtin_bit_cast(us8, o4);
+  const us8 t = __builtin_elementwise_min(__builtin_bit_cast(us8, act), one);
+  return __builtin_bit_cast(u4v, (us8)((us8)(0) - t));
 }
 __device__ __forceinline__ h8 pack8_and(const f16v& a, int s, const u4v& m) {
   return __builtin_bit_cast(h8, (u4v)(__builtin_bit_cast(u4v, pack8(a, s, false)) & m));

@@ -31,8 +31,7 @@ __device__ long long g_pipe8_stamps[8 * 48];
 #define P8STAMP_RESET() do {} while (0)
 #endif
 #define P8SYNC() do { P8STAMP(); role_barrier(); P8STAMP(); } while (0)
-constexpr int C8_E1 = 0, C8_E2 = C8_E1 + E1IMG_BYTES, C8_D = C8_E2 + E2IMG_BYTES, C8_X = C8_D + HSIMG_BYTES,
-              C8_SMALL = C8_X + HSIMG_BYTES, C8_BYTES = C8_SMALL + 512;
+constexpr int C8_BYTES = E1IMG_BYTES + E2IMG_BYTES + 2 * HSIMG_BYTES + 512;  // LDS per chain wave
 constexpr int L8_BL = PK_BYTES, L8_BR = L8_BL + 272, L8_CHAIN = L8_BR + ROWS_LDS * 128 * 4;
 constexpr int RS8_REGION = NBLOCKS;
 constexpr int BK_RS = 100;  // pseudo kind of the row-sum block in the ownership tables
@@ -66,6 +65,11 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
     const float* __restrict__ d_sigma, const float* __restrict__ d_rgb, float gscale, float* __restrict__ records,
     int N, int S, int R, int rows_per_class, int64_t B_stride, long long* __restrict__ rows_fix) {
   constexpr int NCHW = NCH, NTHR = (NCH + NDW) * 64, NACC = 5, LI_RS = local8<NDW>(BK_RS);
+  // per chain wave: E1 image, E2 image, dPre / input slot, row one-hot table (the flush reuses it for the wave's
+  // partial sums)
+  constexpr int K_E1 = 0, K_E2 = E1IMG_BYTES, K_D = K_E2 + E2IMG_BYTES, K_X = K_D + HSIMG_BYTES,
+                K_SMALL = K_X + HSIMG_BYTES, K_BYTES = C8_BYTES;
+  static_assert(K_BYTES == K_SMALL + 512, "layout");
   static_assert(NACC >= 4, "the chain role parks its partial sums in accumulators 0..3");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int c = blockIdx.y;
@@ -94,25 +98,31 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
   const int ntiles = (N + 31) / 32;
   const int tile_step = gridDim.x * NCHW;
 
-  // dW waves: 8 accumulator blocks.  Chain waves never touch them, so their persistent per-lane partial sums live
-  // in the same registers: dB (33 floats) in Wacc[0..2], d b_sigma in Wacc[2][15], d w_sigma in Wacc[3].
+  // dW waves: up to 5 accumulator blocks each.  Chain waves never touch them; their own persistent per-lane partial
+  // sums (dB 33 floats, d w_sigma 16, d b_sigma) are locals of the chain branch, so that branch pays for 50 registers,
+  // not for the dW role's 80.
   f16v Wacc[NACC];
 #pragma unroll
   for (int b = 0; b < NACC; ++b) Wacc[b] = zero16();
-#define DBACC(i) Wacc[(i) >> 4][(i) & 15]
-#define DWS(i) Wacc[3][i]
-#define DBS Wacc[2][15]
+#define DBACC(i) c_dbacc[i]
+#define DWS(i) c_dws[i]
+#define DBS c_dbs
 
   if (is_chain) {
     // ===================================================================================================
     // chain role: one tile per iteration
     // ===================================================================================================
-    unsigned char* cw = chain_base + wv * C8_BYTES;
-    unsigned char* E1img = cw + C8_E1;
-    unsigned char* E2img = cw + C8_E2;
-    unsigned char* Dimg = cw + C8_D;
-    unsigned char* Ximg = cw + C8_X;
-    _Float16* rowoh = reinterpret_cast<_Float16*>(cw + C8_SMALL);  // [5][32]: (object row of sample k == r), row 4 ones
+    float c_dbacc[33], c_dws[16], c_dbs = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 33; ++i) c_dbacc[i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) c_dws[i] = 0.0f;
+    unsigned char* cw = chain_base + wv * K_BYTES;
+    unsigned char* E1img = cw + K_E1;
+    unsigned char* E2img = cw + K_E2;
+    unsigned char* Dimg = cw + K_D;
+    unsigned char* Ximg = cw + K_X;
+    _Float16* rowoh = reinterpret_cast<_Float16*>(cw + K_SMALL);  // [5][32]: (object row of sample k == r), row 4 ones
     const float* Bl_h = reinterpret_cast<const float*>(smem + L8_BL) + 33 * h;
 
     // one lane's inputs of a tile; past the end: a dead tile (all-zero gradients, any valid row)
@@ -382,6 +392,25 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
       cur = nxt;
       P8SYNC();                   // B(XYZ): the dW waves are done with this tile's images
     }
+    {  // publish this wave's partial sums (the last barrier has passed: the dW waves no longer read the row table
+       // this aliases): [0..31] d w_sigma, [32] d b_sigma, [64..126] dB
+      float* small = reinterpret_cast<float*>(cw + K_SMALL);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float v = half_sum_dpp(DWS(i));
+        if (col == 31) small[acc_row(i, h)] = v;
+      }
+      {
+        const float v = half_sum_dpp(DBS);  // zero in lane half 1
+        if (lane == 31) small[32] = v;
+      }
+#pragma unroll
+      for (int i = 0; i < 33; ++i) {
+        const float v = half_sum_dpp(DBACC(i));
+        const int d = i / 3;
+        if (col == 31 && !(h == 1 && d == 10)) small[64 + (11 * h + d) * 3 + (i % 3)] = v;
+      }
+    }
   } else {
     // ===================================================================================================
     // dW role: 8 accumulator blocks per wave, six tiles per step
@@ -411,14 +440,14 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
         u4v fR[DEPTH][2];          // row one-hot operand of the row sums
         auto load_blk = [&](int w, auto kind_c, auto slot_c) {
           constexpr int kind = decltype(kind_c)::value, slot = decltype(slot_c)::value;
-          const unsigned char* cb = chain_base + w * C8_BYTES;
+          const unsigned char* cb = chain_base + w * K_BYTES;
           const unsigned char* ximg;
           int stride = 0, col0 = 0;
-          if (kind == BK_VD_E0 || kind == BK_VD_E1) { ximg = cb + C8_E2; stride = ST_E2; col0 = kind == BK_VD_E1 ? 32 : 0; }
-          else if (kind == BK_CAT_E0 || kind == BK_XYZ_E0) { ximg = cb + C8_E1; stride = ST_E1; col0 = 0; }
-          else if (kind == BK_CAT_E1 || kind == BK_XYZ_E1) { ximg = cb + C8_E1; stride = ST_E1; col0 = 32; }
-          else if (kind == BK_CAT_E2 || kind == BK_XYZ_E2) { ximg = cb + C8_E1; stride = ST_E1; col0 = 64; }
-          else ximg = cb + C8_X;
+          if (kind == BK_VD_E0 || kind == BK_VD_E1) { ximg = cb + K_E2; stride = ST_E2; col0 = kind == BK_VD_E1 ? 32 : 0; }
+          else if (kind == BK_CAT_E0 || kind == BK_XYZ_E0) { ximg = cb + K_E1; stride = ST_E1; col0 = 0; }
+          else if (kind == BK_CAT_E1 || kind == BK_XYZ_E1) { ximg = cb + K_E1; stride = ST_E1; col0 = 32; }
+          else if (kind == BK_CAT_E2 || kind == BK_XYZ_E2) { ximg = cb + K_E1; stride = ST_E1; col0 = 64; }
+          else ximg = cb + K_X;
           if (stride == 0) {  // the step's input image (swizzled rows)
             fX[w % DEPTH][slot][0] = tr_frag_hs(ximg, 0, lane);
             fX[w % DEPTH][slot][1] = tr_frag_hs(ximg, 1, lane);
@@ -433,15 +462,15 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
           Wacc[li] = MFMA(fD[w % DEPTH][1], fX[w % DEPTH][slot][1], Wacc[li]);
         };
         auto load_tile = [&](int w) {
-          const unsigned char* cb = chain_base + w * C8_BYTES;
-          fD[w % DEPTH][0] = tr_frag_hs(cb + C8_D, 0, lane);
-          fD[w % DEPTH][1] = tr_frag_hs(cb + C8_D, 1, lane);
+          const unsigned char* cb = chain_base + w * K_BYTES;
+          fD[w % DEPTH][0] = tr_frag_hs(cb + K_D, 0, lane);
+          fD[w % DEPTH][1] = tr_frag_hs(cb + K_D, 1, lane);
           if constexpr (OWN0) load_blk(w, IC<K0>{}, IC<SL0>{});
           if constexpr (OWN1) load_blk(w, IC<K1>{}, IC<SL1>{});
           if constexpr (OWN2) load_blk(w, IC<K2>{}, IC<SL2>{});
           if constexpr (OWN3) load_blk(w, IC<K3>{}, IC<SL3>{});
           if constexpr (DO_RS) {
-            const _Float16* rowoh = reinterpret_cast<const _Float16*>(cb + C8_SMALL);
+            const _Float16* rowoh = reinterpret_cast<const _Float16*>(cb + K_SMALL);
             fR[w % DEPTH][0] = __builtin_bit_cast(u4v, *reinterpret_cast<const h8*>(rowoh + m_row * 32 + 0 + 8 * h));
             fR[w % DEPTH][1] = __builtin_bit_cast(u4v, *reinterpret_cast<const h8*>(rowoh + m_row * 32 + 16 + 8 * h));
           }
@@ -484,32 +513,13 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
   }
 
   // ========================================= flush ====================================================
-  __syncthreads();
   float* rec = records + ((size_t)c * gridDim.x + blockIdx.x) * REC_FLOATS;
-  if (is_chain) {
-    float* small = reinterpret_cast<float*>(chain_base + wv * C8_BYTES + C8_SMALL);  // [0..31] d w_sigma, [32] d b_sigma, [64..126] dB
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const float v = half_sum_dpp(DWS(i));
-      if (col == 31) small[acc_row(i, h)] = v;
-    }
-    {
-      const float v = half_sum_dpp(DBS);  // zero in lane half 1
-      if (lane == 31) small[32] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < 33; ++i) {
-      const float v = half_sum_dpp(DBACC(i));
-      const int d = i / 3;
-      if (col == 31 && !(h == 1 && d == 10)) small[64 + (11 * h + d) * 3 + (i % 3)] = v;
-    }
-  }
   __syncthreads();
   {
     auto sum_chain = [&](int i) {
       float v = 0.0f;
 #pragma unroll
-      for (int w = 0; w < NCHW; ++w) v += reinterpret_cast<const float*>(chain_base + w * C8_BYTES + C8_SMALL)[i];
+      for (int w = 0; w < NCHW; ++w) v += reinterpret_cast<const float*>(chain_base + w * K_BYTES + K_SMALL)[i];
       return v;
     };
     for (int i = threadIdx.x; i < 63; i += NTHR) { rec[TRUNK + i] = sum_chain(64 + i) * inv_gs; rec[TRUNK + 63 + i] = 0.0f; }
@@ -577,7 +587,7 @@ extern "C" int cnr_field_bwd_pipe8_launch(const float* pts, const float* B, cons
     attr_set = true;
   }
   const int64_t N = (int64_t)R * S;
-  hipLaunchKernelGGL((field_bwd_pipe8_kernel<4, 4>), dim3((unsigned)blocks, (unsigned)C), dim3(512), l8_total(4),
+hipLaunchKernelGGL((field_bwd_pipe8_kernel<4, 4>), dim3((unsigned)blocks, (unsigned)C), dim3(512), l8_total(4),
                      (hipStream_t)stream, pts, B, (const unsigned char*)packed, biasrows, ray_row, 1.0f / scale, d_sigma,
                      d_rgb, grad_scale, (float*)workspace, (int)N, S, R, rows_per_class,
                      B_stride > 0 ? B_stride : (int64_t)63, rows_fix);

@@ -337,3 +337,41 @@ def test_forward_render_one_launch_equals_two(cnr, dev, C, R, S, L):
     with pytest.raises(cnr._C.CnrError):
         _C.call("cnr_field_fwd_render", pts, B, packed, brows, ray_row, 2.0, z, gt_d, gt_c, labels, dmask, 5.0, 10.0, 1.0,
                 ds1, dc1, d1, v1, r1, o1, C, R, 48, 0, ws1, ws1.numel(), None)
+
+
+@pytest.mark.parametrize("C,R,S", [(1, 2048, 64), (2, 1000, 96), (1, 8192, 128)])
+def test_field_bwd_full_size_all_variants_agree_and_repeat(cnr, dev, C, R, S):
+    """BASELINE sizes: every cnr_field_bwd implementation computes the same f16 pipeline, so the gradients agree to
+    fp32 summation order (1e-5 relative L2 per output against the block-split kernels), and a repeated call returns
+    the same bits (records + fixed-order reduction).  The repeat is the check that caught a register hazard which the
+    small fixtures never showed: hundreds of workgroups with several iterations each are needed to hit it."""
+    ops, _C = cnr.ops, cnr._C
+    n_obj, L = 4, 256
+    gen = torch.Generator().manual_seed(3)
+    theta, lay = cnr.fused.init_params(C, L, n_obj, gen, dev)
+    v = lay.views(theta)
+    packed = ops.pack_weights(v["trunk"].contiguous())
+    B = v["B"].contiguous()
+    pts = torch.rand(C, R, S, 3, device=dev) * 2 - 1
+    brows = torch.randn(C * n_obj, 4, 32, device=dev) * 0.1
+    ray_row = (torch.randint(0, n_obj, (C, R), device=dev) + torch.arange(C, device=dev)[:, None] * n_obj).to(torch.int32)
+    dsig = torch.randn(C, R, S, device=dev) * 1e-3
+    drgb = torch.randn(C, R, S, 3, device=dev) * 1e-3
+    wsp = torch.empty(_C.field_bwd_workspace_bytes(C, 0), device=dev, dtype=torch.uint8)
+
+    def run(variant):
+        dtrunk = torch.zeros(C, 13892, device=dev); dB = torch.zeros(C, 21, 3, device=dev); dbr = torch.zeros_like(brows)
+        ops.field_bwd(pts, B, packed, brows, ray_row, 2.0, dsig, drgb, 2048.0, dtrunk, dB, dbr, C, R, S, n_obj, 0, wsp,
+                      variant=variant)
+        torch.cuda.synchronize()
+        return dtrunk, dB, dbr
+
+    ref = run("split")
+    for variant in ("pipe2", "pipe3", "pipe4"):
+        first = run(variant)
+        for name, a, b in zip(("dtrunk", "dB", "dbiasrows"), first, ref):
+            assert rel_l2(a, b) < 1e-5, (variant, name, rel_l2(a, b))
+        for rep in range(3):
+            again = run(variant)
+            for name, a, b in zip(("dtrunk", "dB", "dbiasrows"), again, first):
+                assert torch.equal(a, b), (variant, name, rep, float((a - b).abs().max()))

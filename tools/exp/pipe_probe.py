@@ -5,6 +5,8 @@ sys.path.insert(0, ROOT)
 import torch
 import cnr_amd
 from cnr_amd import ops, _C
+if os.environ.get("CNR_TEST_LIB"):
+    _C.LIB_PATH = os.environ["CNR_TEST_LIB"]
 dev = torch.device("cuda:0")
 L, n_obj = 256, 4
 variant = sys.argv[1] if len(sys.argv) > 1 else "pipe4"
