@@ -26,7 +26,10 @@ __device__ long long g_pipe8_stamps[8 * 48];
 #define P8STAMP() do { if (blockIdx.x == 0 && lane == 0) \
     g_pipe8_stamps[wv * 48 + (pstamp_i++)] = (long long)__builtin_readcyclecounter(); } while (0)
 #define P8STAMP_RESET() int pstamp_i = 0
+#define P8PHASE(k) do { if (blockIdx.x == 0 && lane == 0) \
+    g_pipe8_stamps[wv * 48 + 40 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
+#define P8PHASE(k) do {} while (0)
 #define P8STAMP() do {} while (0)
 #define P8STAMP_RESET() do {} while (0)
 #endif
@@ -75,6 +78,7 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
   const int c = blockIdx.y;
   const int lane = threadIdx.x & 63, h = lane >> 5, col = lane & 31;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  P8PHASE(0);
   const bool is_chain = wv < NCHW;
   const int dwid = wv - NCHW;
   {
@@ -90,6 +94,7 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
     for (int i = threadIdx.x; i < rows_per_class * 128; i += NTHR) br[i] = biasrows[(size_t)c * rows_per_class * 128 + i];
   }
   __syncthreads();
+  P8PHASE(1);
   const float* cf = reinterpret_cast<const float*>(smem + PK_OFF_CONST);
   const unsigned char* bwf = smem + PK_OFF_BWD;
   unsigned char* chain_base = smem + L8_CHAIN;
@@ -514,7 +519,18 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
 
   // ========================================= flush ====================================================
   float* rec = records + ((size_t)c * gridDim.x + blockIdx.x) * REC_FLOATS;
+  // where each trunk parameter's gradient will sit in the LDS image of the blocks: all of a thread's table entries
+  // are requested here, together (a load per loop trip, each waiting for the previous trip's store, cost 12 k cycles
+  // = 10 % of the kernel at 2048 x 64); they arrive while the partial sums and the blocks go to LDS
+  constexpr int NSRC = (TRUNK + NTHR - 1) / NTHR;
+  int psrc[NSRC];
+#pragma unroll
+  for (int k = 0; k < NSRC; ++k) {
+    const int j = threadIdx.x + k * NTHR;
+    psrc[k] = j < TRUNK ? g_param_src[j] : -1;
+  }
   __syncthreads();
+  P8PHASE(2);
   {
     auto sum_chain = [&](int i) {
       float v = 0.0f;
@@ -527,6 +543,7 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
     if (threadIdx.x == 0) rec[OFF_SG_B] = sum_chain(32) * inv_gs;
   }
   __syncthreads();  // everything above has been read: the accumulator image may alias it
+  P8PHASE(3);
   if (!is_chain) {
     float* region = reinterpret_cast<float*>(smem);
 #define CNR_PSTORE8(KIND)                                                                     \
@@ -551,11 +568,13 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
 #undef CNR_PSTORE8
   }
   __syncthreads();
+  P8PHASE(4);
   {
     const float* region = reinterpret_cast<const float*>(smem);
-    for (int j = threadIdx.x; j < TRUNK; j += NTHR) {  // coalesced record stores, LDS gather
-      const int src = g_param_src[j];
-      if (src >= 0) rec[j] = region[src] * inv_gs;
+#pragma unroll
+    for (int k = 0; k < NSRC; ++k) {  // coalesced record stores, LDS gather (indices fetched before the flush began)
+      const int j = threadIdx.x + k * NTHR;
+      if (psrc[k] >= 0) rec[j] = region[psrc[k]] * inv_gs;
     }
     const float* rs = region + RS8_REGION * 1024;  // [m][feature]
     for (int i = threadIdx.x; i < 32; i += NTHR) rec[OFF_ES_B + i] = rs[16 * 32 + i] * inv_gs;
@@ -569,6 +588,7 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
                   (unsigned long long)__double2ll_rn((double)v * cnr_rec::ROWS_FIX_SCALE));
     }
   }
+  P8PHASE(5);
 }
 }  // namespace
 

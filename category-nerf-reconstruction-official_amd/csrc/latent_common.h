@@ -166,6 +166,143 @@ __device__ __forceinline__ void latent_bwd_block(const float* __restrict__ th, c
     }
   }
 }
+// The same block for the step's last launch (tail.hip), n_obj <= 4 and L <= 256, ONE trip per block, no trunk
+// group: latent_bwd_block spends its time in four dependent memory round trips (bias-row sums -> d pre operands ->
+// code norms -> the element's own operands), each behind a barrier.  None of those loads depends on another one's
+// VALUE, so here all of them are issued before the first barrier and the block pays one round trip.
+// Same expressions in the same order as latent_bwd_block: same bits.
+//   rows_fix_c: this class's (n_obj,4,32) entries of copy 0 of the fixed-point bias-row table, copy_stride entries
+//   between copies; rows_out (block 0 only, may be null): the float rows are also published there.
+template <class Sink>
+__device__ __forceinline__ void latent_bwd_block_1trip(const float* __restrict__ th, const FlatLayout& lay,
+                                                       const float* __restrict__ z,
+                                                       const long long* __restrict__ rows_fix_c, int64_t copy_stride,
+                                                       int ncopies, double fix_inv_scale, float* __restrict__ rows_out,
+                                                       float reg_scale, float* sm, const Sink& sink, int blk) {
+  const int n_obj = lay.n_obj, L = lay.L, nrow = n_obj * 128;
+  float* rows = sm;                 // [n_obj * 128] d biasrows
+  float* dpre = rows + nrow;        // [n_obj * 128]
+  float* inv_s = dpre + nrow;       // [n_obj]
+  float* inv_t = inv_s + n_obj;     // [n_obj]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // ---- phase 0: every global load of the block -------------------------------------------------------------
+  long long fx[2][8];
+  float thv[2][32], zv[2];
+#pragma unroll
+  for (int sl = 0; sl < 2; ++sl) {
+    const int i = threadIdx.x + 256 * sl;
+    const bool on = i < nrow;
+    const int ii = on ? i : 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) fx[sl][k] = (on && k < ncopies) ? rows_fix_c[(int64_t)k * copy_stride + ii] : 0;
+    const int kk = (ii >> 5) & 3, j = ii & 31;
+    int w_off, b_off, ld;
+    latent_target(kk, w_off, b_off, ld);
+#pragma unroll
+    for (int o = 0; o < 32; ++o) thv[sl][o] = th[w_off + o * ld + j];
+    zv[sl] = z[ii];
+  }
+  float cvn[2][4];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int t = wv + 4 * r;
+    const bool on = t < 2 * n_obj;
+    const int ob = on ? t % n_obj : 0;
+    const float* code = th + ((on && t >= n_obj) ? lay.tex : lay.shape) + (int64_t)ob * L;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int l = lane + 64 * j; cvn[r][j] = (on && l < L) ? code[l] : 0.0f; }
+  }
+  const int n0 = 4 * 32 * 33, n1 = n0 + 4 * 32 * L, n2 = n1 + 128, n3 = n2 + n_obj * L, n4 = n3 + n_obj * L;
+  const int t = n0 + blk * 256 + threadIdx.x;
+  float opv[96];  // the element's own operands (which, depends on its group)
+  float own = 0.0f;
+  if (t < n1) {
+    const int i = t - n0, k = i / (32 * L), l = (i % (32 * L)) % L;
+    sink.prefetch(lay.latW + i);
+    const float* cbase = th + (k == 3 ? lay.tex : lay.shape) + l;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) opv[u] = u < n_obj ? cbase[(int64_t)u * L] : 0.0f;
+  } else if (t < n2) {
+    sink.prefetch(lay.latb + (t - n1));
+  } else if (t < n3) {
+    const int i = t - n2, l = i % L;
+    sink.prefetch(lay.shape + i);
+#pragma unroll
+    for (int ko = 0; ko < 96; ++ko) opv[ko] = th[lay.latW + (int64_t)ko * L + l];
+    own = th[lay.shape + i];
+  } else if (t < n4) {
+    const int i = t - n3, l = i % L;
+    sink.prefetch(lay.tex + i);
+#pragma unroll
+    for (int o = 0; o < 32; ++o) opv[o] = th[lay.latW + (int64_t)(96 + o) * L + l];
+    own = th[lay.tex + i];
+  }
+  // ---- phase 1: bias-row sums as floats ----------------------------------------------------------------------
+#pragma unroll
+  for (int sl = 0; sl < 2; ++sl) {
+    const int i = threadIdx.x + 256 * sl;
+    if (i < nrow) {
+      long long tt = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) tt += fx[sl][k];
+      const float v = (float)((double)tt * fix_inv_scale);
+      rows[i] = v;
+      if (rows_out) rows_out[i] = v;
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: d z -> d pre ; code norms ---------------------------------------------------------------------
+#pragma unroll
+  for (int sl = 0; sl < 2; ++sl) {
+    const int i = threadIdx.x + 256 * sl;
+    if (i < nrow) {
+      const int ob = i >> 7, k = (i >> 5) & 3;
+      float s = 0.0f;
+#pragma unroll
+      for (int o = 0; o < 32; ++o) s = fmaf(rows[(ob * 4 + k) * 32 + o], thv[sl][o], s);
+      dpre[i] = zv[sl] > 0.0f ? s : 0.0f;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int tt = wv + 4 * r;
+    if (tt < 2 * n_obj) {
+      float s = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s = fmaf(cvn[r][j], cvn[r][j], s);
+      s = wave_sum(s);
+      if (lane == 0) (tt < n_obj ? inv_s : inv_t)[tt % n_obj] = reg_scale / sqrtf(s);
+    }
+  }
+  __syncthreads();
+  // ---- phase 3: this thread's element ---------------------------------------------------------------------------
+  if (t < n1) {
+    const int i = t - n0, k = i / (32 * L), o = (i % (32 * L)) / L;
+    float s = 0.0f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (u < n_obj) s = fmaf(dpre[(u * 4 + k) * 32 + o], opv[u], s);
+    sink.latent_set(lay.latW + i, s);
+  } else if (t < n2) {
+    const int i = t - n1;
+    float s = 0.0f;
+    for (int ob = 0; ob < n_obj; ++ob) s += dpre[ob * 128 + i];
+    sink.latent_set(lay.latb + i, s);
+  } else if (t < n3) {
+    const int i = t - n2, ob = i / L;
+    float s = 0.0f;
+#pragma unroll
+    for (int ko = 0; ko < 96; ++ko) s = fmaf(dpre[ob * 128 + ko], opv[ko], s);
+    sink.latent_set(lay.shape + i, s + inv_s[ob] * own);
+  } else if (t < n4) {
+    const int i = t - n3, ob = i / L;
+    float s = 0.0f;
+#pragma unroll
+    for (int o = 0; o < 32; ++o) s = fmaf(dpre[ob * 128 + 96 + o], opv[o], s);
+    sink.latent_set(lay.tex + i, s + inv_t[ob] * own);
+  }
+}
+
 // the trunk-entry term of that first group for ONE trunk index q of a class row (0 when q is not a latent-target
 // weight / bias): what latent_bwd_block would have added there.  For consumers that finish the trunk gradient
 // themselves (tail.hip).

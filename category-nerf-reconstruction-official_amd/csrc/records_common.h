@@ -20,17 +20,27 @@ __device__ __forceinline__ bool rec_entry_written(int i, int rows_per_class) {
   if (i < TRUNK + 126) return true;
   return rows_per_class <= ROWS_LDS && (i - (TRUNK + 126)) < rows_per_class * 128;
 }
-// sum of entry i over records [w0, w1) of one class (r = that class's first record + i), 8 loads in flight
+// sum of entry i over records [w0, w1) of one class (r = that class's first record + i).  32 loads in flight per
+// thread: the reducing kernels run a few waves per CU, so the loads in flight per thread are what hides the memory
+// latency (8 in flight: 64 records = 8 round trips = 8 us; 32: 2 round trips).  Fixed order -> reproducible bits.
 __device__ __forceinline__ float record_range_sum(const float* __restrict__ r, int w0, int w1) {
-  float a[8];
+  constexpr int U = 32;
+  float a[U];
 #pragma unroll
-  for (int u = 0; u < 8; ++u) a[u] = 0.0f;
+  for (int u = 0; u < U; ++u) a[u] = 0.0f;
   int w = w0;
-  for (; w + 7 < w1; w += 8) {
+  for (; w + U - 1 < w1; w += U) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) a[u] += r[(size_t)(w + u) * REC_FLOATS];
+    for (int u = 0; u < U; ++u) a[u] += r[(size_t)(w + u) * REC_FLOATS];
   }
-  for (; w < w1; ++w) a[0] += r[(size_t)w * REC_FLOATS];
-  return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+#pragma unroll
+  for (int u = 0; u < U; ++u)   // the rest (< U records), still issued together
+    if (w + u < w1) a[u] += r[(size_t)(w + u) * REC_FLOATS];
+#pragma unroll
+  for (int st = U / 2; st >= 1; st >>= 1) {
+#pragma unroll
+    for (int u = 0; u < st; ++u) a[u] += a[u + st];
+  }
+  return a[0];
 }
 }  // namespace cnr_rec

@@ -78,8 +78,27 @@ __device__ __forceinline__ void load_rows_fix(const TailArgs& a, int c, float* d
   __syncthreads();
 }
 
+#ifdef CNR_TAIL_STAMPS  // tools/exp only
+__device__ unsigned long long g_tail_t[8];  // [type 0..2][min start, max end], [6] = min start over all
+#define TAIL_T0() const unsigned long long tt0 = __builtin_amdgcn_s_memrealtime(); \
+  if (threadIdx.x == 0) atomicMin(&g_tail_t[6], tt0)
+#define TAIL_T1(type) do { __syncthreads(); if (threadIdx.x == 0) { atomicMin(&g_tail_t[2 * (type)], tt0); \
+  atomicMax(&g_tail_t[2 * (type) + 1], __builtin_amdgcn_s_memrealtime()); } } while (0)
+extern "C" int cnr_tail_stamps(unsigned long long* host, int reset) {
+  if (reset) {
+    unsigned long long init[8] = {~0ull, 0, ~0ull, 0, ~0ull, 0, ~0ull, 0};
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_tail_t), init, sizeof(init));
+  }
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tail_t), sizeof(unsigned long long) * 8);
+}
+#else
+#define TAIL_T0() do {} while (0)
+#define TAIL_T1(type) do {} while (0)
+#endif
+
 __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
   extern __shared__ float sm[];
+  TAIL_T0();
   const int C = a.C, P = (int)a.lay.stride;
   const int nlat = a.do_latent ? a.NL * C : 0;
   int b = blockIdx.x;
@@ -93,6 +112,16 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
     AdamSink sink{a, (int64_t)c * P, step_size, inv_bc2_sqrt};
     const float* dbr = a.dbiasrows + (int64_t)c * a.lay.n_obj * 128;
     float* scratch = sm;
+    const int64_t nlat_out = (int64_t)4 * 32 * a.lay.L + 128 + (int64_t)2 * a.lay.n_obj * a.lay.L;
+    if (a.rows_fix && a.lay.n_obj <= 4 && a.lay.L <= 256 && (int64_t)a.NL * 256 >= nlat_out) {
+      // the common case: one element per thread, every load of the block in one round trip
+      const int n = a.lay.n_obj * 128;
+      latent_bwd_block_1trip(a.theta_in + (int64_t)c * P, a.lay, a.zl + (int64_t)c * n, a.rows_fix + (size_t)c * n,
+                             (int64_t)a.C * n, cnr_rec::ROWS_FIX_COPIES, 1.0 / cnr_rec::ROWS_FIX_SCALE,
+                             blk == 0 ? a.dbiasrows + (int64_t)c * n : nullptr, a.reg_scale, sm, sink, blk);
+      TAIL_T1(0);
+      return;
+    }
     if (a.rows_fix) {  // rows from the fixed-point table (block 0 of the class also publishes them as floats)
       float* rows = sm;
       load_rows_fix(a, c, rows);
@@ -144,6 +173,7 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
         pi -= step_size * (mi / denom);
         a.theta_out[idx] = pi; a.m[idx] = mi; a.v[idx] = vi;
       }
+      TAIL_T1(1);
       return;
     }
     b -= a.NR * C;
@@ -174,9 +204,22 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
   if (wv == 0) cnr_rl::finish_class(a.partials, a.nb, a.losses, a.flags, C, c, lane);
   if (a.max_bound) {
     float mx = -INFINITY;
-    const int64_t base = (int64_t)c * a.pool_rows + cursor;
-    for (int r = threadIdx.x; r < a.R; r += 256)
-      mx = fmaxf(mx, a.depth[a.perm ? (int64_t)c * a.pool_rows + a.perm[base + r] : base + r]);
+    const int64_t cbase = (int64_t)c * a.pool_rows, base = cbase + cursor;
+    // this block is the launch's critical path (cursor -> permutation entry -> depth are dependent loads): eight rays
+    // per thread at a time, all permutation entries together, then all depths together = two round trips per 2048 rays
+    for (int r0 = 0; r0 < a.R; r0 += 8 * 256) {
+      int64_t at[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int r = r0 + u * 256 + threadIdx.x;
+        at[u] = r < a.R ? (a.perm ? cbase + a.perm[base + r] : base + r) : -1;
+      }
+      float d[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) d[u] = at[u] >= 0 ? a.depth[at[u]] : -INFINITY;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) mx = fmaxf(mx, d[u]);
+    }
     mx = wave_max(mx);
     if (lane == 0) red[wv] = mx;
     __syncthreads();
@@ -185,6 +228,7 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
   if (c == 0 && threadIdx.x == 0) {
     a.state_next[0] = cursor; a.state_next[1] = a.state_cur[1] + 1; a.state_next[2] = a.state_cur[2] + 1;
   }
+  TAIL_T1(2);
 }
 }  // namespace
 

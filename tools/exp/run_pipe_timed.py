@@ -41,6 +41,9 @@ for it in range(3):
             print(rc, "wave", w, "t0", st[0] - base, "total", st[36] - st[0], "sum work", sum(work), "sum wait", sum(wait))
             print("      work", work)
             print("      wait", wait)
+            ph = list(buf)[w * 48 + 40: w * 48 + 46]
+            print("      phases: start->weights in LDS", ph[1] - ph[0], "loops", ph[2] - ph[1], "partial sums -> record", ph[3] - ph[2],
+                  "blocks -> LDS image", ph[4] - ph[3], "image -> record", ph[5] - ph[4], "| total", ph[5] - ph[0])
         continue
     buf = (ctypes.c_longlong * 160)()
     lib.cnr_pipe_read_stamps(buf)
