@@ -114,6 +114,24 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ tru
 // and the zero fill of the gradient buffers.  grid (NPACK + 4 n_obj + nzero, C).
 // With sample blocks appended (cnr_step_prologue) the sampler -- which depends on the ray pool and the step state
 // only -- runs beside them as well: grid (NPACK + 4 n_obj + nzero + ceil(R / 4), C), one wavefront per ray.
+#ifdef CNR_PREP_STAMPS  // tools/exp only: earliest start / latest end per job of the prologue launch (100 MHz counter)
+__device__ unsigned long long g_prep_t[10];  // [job 0..3][min start, max end], [8] = min start over all
+#define PREP_T0() const unsigned long long tt0 = __builtin_amdgcn_s_memrealtime(); \
+  if (threadIdx.x == 0) atomicMin(&g_prep_t[8], tt0)
+#define PREP_T1(job) do { __syncthreads(); if (threadIdx.x == 0) { atomicMin(&g_prep_t[2 * (job)], tt0); \
+  atomicMax(&g_prep_t[2 * (job) + 1], __builtin_amdgcn_s_memrealtime()); } } while (0)
+extern "C" int cnr_prep_stamps(unsigned long long* host, int reset) {
+  if (reset) {
+    unsigned long long init[10] = {~0ull, 0, ~0ull, 0, ~0ull, 0, ~0ull, 0, ~0ull, 0};
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_prep_t), init, sizeof(init));
+  }
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_prep_t), sizeof(unsigned long long) * 10);
+}
+#else
+#define PREP_T0() do {} while (0)
+#define PREP_T1(job) do {} while (0)
+#endif
+
 __global__ __launch_bounds__(256) void param_prep_kernel(const float* __restrict__ theta, cnr::FlatLayout lay,
                                                          int64_t off_trunk, unsigned char* __restrict__ packed,
                                                          float* __restrict__ zl, float* __restrict__ biasrows,
@@ -123,13 +141,15 @@ __global__ __launch_bounds__(256) void param_prep_kernel(const float* __restrict
   const int c = blockIdx.y, C = gridDim.y;
   const float* th = theta + (int64_t)c * lay.stride;
   int b = blockIdx.x;
-  if (b < NPACK) { pack_block(th + off_trunk, packed + (size_t)c * PK_BYTES, b); return; }
+  PREP_T0();
+  if (b < NPACK) { pack_block(th + off_trunk, packed + (size_t)c * PK_BYTES, b); PREP_T1(0); return; }
   b -= NPACK;
-  if (b < 4 * lay.n_obj) { cnr::latent_fwd_block(th, th + off_trunk, lay, zl, biasrows, b >> 2, b & 3, c); return; }
+  if (b < 4 * lay.n_obj) { cnr::latent_fwd_block(th, th + off_trunk, lay, zl, biasrows, b >> 2, b & 3, c); PREP_T1(1); return; }
   b -= 4 * lay.n_obj;
   if (b >= nzero) {  // a2-a5: four rays of class c per block
     const int r = (b - nzero) * 4 + (threadIdx.x >> 6);
     if (nsample > 0 && r < sa.R) cnr_sample::sample_ray(sa, (int64_t)c * sa.R + r, threadIdx.x & 63);
+    PREP_T1(3);
     return;
   }
   // zero fill: block (b, c) of nzero * C takes a contiguous float4 range
@@ -139,6 +159,7 @@ __global__ __launch_bounds__(256) void param_prep_kernel(const float* __restrict
   f4 z4 = {0.f, 0.f, 0.f, 0.f};
   for (int64_t i = lo + threadIdx.x; i < hi; i += 256) reinterpret_cast<f4*>(zero_buf)[i] = z4;
   if (me == 0 && threadIdx.x < (zero_count & 3)) zero_buf[(nvec << 2) + threadIdx.x] = 0.0f;
+  PREP_T1(2);
 }
 
 }  // namespace
