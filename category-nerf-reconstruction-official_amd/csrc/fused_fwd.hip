@@ -127,9 +127,15 @@ extern "C" int cnr_prep_stamps(unsigned long long* host, int reset) {
   }
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_prep_t), sizeof(unsigned long long) * 10);
 }
+__device__ unsigned long long g_fr_t[8];  // field_fwd_render, block 0 / wave 0: phase boundaries (shader clock)
+#define FR_T(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_fr_t[k] = (unsigned long long)__builtin_readcyclecounter(); } while (0)
+extern "C" int cnr_fwd_render_stamps(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_fr_t), sizeof(unsigned long long) * 8);
+}
 #else
 #define PREP_T0() do {} while (0)
 #define PREP_T1(job) do {} while (0)
+#define FR_T(k) do {} while (0)
 #endif
 
 __global__ __launch_bounds__(256) void param_prep_kernel(const float* __restrict__ theta, cnr::FlatLayout lay,
@@ -326,10 +332,31 @@ __global__ __launch_bounds__(256, 2) void field_fwd_render_kernel(
     int64_t B_stride, float* __restrict__ partials, const unsigned char* __restrict__ packed_lo) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ float cnt[12];
-  if (SPLIT) stage_lo(smem, packed_lo, blockIdx.y);
+  __shared__ float cntw[4][3 * 16];  // per wave, per class: the three mask counts (register path below)
+  FR_T(0);
   constexpr int S = 32 * K;
   const int c = blockIdx.y;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, h = lane >> 5, col = lane & 31;
+  // ---- mask counts of every class (the empty-mask rule of render_rays.py:67-72 couples the classes).  Every block needs
+  // them, but only for the loss gradients: their loads go out FIRST, four rays per 32-bit word, and are counted after
+  // the weight copy below has landed -- the scan used to be a memory round trip of its own behind that copy (5.7 k of
+  // the 28 k cycles a block lives).  Register path: C * ceil(R / 1024) <= 8 words per array and thread, R % 4 == 0,
+  // C <= 16; anything else takes the loop further down.
+  constexpr int MAXW = 8;
+  const int nw = (R + 1023) / 1024;
+  const bool counts_in_regs = C * nw <= MAXW && (R & 3) == 0 && C <= 16;
+  unsigned int lw[MAXW], mw[MAXW];
+  if (counts_in_regs) {
+#pragma unroll
+    for (int i = 0; i < MAXW; ++i) {
+      const int cc = i / nw, r4 = ((i % nw) * 256 + (int)threadIdx.x) * 4;
+      const bool on = i < C * nw && r4 < R;
+      lw[i] = on ? *reinterpret_cast<const unsigned int*>(labels + (size_t)cc * R + r4) : 0u;
+      mw[i] = on ? *reinterpret_cast<const unsigned int*>(depth_mask + (size_t)cc * R + r4) : 0xffffffffu;
+      if (!on) lw[i] = 0xffffffffu;  // marks "no rays here" (labels are 0, 1 or 2)
+    }
+  }
+  if (SPLIT) stage_lo(smem, packed_lo, blockIdx.y);
   {
     const unsigned char* src = packed + (size_t)c * PK_BYTES;
     for (int i = threadIdx.x * 16; i < PK_OFF_BWD; i += 256 * 16)
@@ -340,26 +367,53 @@ __global__ __launch_bounds__(256, 2) void field_fwd_render_kernel(
       Bl[i] = (hh == 1 && d == 10) ? 0.0f : Bdir[(size_t)c * B_stride + (11 * hh + d) * 3 + (k % 3)];
     }
   }
-  // ---- mask counts of every class (the empty-mask rule of render_rays.py:67-72 couples the classes) ---------------
+  FR_T(1);
   bool empty_d = false, empty_c = false, empty_o = false;
   float nd = 0.f, nc = 0.f, no = 0.f;
-  for (int cc = 0; cc < C; ++cc) {
-    float a = 0.f, b = 0.f, d = 0.f;
-    for (int r = threadIdx.x; r < R; r += 256) {
-      const uint8_t lab = labels[(size_t)cc * R + r];
-      const bool mo = lab != 0, ms = lab != 2, md = depth_mask[(size_t)cc * R + r] != 0;
-      a += (md && mo) ? 1.f : 0.f; b += mo ? 1.f : 0.f; d += ms ? 1.f : 0.f;
+  if (counts_in_regs) {
+    for (int cc = 0; cc < C; ++cc) {
+      float a = 0.f, b = 0.f, d = 0.f;
+#pragma unroll
+      for (int i = 0; i < MAXW; ++i) {
+        if (i / nw != cc || lw[i] == 0xffffffffu) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const unsigned int lab = (lw[i] >> (8 * j)) & 0xffu, dm = (mw[i] >> (8 * j)) & 0xffu;
+          const bool mo = lab != 0, ms = lab != 2, md = dm != 0;
+          a += (md && mo) ? 1.f : 0.f; b += mo ? 1.f : 0.f; d += ms ? 1.f : 0.f;
+        }
+      }
+      a = cnr::wave_sum(a); b = cnr::wave_sum(b); d = cnr::wave_sum(d);  // counts: exact in fp32 in any order
+      if (lane == 0) { cntw[wv][cc * 3 + 0] = a; cntw[wv][cc * 3 + 1] = b; cntw[wv][cc * 3 + 2] = d; }
     }
-    a = cnr::wave_sum(a); b = cnr::wave_sum(b); d = cnr::wave_sum(d);
+    __syncthreads();  // also: the weight fragments are in LDS
+    for (int cc = 0; cc < C; ++cc) {
+      const float a = (cntw[0][cc * 3 + 0] + cntw[1][cc * 3 + 0]) + (cntw[2][cc * 3 + 0] + cntw[3][cc * 3 + 0]);
+      const float b = (cntw[0][cc * 3 + 1] + cntw[1][cc * 3 + 1]) + (cntw[2][cc * 3 + 1] + cntw[3][cc * 3 + 1]);
+      const float d = (cntw[0][cc * 3 + 2] + cntw[1][cc * 3 + 2]) + (cntw[2][cc * 3 + 2] + cntw[3][cc * 3 + 2]);
+      empty_d |= (a == 0.f); empty_c |= (b == 0.f); empty_o |= (d == 0.f);
+      if (cc == c) { nd = a; nc = b; no = d; }
+    }
+  } else {
+    for (int cc = 0; cc < C; ++cc) {
+      float a = 0.f, b = 0.f, d = 0.f;
+      for (int r = threadIdx.x; r < R; r += 256) {
+        const uint8_t lab = labels[(size_t)cc * R + r];
+        const bool mo = lab != 0, ms = lab != 2, md = depth_mask[(size_t)cc * R + r] != 0;
+        a += (md && mo) ? 1.f : 0.f; b += mo ? 1.f : 0.f; d += ms ? 1.f : 0.f;
+      }
+      a = cnr::wave_sum(a); b = cnr::wave_sum(b); d = cnr::wave_sum(d);
+      __syncthreads();
+      if (lane == 0) { cnt[wv] = a; cnt[4 + wv] = b; cnt[8 + wv] = d; }
+      __syncthreads();
+      a = (cnt[0] + cnt[1]) + (cnt[2] + cnt[3]); b = (cnt[4] + cnt[5]) + (cnt[6] + cnt[7]);
+      d = (cnt[8] + cnt[9]) + (cnt[10] + cnt[11]);
+      empty_d |= (a == 0.f); empty_c |= (b == 0.f); empty_o |= (d == 0.f);
+      if (cc == c) { nd = a; nc = b; no = d; }
+    }
     __syncthreads();
-    if (lane == 0) { cnt[wv] = a; cnt[4 + wv] = b; cnt[8 + wv] = d; }
-    __syncthreads();
-    a = (cnt[0] + cnt[1]) + (cnt[2] + cnt[3]); b = (cnt[4] + cnt[5]) + (cnt[6] + cnt[7]);
-    d = (cnt[8] + cnt[9]) + (cnt[10] + cnt[11]);
-    empty_d |= (a == 0.f); empty_c |= (b == 0.f); empty_o |= (d == 0.f);
-    if (cc == c) { nd = a; nc = b; no = d; }
   }
-  __syncthreads();
+  FR_T(2);
   const float wd = empty_d ? 0.f : 1.0f / (nd + 1e-10f);
   const float wc = empty_c ? 0.f : 1.0f / (nc + 1e-10f);
   const float wo = empty_o ? 0.f : 1.0f / (no + 1e-10f);
@@ -413,6 +467,7 @@ __global__ __launch_bounds__(256, 2) void field_fwd_render_kernel(
       const float term = occ[t] * T[t];
       sd += term * zz[t]; so += term; sr += term * c0[t]; sg += term * c1[t]; sb += term * c2[t];
       carry *= __shfl(incl, 31, 64);
+      FR_T(3 + t);
     }
     sd = cnr::wave_sum(sd); so = cnr::wave_sum(so);
     sr = cnr::wave_sum(sr); sg = cnr::wave_sum(sg); sb = cnr::wave_sum(sb);
@@ -462,6 +517,7 @@ __global__ __launch_bounds__(256, 2) void field_fwd_render_kernel(
       suf_carry += __shfl(incl_suf, 0, 64);
     }
   }
+  FR_T(7);
   // ---- loss values: block partials for finish_class -------------------------------------------------------------------
   __syncthreads();
   if (lane == 0) { cnt[wv] = ld; cnt[4 + wv] = lc; cnt[8 + wv] = lo; }

@@ -31,3 +31,9 @@ for it in range(6):
     lib.cnr_prep_stamps(pb, 0)
     t0 = pb[8]
     print("       prologue:", " | ".join(f"{n}: {(pb[2*i]-t0)/100:.2f} .. {(pb[2*i+1]-t0)/100:.2f} us" for i, n in enumerate(("pack", "latent fwd", "zero fill", "sample rays"))))
+    fb = (ctypes.c_ulonglong * 8)()
+    lib.cnr_fwd_render_stamps.argtypes = [ctypes.c_void_p]
+    lib.cnr_fwd_render_stamps(fb)
+    f = list(fb)
+    print("       fwd_render block 0 wave 0 (cycles): weights copy issued", f[1] - f[0], "| mask counts + barrier", f[2] - f[1],
+          "| tile 0 forward + composite", f[3] - f[2], "| tile 1", f[4] - f[3], "| losses + composite backward + stores", f[7] - f[4])
