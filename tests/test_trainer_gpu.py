@@ -28,6 +28,7 @@ def _oracle_params(cnr, tr, theta):
 
 @pytest.mark.parametrize("C,R,n1,n2,L", [(1, 256, 4, 28, 256), (2, 128, 8, 56, 32)])
 def test_fused_train_step_against_oracle(cnr, dev, C, R, n1, n2, L):
+    torch.manual_seed(1234)  # the trainer draws its epoch permutation from the default generator
     cfg = cnr.cfg.synthetic_config(device=str(dev), latent_dim=L, n_bins_cam2surface=n1, n_bins=n2)
     gen = torch.Generator().manual_seed(7)
     pools = [cnr.scene_cateogries.synthetic_pool(8 * R, 4, gen, "cpu") for _ in range(C)]
@@ -79,7 +80,12 @@ def test_fused_train_step_against_oracle(cnr, dev, C, R, n1, n2, L):
     old = tr.lay.views(theta0.cpu())
     upd_ref = (B.detach() - old["B"]).reshape(-1)
     upd_got = (new["B"] - old["B"]).reshape(-1)
-    assert float((torch.sign(upd_ref) == torch.sign(upd_got)).float().mean()) > 0.97
+    # ... on the entries whose reference gradient is not noise (an f16-pipeline gradient within rounding of zero takes
+    # either sign; which entries those are depends on the sampled batch)
+    g_ref = B.grad.reshape(-1).abs()
+    clear = g_ref > 0.02 * g_ref.max()
+    assert float(clear.float().mean()) > 0.5
+    assert float((torch.sign(upd_ref) == torch.sign(upd_got))[clear].float().mean()) > 0.97
 
 
 def test_graph_replay_trains(cnr, dev):
