@@ -340,7 +340,7 @@ def test_forward_render_one_launch_equals_two(cnr, dev, C, R, S, L):
                 ds1, dc1, d1, v1, r1, o1, C, R, 48, 0, ws1, ws1.numel(), None)
 
 
-@pytest.mark.parametrize("C,R,S", [(1, 2048, 64), (2, 1000, 96), (1, 8192, 128)])
+@pytest.mark.parametrize("C,R,S", [(1, 2048, 64), (2, 1000, 96), (1, 8192, 128), (1, 77, 240), (2, 50, 33), (1, 1, 1)])
 def test_field_bwd_full_size_all_variants_agree_and_repeat(cnr, dev, C, R, S):
     """BASELINE sizes: every cnr_field_bwd implementation computes the same f16 pipeline, so the gradients agree to
     fp32 summation order (1e-5 relative L2 per output against the block-split kernels), and a repeated call returns
@@ -376,3 +376,20 @@ def test_field_bwd_full_size_all_variants_agree_and_repeat(cnr, dev, C, R, S):
             again = run(variant)
             for name, a, b in zip(("dtrunk", "dB", "dbiasrows"), again, first):
                 assert torch.equal(a, b), (variant, name, rep, float((a - b).abs().max()))
+
+
+def test_field_bwd_pipe_refuses_more_than_240_samples(cnr, dev):
+    """The pipelined kernels divide by S with a 16-bit reciprocal that is exact up to S = 240 (sizes above are the
+    block-split kernels' job): a larger S is an error, not a wrong gradient."""
+    ops, _C = cnr.ops, cnr._C
+    C, R, S, n_obj = 1, 8, 241, 4
+    theta, lay = cnr.fused.init_params(C, 32, n_obj, torch.Generator().manual_seed(0), dev)
+    v = lay.views(theta)
+    packed = ops.pack_weights(v["trunk"].contiguous())
+    z = lambda *s: torch.zeros(*s, device=dev)
+    brows, ray_row = z(C * n_obj, 4, 32), torch.zeros(C, R, device=dev, dtype=torch.int32)
+    wsp = torch.empty(_C.field_bwd_workspace_bytes(C, 0), device=dev, dtype=torch.uint8)
+    for variant in ("pipe2", "pipe3", "pipe4"):
+        with pytest.raises(_C.CnrError):
+            ops.field_bwd(z(C, R, S, 3), v["B"].contiguous(), packed, brows, ray_row, 2.0, z(C, R, S), z(C, R, S, 3), 1.0,
+                          z(C, 13892), z(C, 21, 3), z(C * n_obj, 4, 32), C, R, S, n_obj, 0, wsp, variant=variant)
