@@ -36,6 +36,8 @@ struct TailArgs {
   // optional: the field backward's per-workgroup records (nwg per class) are reduced HERE, and the per-object
   // bias-row sums come from the fixed-point table the field backward accumulated with integer atomics
   const float* records; int nwg; const long long* rows_fix; int NR;
+  // grad_only: stop at the finished gradient (no AdamW, no epilogue blocks): the multi-GPU step all-reduces it first
+  int grad_only;
 };
 
 __device__ __forceinline__ void adam_one(const TailArgs& a, int64_t e, float g, float step_size, float inv_bc2_sqrt) {
@@ -52,11 +54,13 @@ struct AdamSink {  // latent-path gradient element -> gradient buffer (kept for 
   mutable float p0, m0, v0;  // parameter and moments of the element in work, loaded while its gradient is computed
   __device__ __forceinline__ void trunk_add(int, float) const {}
   __device__ __forceinline__ void prefetch(int64_t idx) const {
+    if (a.grad_only) return;
     p0 = a.theta_in[row0 + idx]; m0 = a.m[row0 + idx]; v0 = a.v[row0 + idx];
   }
   __device__ __forceinline__ void latent_set(int64_t idx, float g) const {
     const int64_t e = row0 + idx;
     a.grad[e] = g;
+    if (a.grad_only) return;
     float pi = p0 * (1.0f - a.lr * a.wd);
     const float mi = m0 + (g - m0) * (1.0f - a.b1);
     const float vi = v0 * a.b2 + (1.0f - a.b2) * g * g;
@@ -102,8 +106,8 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
   const int C = a.C, P = (int)a.lay.stride;
   const int nlat = a.do_latent ? a.NL * C : 0;
   int b = blockIdx.x;
-  float step_size, inv_bc2_sqrt;
-  {
+  float step_size = 0.0f, inv_bc2_sqrt = 0.0f;
+  if (!a.grad_only) {
     AdamArgs co{nullptr, nullptr, nullptr, nullptr, 0, a.lr, a.b1, a.b2, a.eps, a.wd, 1.0f};
     adam_coefficients(co, a.state_cur[2] + 1, step_size, inv_bc2_sqrt);
   }
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
       float s0 = 0.0f, s1 = 0.0f;
       const int64_t idx = (int64_t)c * P + (i < TRUNK ? i : a.off_B + (i - TRUNK));
       float p0 = 0.f, m0 = 0.f, v0 = 0.f;
-      if (q == 0 && owner) { p0 = a.theta_in[idx]; m0 = a.m[idx]; v0 = a.v[idx]; }   // in flight under the record sum
+      if (q == 0 && owner && !a.grad_only) { p0 = a.theta_in[idx]; m0 = a.m[idx]; v0 = a.v[idx]; }   // in flight under the record sum
       if (owner) {
         const int per = (a.nwg + 3) / 4, w0 = q * per, w1 = min(a.nwg, w0 + per);
         const float* r = a.records + (size_t)c * a.nwg * cnr_rec::REC_FLOATS + i;
@@ -166,12 +170,14 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
         if (i >= TRUNK) g += (part[256 + e] + part[320 + e]) + (part[384 + e] + part[448 + e]);
         if (i < TRUNK) g += latent_trunk_term(i, a.zl + (int64_t)c * a.lay.n_obj * 128, rows, a.lay.n_obj);
         a.grad[idx] = g;
-        float pi = p0 * (1.0f - a.lr * a.wd);
-        const float mi = m0 + (g - m0) * (1.0f - a.b1);
-        const float vi = v0 * a.b2 + (1.0f - a.b2) * g * g;
-        const float denom = sqrtf(vi) * inv_bc2_sqrt + a.eps;
-        pi -= step_size * (mi / denom);
-        a.theta_out[idx] = pi; a.m[idx] = mi; a.v[idx] = vi;
+        if (!a.grad_only) {
+          float pi = p0 * (1.0f - a.lr * a.wd);
+          const float mi = m0 + (g - m0) * (1.0f - a.b1);
+          const float vi = v0 * a.b2 + (1.0f - a.b2) * g * g;
+          const float denom = sqrtf(vi) * inv_bc2_sqrt + a.eps;
+          pi -= step_size * (mi / denom);
+          a.theta_out[idx] = pi; a.m[idx] = mi; a.v[idx] = vi;
+        }
       }
       TAIL_T1(1);
       return;
@@ -269,6 +275,34 @@ extern "C" int cnr_step_tail(const float* theta_in, float* theta_out, float* gra
   a.NA = (int)na;
   a.records = (const float*)records; a.nwg = nwg; a.rows_fix = rows_fix; a.NR = cnr_rec::REC_FLOATS / 64;
   const unsigned grid = (unsigned)((a.do_latent ? a.NL * C : 0) + (records ? a.NR * C : a.NA) + C);
+  const size_t lds = (size_t)(2 * n_obj * 128 + 2 * n_obj + 520) * sizeof(float);
+  hipLaunchKernelGGL(tail_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
+  CNR_LAUNCH_CHECK();
+  return CNR_OK;
+}
+
+// The gradient half of cnr_step_tail on its own, for a host that needs the finished gradient before the optimiser
+// (data parallel: all-reduce in between): fixed-order reduction of the field backward's records + latent backward +
+// code regulariser, side by side in one launch, into `grad` (class_stride floats per class, the layout of theta).
+// Afterwards: all-reduce, then cnr_step_tail(..., do_latent = 0, records = NULL, ...) for AdamW + epilogue.
+extern "C" int cnr_step_grad(const float* theta, float* grad, int64_t class_stride, int64_t off_B, int64_t off_latW,
+                             int64_t off_latb, int64_t off_shape, int64_t off_tex, int L, int n_obj, int C,
+                             const float* zl, float* dbiasrows, float reg_scale, const void* records, int nwg,
+                             const long long* rows_fix, void* stream) {
+  if (!theta || !grad || class_stride <= 0 || L <= 0 || n_obj <= 0 || C <= 0 || !zl || !dbiasrows || !records ||
+      nwg <= 0 || !rows_fix)
+    return CNR_E_ARG;
+  if (n_obj > cnr_rec::ROWS_LDS) return CNR_E_SHAPE;
+  TailArgs a{};
+  a.theta_in = theta; a.grad = grad;
+  a.lay = FlatLayout{class_stride, off_latW, off_latb, off_shape, off_tex, L, n_obj};
+  a.off_B = off_B; a.C = C; a.zl = zl; a.dbiasrows = dbiasrows; a.reg_scale = n_obj > 1 ? reg_scale : 0.0f;
+  a.do_latent = 1; a.grad_only = 1;
+  const int64_t nlat_out = (int64_t)4 * 32 * L + 128 + (int64_t)2 * n_obj * L;
+  a.NL = (int)((nlat_out + 255) / 256);
+  if (a.NL > 256) a.NL = 256;
+  a.records = (const float*)records; a.nwg = nwg; a.rows_fix = rows_fix; a.NR = cnr_rec::REC_FLOATS / 64;
+  const unsigned grid = (unsigned)(a.NL * C + a.NR * C);
   const size_t lds = (size_t)(2 * n_obj * 128 + 2 * n_obj + 520) * sizeof(float);
   hipLaunchKernelGGL(tail_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
   CNR_LAUNCH_CHECK();

@@ -95,10 +95,14 @@ class FusedCategoryTrainer:
         # ... plus (single GPU, <= 4 objects per class) the int64 fixed-point table of the per-object bias-row sums
         # that the field backward fills with integer atomics for cnr_step_tail
         n_th, n_db = self.theta.numel(), n_cls * n_obj * 128
-        self.fused_tail = process_group is None and n_obj <= 4 and ops.FIELD_BWD_VARIANT.startswith("pipe")
+        # the field backward leaves per-workgroup records + the fixed-point table; ONE later launch reduces them next to
+        # the latent backward: with AdamW and the epilogue on a single GPU (cnr_step_tail), gradient only with a process
+        # group (cnr_step_grad: the all-reduce comes between gradient and optimiser)
+        self.use_records = n_obj <= 4 and ops.FIELD_BWD_VARIANT.startswith("pipe")
+        self.fused_tail = process_group is None and self.use_records
         fix_off = (n_th + n_db + 3) // 4 * 4                      # 16-byte aligned
-        self._gbuf = torch.zeros(fix_off + (2 * 8 * n_db if self.fused_tail else 0), device=self.device)  # 8 copies
-        self.rows_fix = self._gbuf[fix_off:].view(torch.int64) if self.fused_tail else None
+        self._gbuf = torch.zeros(fix_off + (2 * 8 * n_db if self.use_records else 0), device=self.device)  # 8 copies
+        self.rows_fix = self._gbuf[fix_off:].view(torch.int64) if self.use_records else None
         self.grad = self._gbuf[:self.theta.numel()].view_as(self.theta)
         self.exp_avg = torch.zeros_like(self.theta)
         self.exp_avg_sq = torch.zeros_like(self.theta)
@@ -125,7 +129,7 @@ class FusedCategoryTrainer:
         self.flags = torch.zeros(n_cls, device=self.device, dtype=torch.int32)
         self.dbias = self._gbuf[n_th:n_th + n_db].view(n_cls * n_obj, 4, 32)
         self._nwg = int(_C.load().cnr_field_bwd_pipe_blocks(self.R, self.S, int(ops.FIELD_BWD_VARIANT[-1]), self.bwd_blocks)) \
-            if self.fused_tail else 0
+            if self.use_records else 0
         # split-weight forward (f16(W) + f16(W - f16(W)), two MFMAs per fragment): occupancy error 6.7e-4 -> 3.9e-4 at
         # configs[1] for +2.7 us per step; off by default, CNR_SPLIT_WEIGHTS=1 or split_weights=True turns it on
         self.split_weights = bool(int(os.environ.get("CNR_SPLIT_WEIGHTS", "0"))) if split_weights is None \
@@ -218,10 +222,15 @@ class FusedCategoryTrainer:
         # fused backward: dtrunk, dB, dbiasrows straight into the flat gradient buffer views
         ops.field_bwd(b["pts"], Bc, packed, brows, ray_row, self.scale, o["dsig"], o["drgb"], self.grad_scale,
                       g_trunk, g_B, self.dbias, C, R, S, n_obj, self.bwd_blocks, o["bwd_ws"],
-                      B_stride=P, dtrunk_stride=P, dB_stride=P, rows_fix=self.rows_fix, skip_reduce=self.fused_tail)
+                      B_stride=P, dtrunk_stride=P, dB_stride=P, rows_fix=self.rows_fix, skip_reduce=self.use_records)
         self._reg = 0.0005 * inv_w               # code regulariser scale: loss.py:5-15, train.py:165-167
         if self.pg is not None:                  # data parallel: the all-reduce needs the complete gradient first
-            _C.call("cnr_latent_bwd", self.theta, *lat_args, zl, self.dbias, self._reg, self.grad)
+            if self.use_records:                 # record reduction + latent backward in one launch, gradient only
+                _C.call("cnr_step_grad", self.theta, self.grad, lay.total, lay.B[0], lay.latW[0], lay.latb[0],
+                        lay.shape[0], lay.tex[0], L, n_obj, C, zl, self.dbias, self._reg, o["bwd_ws"], self._nwg,
+                        self.rows_fix)
+            else:
+                _C.call("cnr_latent_bwd", self.theta, *lat_args, zl, self.dbias, self._reg, self.grad)
 
     def _step_back(self):
         """Last launch (cnr_step_tail): the fixed-order reduction of the field backward's records (single GPU, <= 4
@@ -236,8 +245,8 @@ class FusedCategoryTrainer:
                 o["zl"], self.dbias, self._reg, 0 if self.pg is not None else 1, self.lr, 0.9, 0.999, 1e-8, self.wd,
                 self.d_state2[par], self.d_state2[1 - par], R, o["rl_ws"], self.losses, self.flags,
                 self.pool["depth"], self.pool_rows, self.perm, self.max_bound, R,
-                o["bwd_ws"] if self.fused_tail else None, self._nwg if self.fused_tail else 0, self.rows_fix,
-                self._rl_blocks)
+                o["bwd_ws"] if self.fused_tail else None, self._nwg if self.fused_tail else 0,
+                self.rows_fix if self.fused_tail else None, self._rl_blocks)
 
     def step(self):
         """One train step.  Returns nothing; ``self.losses`` (3,C) / ``self.flags`` (C,) hold the device-side

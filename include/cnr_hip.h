@@ -325,6 +325,15 @@ int cnr_step_tail(const float* theta_in, float* theta_out, float* grad, float* e
                   float* next_max_bound, int R, const void* records, int nwg, const long long* rows_fix,
                   int rl_blocks, void* stream);
 
+/* The gradient half of cnr_step_tail on its own (records reduction + latent backward + code regulariser in one launch,
+ * no optimiser, no epilogue): for hosts that need the finished gradient first, e.g. to all-reduce it across GPUs.
+ * Same arguments as the corresponding ones of cnr_step_tail; follow it (after the collective) with
+ * cnr_step_tail(..., do_latent = 0, ..., records = NULL, nwg = 0, rows_fix = NULL, ...). */
+int cnr_step_grad(const float* theta, float* grad, int64_t class_stride, int64_t off_B, int64_t off_latW,
+                  int64_t off_latb, int64_t off_shape, int64_t off_tex, int L, int n_obj, int C, const float* zl,
+                  float* dbiasrows, float reg_scale, const void* records, int nwg, const long long* rows_fix,
+                  void* stream);
+
 /* Same contract and results as cnr_field_bwd, ONE field kernel + the record reduction: each workgroup is
  * `chain_waves` waves that run forward recompute + data-gradient chain + PE backward for one 32-sample tile each,
  * plus the waves that own the weight-gradient accumulators and consume the chain waves' per-layer images behind a
