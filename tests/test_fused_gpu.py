@@ -294,7 +294,7 @@ def test_fused_backward_vs_fp32_reference(cnr, dev, name, bwd_variant):
 
 
 @pytest.mark.parametrize("C,R,S,L", [(1, 2048, 64, 256), (2, 333, 32, 32), (1, 500, 128, 256), (1, 64, 96, 32), (2, 128, 64, 32),
-                                     (3, 96, 96, 32)])
+                                     (3, 96, 96, 32), (9, 64, 32, 32)])
 def test_forward_render_one_launch_equals_two(cnr, dev, C, R, S, L):
     """cnr_field_fwd_render == cnr_field_fwd -> cnr_render_loss: same f16 forward, same composite expressions; lane
     sums run over 32-lane tiles instead of 64-lane chunks, hence agreement to fp32 summation order: 1e-6 on the
