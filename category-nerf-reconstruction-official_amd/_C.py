@@ -49,7 +49,8 @@ SIGNATURES = {
     "cnr_dense_bwd_workspace_bytes": [_i, _i, _i],
     "cnr_step_prologue": [_vp, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _i64,
                           _vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64, _vp, _i64, _vp, _i, _i, _i, _i, _f, _f, _f,
-                          _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+                          _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "cnr_slice_maxdepth": [_vp, _vp, _i64, _i, _i, _i, _vp, _vp],
     "cnr_adamw_epilogue": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64,
                            _vp, _vp, _i, _i, _vp],
     "cnr_step_tail": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _vp, _vp, _f, _i, _f, _f, _f,

@@ -669,7 +669,8 @@ extern "C" int cnr_step_prologue(
     const float* g, uint64_t seed, uint64_t offset, const int64_t* d_state, int64_t pool_rows, const float* max_bound,
     int world_frame, int R, int n1, int n2, float eps, float stop_eps, float min_bound, float* z, float* pts,
     float* origins, float* dirs_o, float* gt_rgb, float* gt_depth, uint8_t* depth_mask, uint8_t* labels,
-    const int64_t* pool_indices, int* ray_row, const int* perm, void* stream) {
+    const int64_t* pool_indices, int* ray_row, const int* perm, int max_bound_slices, void* stream) {
+  if (max_bound_slices < 0 || (max_bound_slices > 1 && (pool_rows <= 0 || !d_state))) return CNR_E_ARG;
   if (!theta || !packed || !zl || !biasrows || L <= 0 || n_obj <= 0 || C <= 0 || zero_count < 0 ||
       (zero_count > 0 && !zero_buf))
     return CNR_E_ARG;
@@ -688,7 +689,7 @@ extern "C" int cnr_step_prologue(
   const int nsample = (R + 3) / 4;
   cnr_sample::SampleArgs sa{rgbs, depth, dirs_c, T, u, g, seed, offset, d_state, pool_rows, max_bound, world_frame,
                             C, R, n1, n2, eps, stop_eps, min_bound, z, pts, origins, dirs_o, gt_rgb, gt_depth,
-                            depth_mask, labels, pool_indices, n_obj, ray_row, perm};
+                            depth_mask, labels, pool_indices, n_obj, ray_row, perm, max_bound_slices};
   dim3 grid(fz::NKK_FWD + fz::NKK_BWD + 1 + 4 * n_obj + nzero + nsample, (unsigned)C);
   hipLaunchKernelGGL(param_prep_kernel, grid, dim3(256), 0, (hipStream_t)stream, theta, lay, off_trunk,
                      (unsigned char*)packed, zl, biasrows, zero_buf, zero_count, nzero, sa, nsample);

@@ -27,6 +27,29 @@ __global__ void maxdepth_kernel(const float* __restrict__ depth, float* __restri
   }
 }
 
+// max depth of every slice of an epoch: block (s, c) -> out[c][s] = max_r depth[c][perm[c][s R + r]]
+__global__ __launch_bounds__(256) void slice_maxdepth_kernel(const float* __restrict__ depth, const int* __restrict__ perm,
+                                                             int64_t pool_rows, int R, float* __restrict__ out) {
+  const int s = blockIdx.x, c = blockIdx.y, nsl = gridDim.x;
+  const int64_t cbase = (int64_t)c * pool_rows, base = cbase + (int64_t)s * R;
+  float m = -INFINITY;
+  for (int r0 = 0; r0 < R; r0 += 8 * 256) {   // permutation entries together, then depths together
+    int64_t at[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int r = r0 + u * 256 + (int)threadIdx.x;
+      at[u] = r < R ? (perm ? cbase + perm[base + r] : base + r) : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) m = fmaxf(m, at[u] >= 0 ? depth[at[u]] : -INFINITY);
+  }
+  __shared__ float sm[4];
+  m = cnr::wave_max(m);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) out[(int64_t)c * nsl + s] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+}
+
 __global__ __launch_bounds__(256) void sample_kernel(cnr_sample::SampleArgs a) {
   const int lane = threadIdx.x & 63;
   const int64_t ray = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -56,6 +79,15 @@ extern "C" int cnr_sample_maxdepth(const float* depth, float* max_bound, const i
   return CNR_OK;
 }
 
+extern "C" int cnr_slice_maxdepth(const float* depth, const int* perm, int64_t pool_rows, int C, int R, int slices,
+                                  float* out, void* stream) {
+  if (!depth || !out || C <= 0 || R <= 0 || slices <= 0 || pool_rows < (int64_t)slices * R) return CNR_E_ARG;
+  hipLaunchKernelGGL(slice_maxdepth_kernel, dim3((unsigned)slices, (unsigned)C), dim3(256), 0, (hipStream_t)stream, depth,
+                     perm, pool_rows, R, out);
+  CNR_LAUNCH_CHECK();
+  return CNR_OK;
+}
+
 extern "C" int cnr_sample_rays(const uint8_t* rgbs, const float* depth, const float* dirs_c, const float* T,
                                const float* u, const float* g, uint64_t seed, uint64_t offset,
                                const int64_t* d_state, int64_t pool_rows,
@@ -76,7 +108,7 @@ extern "C" int cnr_sample_rays(const uint8_t* rgbs, const float* depth, const fl
   const int64_t blocks = (rays + waves_per_block - 1) / waves_per_block;
   cnr_sample::SampleArgs args{rgbs, depth, dirs_c, T, u, g, seed, offset, d_state, pool_rows, max_bound, world_frame,
                               C, R, n1, n2, eps, stop_eps, min_bound, z, pts, origins, dirs_o, gt_rgb, gt_depth,
-                              depth_mask, labels, pool_indices, n_obj, ray_row, perm};
+                              depth_mask, labels, pool_indices, n_obj, ray_row, perm, 0};
   hipLaunchKernelGGL(sample_kernel, dim3((unsigned)blocks), dim3(64 * waves_per_block), 0, (hipStream_t)stream, args);
   CNR_LAUNCH_CHECK();
   return CNR_OK;

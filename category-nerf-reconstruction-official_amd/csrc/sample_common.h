@@ -11,6 +11,9 @@ struct SampleArgs {
   int C, R, n1, n2; float eps, stop_eps, min_bound;
   float* z; float* pts; float* origins; float* dirs_o; float* gt_rgb; float* gt_depth; uint8_t* depth_mask;
   uint8_t* labels; const int64_t* pool_indices; int n_obj; int* ray_row; const int* perm;
+  // max_bound layout: mb_slices <= 1: one value per class (this step's slice); mb_slices > 1: a (C, mb_slices) table
+  // over the epoch's slices, indexed by device cursor / R (filled once per reshuffle by cnr_slice_maxdepth)
+  int mb_slices;
 };
 
 
@@ -154,7 +157,7 @@ __device__ __forceinline__ void sample_ray(const SampleArgs& a, int64_t ray, int
 
   // ---- a3/a5: per-column z -------------------------------------------------------------------
   float mb;
-  if (max_bound) mb = max_bound[c];
+  if (max_bound) mb = a.mb_slices > 1 ? max_bound[(int64_t)c * a.mb_slices + (int)(d_state[0] / R)] : max_bound[c];
   else {  // max depth of this step's slice of class c, by this wave (same value as cnr_sample_maxdepth: max is exact)
     float m = -INFINITY;
     const int64_t base = pool_rows > 0 ? (int64_t)c * pool_rows + d_state[0] : (int64_t)c * R;

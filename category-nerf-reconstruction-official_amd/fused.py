@@ -119,7 +119,10 @@ class FusedCategoryTrainer:
         # epoch shuffle as an index permutation (C, pool_rows): the pool itself never moves
         self.perm = torch.empty(n_cls, self.pool_rows, device=self.device, dtype=torch.int32)
         self._zero64 = torch.zeros(1, device=self.device, dtype=torch.int64)
-        self.max_bound = torch.zeros(n_cls, device=self.device)
+        # max depth of every slice of the epoch (scene_cateogries.py:486 needs the current slice's): one table per
+        # reshuffle, indexed on the device by cursor / R -- no step computes a maximum
+        self.n_slices = self.pool_rows // self.R
+        self.slice_max = torch.zeros(n_cls, self.n_slices, device=self.device)
         self.cursor = 0
         self.seed = int(seed) + 1
         self.grad_scale = float(grad_scale) if grad_scale else float(2 ** round(math.log2(max(self.R, 2))))
@@ -191,13 +194,12 @@ class FusedCategoryTrainer:
         # microseconds of overlap it buys at this step size, 0.154 -> 0.170 ms per step.)
         # First node, one launch, four independent jobs side by side in the grid: zero the gradient buffers | a7 +
         # latent layers (per-object bias rows) | f16 operand image of the trunk | a2-a6: slice the device pool at
-        # the device cursor, transform, sample (the slice's max depth is already in self.max_bound: the previous
-        # step's epilogue, or _reshuffle, put it there)
+        # the device cursor, transform, sample (the slice's max depth comes out of self.slice_max, which _reshuffle
+        # filled for the whole epoch)
         b = ops.step_prologue(self.theta, lay, L, n_obj, packed, zl, brows, self._gbuf, self.pool["rgbs"],
                               self.pool["depth"], self.pool["dirs"], self.pool["T"], self.n1, self.n2, cfg.surface_eps,
                               cfg.stop_eps, cfg.min_depth, self.seed, self.d_state2[self.parity], R, self.bufs,
-                              self.max_bound,
-                              self.pool["indices"], self.perm)
+                              self.slice_max, self.pool["indices"], self.perm, max_bound_slices=self.n_slices)
         ray_row = b["ray_row"]
         lo = None
         if self.split_weights:
@@ -244,7 +246,7 @@ class FusedCategoryTrainer:
                 lay.total, lay.B[0], lay.latW[0], lay.latb[0], lay.shape[0], lay.tex[0], self.L, self.n_obj, C,
                 o["zl"], self.dbias, self._reg, 0 if self.pg is not None else 1, self.lr, 0.9, 0.999, 1e-8, self.wd,
                 self.d_state2[par], self.d_state2[1 - par], R, o["rl_ws"], self.losses, self.flags,
-                self.pool["depth"], self.pool_rows, self.perm, self.max_bound, R,
+                None, self.pool_rows, None, None, R,
                 o["bwd_ws"] if self.fused_tail else None, self._nwg if self.fused_tail else 0,
                 self.rows_fix if self.fused_tail else None, self._rl_blocks)
 
@@ -316,9 +318,8 @@ class FusedCategoryTrainer:
             self.perm[c].copy_(torch.randperm(self.pool_rows, device=self.device))
         self.cursor = 0
         self.d_state2[self.parity, 0:1].copy_(self._zero64)
-        _C.call("cnr_sample_maxdepth", self.pool["depth"], self.max_bound, self.d_state2[self.parity], self.pool_rows,
-                self.perm,
-                self.C, self.R)
+        _C.call("cnr_slice_maxdepth", self.pool["depth"], self.perm, self.pool_rows, self.C, self.R, self.n_slices,
+                self.slice_max)
 
     # ---- reference-named export ------------------------------------------------------------------------
     def state_dicts(self, c=0):

@@ -270,9 +270,11 @@ def sample_rays(rgbs, depth, dirs_c, T, n1, n2, eps, stop_eps, min_bound=0.0, wo
 
 
 def step_prologue(theta, lay, L, n_obj, packed, zl, brows, zero_buf, rgbs, depth, dirs_c, T, n1, n2, eps, stop_eps,
-                  min_bound, seed, d_state, rays, out, max_bound, pool_indices, perm):
+                  min_bound, seed, d_state, rays, out, max_bound, pool_indices, perm, max_bound_slices=0):
     """cnr_step_prologue: the parameter-only jobs (pack | latent rows | gradient zero fill) and the sampler of one
-    fused-trainer step in ONE launch.  Same outputs dict as :func:`sample_rays` (device pools, device cursor)."""
+    fused-trainer step in ONE launch.  Same outputs dict as :func:`sample_rays` (device pools, device cursor).
+    max_bound: (C,) max depth of this step's slice, or with max_bound_slices = k > 1 a (C, k) table over the epoch's
+    slices (cnr_slice_maxdepth), indexed on the device by cursor / rays."""
     C, R, S = depth.shape[0], int(rays), n1 + n2
     dev = depth.device
     def buf(name, shape, dtype=torch.float32):
@@ -286,7 +288,8 @@ def step_prologue(theta, lay, L, n_obj, packed, zl, brows, zero_buf, rgbs, depth
     _C.call("cnr_step_prologue", theta, lay.total, lay.trunk[0], lay.latW[0], lay.latb[0], lay.shape[0], lay.tex[0],
             L, n_obj, C, packed, zl, brows, zero_buf, zero_buf.numel(),
             rgbs, depth, dirs_c, T, None, None, int(seed), 0, d_state, depth.shape[1], max_bound, 0, R, n1, n2,
-            float(eps), float(stop_eps), float(min_bound), z, pts, None, None, gt, gd, dm, lab, pool_indices, rr, perm)
+            float(eps), float(stop_eps), float(min_bound), z, pts, None, None, gt, gd, dm, lab, pool_indices, rr, perm,
+            int(max_bound_slices))
     return out
 
 

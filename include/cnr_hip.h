@@ -250,8 +250,15 @@ int cnr_field_fwd_render(const float* pts, const float* B, const void* packed, c
                          float* opacity, int C, int R, int S, int64_t B_stride, void* workspace,
                          int64_t workspace_bytes, const void* packed_lo, void* stream);
 
+/* Max depth of every slice of an epoch in one launch: out[c][s] = max over r < R of depth[c][perm[c][s R + r]]
+ * (perm NULL: identity), s < slices, slices * R <= pool_rows.  cnr_step_prologue takes such a table as max_bound when
+ * max_bound_slices = slices > 1 and indexes it with the device cursor / R -- the fused trainer fills it once per
+ * reshuffle instead of computing the next slice's maximum in every step's last launch. */
+int cnr_slice_maxdepth(const float* depth, const int* perm, int64_t pool_rows, int C, int R, int slices, float* out,
+                       void* stream);
+
 /* cnr_param_prep and cnr_sample_rays side by side in ONE launch (same arguments, in that order; max_bound must be
- * given here): the sampler needs the ray pool and the step state only, so the first node of the fused trainer's step
+ * given here, max_bound_slices = 0 or 1 for the per-class form): the sampler needs the ray pool and the step state only, so the first node of the fused trainer's step
  * runs it beside the parameter-only jobs instead of after them. */
 int cnr_step_prologue(const float* theta, int64_t class_stride, int64_t off_trunk, int64_t off_latW, int64_t off_latb,
                       int64_t off_shape, int64_t off_tex, int L, int n_obj, int C, void* packed, float* zl,
@@ -261,7 +268,7 @@ int cnr_step_prologue(const float* theta, int64_t class_stride, int64_t off_trun
                       const float* max_bound, int world_frame, int R, int n1, int n2, float eps, float stop_eps,
                       float min_bound, float* z, float* pts, float* origins, float* dirs_o, float* gt_rgb,
                       float* gt_depth, uint8_t* depth_mask, uint8_t* labels, const int64_t* pool_indices,
-                      int* ray_row, const int* perm, void* stream);
+                      int* ray_row, const int* perm, int max_bound_slices, void* stream);
 
 /* a11-a15 fused for the render + loss step of the fused trainer: cnr_composite_fwd -> cnr_loss_fwd_bwd ->
  * cnr_composite_bwd in ONE kernel (src/render_rays.py:3-7,25-33,46-95; src/loss.py:18-74).  Possible because the

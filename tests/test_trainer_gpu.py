@@ -188,6 +188,17 @@ def test_prologue_and_epilogue_launches_equal_their_parts(cnr, dev):
     assert torch.equal(pk[0], pk[1]) and torch.equal(zl[0], zl[1]) and torch.equal(br[0], br[1]) and torch.equal(zb[0], zb[1])
     for k in ("z", "pts", "gt_rgb", "gt_depth", "depth_mask", "labels", "ray_row"):
         assert torch.equal(a[k], b[k]), k
+    # ---- the epoch's slice maxima as a table (cnr_slice_maxdepth) instead of this slice's value: same samples
+    nsl = pool_rows // R
+    table = torch.empty(C, nsl, device=dev)
+    _C.call("cnr_slice_maxdepth", depth, perm, pool_rows, C, R, nsl, table)
+    ref = torch.stack([depth[c][perm[c].long()][: nsl * R].reshape(nsl, R).max(dim=1).values for c in range(C)])
+    assert torch.equal(table, ref) and torch.equal(table[:, 3], mb)
+    zb2, pk2 = torch.full((1000,), 5.0, device=dev), torch.empty_like(pk[0])
+    b2 = ops.step_prologue(theta, lay, L, n_obj, pk2, torch.empty_like(zl[0]), torch.empty_like(br[0]), zb2, rgbs, depth,
+                           dirs, T, n1, n2, 0.1, 0.05, 0.0, 9, state, R, {}, table, idx, perm, max_bound_slices=nsl)
+    for k in ("z", "pts", "gt_rgb", "gt_depth", "depth_mask", "labels", "ray_row"):
+        assert torch.equal(a[k], b2[k]), k
     # ---- epilogue
     n = theta.numel()
     grad = torch.randn(n, generator=gen).to(dev) * 1e-3
