@@ -393,3 +393,34 @@ def test_field_bwd_pipe_refuses_more_than_240_samples(cnr, dev):
         with pytest.raises(_C.CnrError):
             ops.field_bwd(z(C, R, S, 3), v["B"].contiguous(), packed, brows, ray_row, 2.0, z(C, R, S), z(C, R, S, 3), 1.0,
                           z(C, 13892), z(C, 21, 3), z(C * n_obj, 4, 32), C, R, S, n_obj, 0, wsp, variant=variant)
+
+
+@pytest.mark.parametrize("C,R,S", [(1, 2048, 64), (2, 4096, 128)])
+def test_field_bwd_is_linear_in_the_upstream_gradients(cnr, dev, C, R, S):
+    """BASELINE sizes, size-independent property: the backward is linear in (d sigma, d colour).  Doubling both changes
+    nothing but the exponents of the f16 dPre operands, except where those are subnormal (fixed spacing there): the
+    gradients double to 1e-4; a sum of two upstream gradients gives the sum of the gradients to the f16 rounding of
+    the dPre operands."""
+    ops, _C = cnr.ops, cnr._C
+    n_obj, L = 4, 256
+    gen = torch.Generator().manual_seed(17)
+    theta, lay = cnr.fused.init_params(C, L, n_obj, gen, dev)
+    v = lay.views(theta)
+    packed = ops.pack_weights(v["trunk"].contiguous())
+    B = v["B"].contiguous()
+    pts = torch.rand(C, R, S, 3, device=dev) * 2 - 1
+    brows = torch.randn(C * n_obj, 4, 32, device=dev) * 0.1
+    ray_row = (torch.randint(0, n_obj, (C, R), device=dev) + torch.arange(C, device=dev)[:, None] * n_obj).to(torch.int32)
+    wsp = torch.empty(_C.field_bwd_workspace_bytes(C, 0), device=dev, dtype=torch.uint8)
+
+    def run(dsig, drgb):
+        dtrunk = torch.zeros(C, 13892, device=dev); dB = torch.zeros(C, 21, 3, device=dev); dbr = torch.zeros_like(brows)
+        ops.field_bwd(pts, B, packed, brows, ray_row, 2.0, dsig, drgb, 1024.0, dtrunk, dB, dbr, C, R, S, n_obj, 0, wsp)
+        torch.cuda.synchronize()
+        return torch.cat([dtrunk.flatten(), dB.flatten(), dbr.flatten()])
+
+    a_s, a_c = torch.randn(C, R, S, device=dev) * 1e-3, torch.randn(C, R, S, 3, device=dev) * 1e-3
+    b_s, b_c = torch.randn(C, R, S, device=dev) * 1e-3, torch.randn(C, R, S, 3, device=dev) * 1e-3
+    ga, gb = run(a_s, a_c), run(b_s, b_c)
+    assert rel_l2(run(2 * a_s, 2 * a_c), 2 * ga) < 1e-4
+    assert rel_l2(run(a_s + b_s, a_c + b_c), ga + gb) < 2e-3

@@ -282,3 +282,46 @@ def test_process_group_path_matches_single_gpu_path(cnr, dev):
         assert cnr.parallel.params_in_sync(g[0], dist.group.WORLD)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("C,R,n1,n2", [(1, 2048, 8, 56), (2, 4096, 16, 112)])
+def test_full_size_step_sampling_invariants(cnr, dev, C, R, n1, n2):
+    """BASELINE sizes: the samples the fused step draws obey the reference's construction (scene_cateogries.py:453-546)
+    whatever the size -- stratified bins between min depth and surface - eps, sorted draws inside surface +- eps for
+    rays on the object, stratified bins up to surface + stop_eps for other rays, min .. slice max for rays without
+    depth -- and the step's losses are finite."""
+    torch.manual_seed(5)
+    cfg = cnr.cfg.synthetic_config(device=str(dev), latent_dim=256, n_bins_cam2surface=n1, n_bins=n2)
+    gen = torch.Generator().manual_seed(31)
+    pools = [cnr.scene_cateogries.synthetic_pool(4 * R, 4, gen, "cpu") for _ in range(C)]
+    tr = cnr.fused.FusedCategoryTrainer(cfg, C, 4, pools, R, dev, seed=2, generator=gen, use_graph=False)
+    rows = tr.perm[:, :R].long().cpu()
+    tr.step()
+    torch.cuda.synchronize()
+    z = tr.bufs["z"].cpu()
+    assert torch.isfinite(tr.losses).all() and torch.isfinite(z).all()
+    eps, stop, lo = cfg.surface_eps, cfg.stop_eps, cfg.min_depth
+    for c in range(C):
+        d = pools[c]["depth"][rows[c]]
+        state = pools[c]["rgbs"][rows[c]][:, 3]
+        valid, on_obj = d > lo, (pools[c]["rgbs"][rows[c]][:, 3] == 1) & (d > lo)
+        zc = z[c]
+        # camera -> surface bins
+        front = zc[valid][:, :n1]
+        assert bool((front >= lo - 1e-6).all()) and bool((front <= (d[valid] - eps)[:, None] + 1e-5).all())
+        assert bool((front[:, 1:] >= front[:, :-1]).all())
+        # around the surface, rays on the object: ascending, clipped to +- eps
+        near = zc[on_obj][:, n1:]
+        assert bool((near[:, 1:] >= near[:, :-1]).all())
+        assert bool(((near - d[on_obj][:, None]).abs() <= eps + 1e-5).all())
+        # other rays with depth: up to surface + stop_eps
+        other = valid & ~on_obj
+        if bool(other.any()):
+            back = zc[other][:, n1:]
+            assert bool((back >= (d[other] - eps)[:, None] - 1e-5).all()) and bool((back <= (d[other] + stop)[:, None] + 1e-5).all())
+        # rays without depth: min depth .. max depth of the slice
+        if bool((~valid).any()):
+            mb = float(d.max())
+            free = zc[~valid]
+            assert bool((free >= lo - 1e-6).all()) and bool((free <= mb + 1e-4).all())
+        assert state.max() <= 2
