@@ -421,6 +421,24 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
     // dW role: 8 accumulator blocks per wave, six tiles per step
     // ===================================================================================================
     const int m_row = col < 16 ? (col & 3) : 4, m_grp = col < 16 ? (col >> 2) : (col - 12);
+    // Where this lane's column of each owned block goes in the record: every block kind is affine in the output row,
+    // idx(o) = i0 + o * st (weights: st = the layer's row length; a bias column: st = 1), i0 < 0 = not a parameter.
+    // Computed here, while the chain waves recompute the first forward: the flush then stores accumulators straight to
+    // the record (no LDS image, no index table, no gather loop: 7 k -> 2.5 k cycles of every workgroup's tail).
+    int bi0[NACC], bst[NACC], r2i0 = -1, r2st = 0;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) { bi0[i] = -1; bst[i] = 0; }
+#define CNR_PIDX8(KIND)                                                                        \
+  if (owner8<NDW>(KIND) == dwid) {                                                             \
+    constexpr int li = local8<NDW>(KIND);                                                      \
+    bi0[li] = block_index(KIND, 0, col);                                                       \
+    bst[li] = block_index(KIND, 1, col) - bi0[li];                                             \
+  }
+    CNR_PIDX8(BK_R0) CNR_PIDX8(BK_T1) CNR_PIDX8(BK_VD_Y) CNR_PIDX8(BK_VD_E0) CNR_PIDX8(BK_VD_E1) CNR_PIDX8(BK_ES)
+    CNR_PIDX8(BK_S2) CNR_PIDX8(BK_CAT_Y) CNR_PIDX8(BK_CAT_E0) CNR_PIDX8(BK_CAT_E1) CNR_PIDX8(BK_CAT_E2) CNR_PIDX8(BK_S1)
+    CNR_PIDX8(BK_XYZ_E0) CNR_PIDX8(BK_XYZ_E1) CNR_PIDX8(BK_XYZ_E2)
+#undef CNR_PIDX8
+    if (owner8<NDW>(BK_R0) == dwid) { r2i0 = block_index(BK_R2, 0, col); r2st = block_index(BK_R2, 1, col) - r2i0; }
     for (int t0 = blockIdx.x * NCHW; t0 < ntiles; t0 += tile_step) {
       asm volatile("" ::: "memory");
       P8STAMP_RESET();
@@ -515,20 +533,53 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
       STEP8(3, BK_XYZ_E0, BK_XYZ_E1, BK_XYZ_E2, BK_XYZ_E2, -1)               // encoding_xyz
 #undef STEP8
     }
+    // ---- this wave's blocks -> the workgroup's record, straight from the accumulators -------------------------
+    float* rec = records + ((size_t)c * gridDim.x + blockIdx.x) * REC_FLOATS;
+#define CNR_PSTORE8(KIND, NROWS)                                                               \
+  if (owner8<NDW>(KIND) == dwid) {                                                             \
+    constexpr int li = local8<NDW>(KIND);                                                      \
+    if (bi0[li] >= 0) {                                                                        \
+      _Pragma("unroll") for (int reg = 0; reg < 16; ++reg) {                                   \
+        const int o = acc_row(reg, h);                                                         \
+        if (o < (NROWS)) rec[bi0[li] + o * bst[li]] = Wacc[li][reg] * inv_gs;                  \
+      }                                                                                        \
+    }                                                                                          \
+  }
+    CNR_PSTORE8(BK_R0, 16) CNR_PSTORE8(BK_T1, 32) CNR_PSTORE8(BK_VD_Y, 32) CNR_PSTORE8(BK_VD_E0, 32)
+    CNR_PSTORE8(BK_VD_E1, 32) CNR_PSTORE8(BK_ES, 32) CNR_PSTORE8(BK_S2, 32) CNR_PSTORE8(BK_CAT_Y, 32)
+    CNR_PSTORE8(BK_CAT_E0, 32) CNR_PSTORE8(BK_CAT_E1, 32) CNR_PSTORE8(BK_CAT_E2, 32) CNR_PSTORE8(BK_S1, 32)
+    CNR_PSTORE8(BK_XYZ_E0, 32) CNR_PSTORE8(BK_XYZ_E1, 32) CNR_PSTORE8(BK_XYZ_E2, 32)
+#undef CNR_PSTORE8
+    if (dwid == owner8<NDW>(BK_R0) && r2i0 >= 0) {  // rgb.2 out of rows 16..18 of rgb.0's block
+      constexpr int li = local8<NDW>(BK_R0);
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int o = acc_row(reg, h) - 16;
+        if (o >= 0 && o < 3) rec[r2i0 + o * r2st] = Wacc[li][reg] * inv_gs;
+      }
+    }
+    if (dwid == owner8<NDW>(BK_RS)) {  // the row-sum block: [m][feature], m = 4 * latent slot + object row | 16, 17: biases
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int m = acc_row(reg, h);
+        const float v = Wacc[LI_RS][reg] * inv_gs;
+        if (m == 16) rec[OFF_ES_B + col] = v;
+        else if (m == 17) { if (col < 16) rec[OFF_R0_B + col] = v; }
+        else if (m < 16 && (m & 3) < rows_per_class) {
+          const int i = (m & 3) * 128 + (m >> 2) * 32 + col;  // dbiasrows [row][latent slot][feature]
+          rec[TRUNK + 126 + i] = v;
+          if (rows_fix)
+            atomicAdd(reinterpret_cast<unsigned long long*>(
+                          rows_fix + ((size_t)(blockIdx.x % cnr_rec::ROWS_FIX_COPIES) * gridDim.y + c) * rows_per_class * 128 + i),
+                      (unsigned long long)__double2ll_rn((double)v * cnr_rec::ROWS_FIX_SCALE));
+        }
+      }
+    }
   }
 
   // ========================================= flush ====================================================
+  // (the dW waves have written their blocks above; what is left are the chain waves' partial sums)
   float* rec = records + ((size_t)c * gridDim.x + blockIdx.x) * REC_FLOATS;
-  // where each trunk parameter's gradient will sit in the LDS image of the blocks: all of a thread's table entries
-  // are requested here, together (a load per loop trip, each waiting for the previous trip's store, cost 12 k cycles
-  // = 10 % of the kernel at 2048 x 64); they arrive while the partial sums and the blocks go to LDS
-  constexpr int NSRC = (TRUNK + NTHR - 1) / NTHR;
-  int psrc[NSRC];
-#pragma unroll
-  for (int k = 0; k < NSRC; ++k) {
-    const int j = threadIdx.x + k * NTHR;
-    psrc[k] = j < TRUNK ? g_param_src[j] : -1;
-  }
   __syncthreads();
   P8PHASE(2);
   {
@@ -542,52 +593,7 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
     for (int i = threadIdx.x; i < 32; i += NTHR) rec[OFF_SG_W + i] = sum_chain(i) * inv_gs;
     if (threadIdx.x == 0) rec[OFF_SG_B] = sum_chain(32) * inv_gs;
   }
-  __syncthreads();  // everything above has been read: the accumulator image may alias it
-  P8PHASE(3);
-  if (!is_chain) {
-    float* region = reinterpret_cast<float*>(smem);
-#define CNR_PSTORE8(KIND)                                                                     \
-  if (owner8<NDW>(KIND) == dwid) {                                                                 \
-    constexpr int li = local8<NDW>(KIND);                                                          \
-    _Pragma("unroll") for (int reg = 0; reg < 16; ++reg)                                      \
-        region[(KIND) * 1024 + acc_row(reg, h) * 32 + col] = Wacc[li][reg];                   \
-  }
-    if (dwid == owner8<NDW>(BK_RS)) {  // the row-sum block
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) region[RS8_REGION * 1024 + acc_row(reg, h) * 32 + col] = Wacc[LI_RS][reg];
-    }
-    if (dwid == owner8<NDW>(BK_R0)) {  // rgb.2 out of rows 16..31 of rgb.0's block
-#pragma unroll
-      for (int reg = 8; reg < 16; ++reg)
-        region[BK_R2 * 1024 + (acc_row(reg, h) - 16) * 32 + col] = Wacc[local8<NDW>(BK_R0)][reg];
-    }
-    CNR_PSTORE8(BK_R0) CNR_PSTORE8(BK_T1) CNR_PSTORE8(BK_VD_Y) CNR_PSTORE8(BK_VD_E0)
-    CNR_PSTORE8(BK_VD_E1) CNR_PSTORE8(BK_ES) CNR_PSTORE8(BK_S2) CNR_PSTORE8(BK_CAT_Y) CNR_PSTORE8(BK_CAT_E0)
-    CNR_PSTORE8(BK_CAT_E1) CNR_PSTORE8(BK_CAT_E2) CNR_PSTORE8(BK_S1) CNR_PSTORE8(BK_XYZ_E0) CNR_PSTORE8(BK_XYZ_E1)
-    CNR_PSTORE8(BK_XYZ_E2)
-#undef CNR_PSTORE8
-  }
-  __syncthreads();
-  P8PHASE(4);
-  {
-    const float* region = reinterpret_cast<const float*>(smem);
-#pragma unroll
-    for (int k = 0; k < NSRC; ++k) {  // coalesced record stores, LDS gather (indices fetched before the flush began)
-      const int j = threadIdx.x + k * NTHR;
-      if (psrc[k] >= 0) rec[j] = region[psrc[k]] * inv_gs;
-    }
-    const float* rs = region + RS8_REGION * 1024;  // [m][feature]
-    for (int i = threadIdx.x; i < 32; i += NTHR) rec[OFF_ES_B + i] = rs[16 * 32 + i] * inv_gs;
-    for (int i = threadIdx.x; i < 16; i += NTHR) rec[OFF_R0_B + i] = rs[17 * 32 + i] * inv_gs;
-    for (int i = threadIdx.x; i < rows_per_class * 128; i += NTHR) {  // dbiasrows [row][latent slot][feature]
-      const float v = rs[(((i >> 5) & 3) * 4 + (i >> 7)) * 32 + (i & 31)] * inv_gs;
-      rec[TRUNK + 126 + i] = v;
-      if (rows_fix)
-        atomicAdd(reinterpret_cast<unsigned long long*>(
-                      rows_fix + ((size_t)(blockIdx.x % cnr_rec::ROWS_FIX_COPIES) * gridDim.y + c) * rows_per_class * 128 + i),
-                  (unsigned long long)__double2ll_rn((double)v * cnr_rec::ROWS_FIX_SCALE));
-    }
-  }
+  P8PHASE(3); P8PHASE(4);
   P8PHASE(5);
 }
 }  // namespace
@@ -602,8 +608,6 @@ extern "C" int cnr_field_bwd_pipe8_launch(const float* pts, const float* B, cons
     hipError_t er = hipFuncSetAttribute((const void*)field_bwd_pipe8_kernel<4, 4>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, l8_total(4));
     if (er != hipSuccess) return (int)er;
-    hipLaunchKernelGGL(build_param_src_kernel, dim3(16), dim3(256), 0, (hipStream_t)stream);
-    hipLaunchKernelGGL(fill_param_src_kernel, dim3(16), dim3(256), 0, (hipStream_t)stream);
     attr_set = true;
   }
   const int64_t N = (int64_t)R * S;
