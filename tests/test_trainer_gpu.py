@@ -325,3 +325,24 @@ def test_full_size_step_sampling_invariants(cnr, dev, C, R, n1, n2):
             free = zc[~valid]
             assert bool((free >= lo - 1e-6).all()) and bool((free <= mb + 1e-4).all())
         assert state.max() <= 2
+
+
+def test_many_epochs_graph_equals_eager(cnr, dev):
+    """Sixty steps over a pool of eight slices (a reshuffle every seven steps: new permutation, new per-slice max-depth
+    table, cursor back to zero) -- the captured graphs must keep following the device-side state across epochs: same
+    losses and parameters, bitwise, as the eager trainer."""
+    res = {}
+    for name, graph in (("eager", False), ("graph", True)):
+        torch.manual_seed(77)          # epoch permutations come from the default generator
+        cfg = cnr.cfg.synthetic_config(device=str(dev), latent_dim=64, n_bins_cam2surface=4, n_bins=28)
+        gen = torch.Generator().manual_seed(3)
+        pools = [cnr.scene_cateogries.synthetic_pool(8 * 128, 4, gen, "cpu") for _ in range(2)]
+        tr = cnr.fused.FusedCategoryTrainer(cfg, 2, 4, pools, 128, dev, seed=1, generator=gen, use_graph=graph)
+        hist = []
+        for _ in range(60):
+            tr.step()
+            hist.append(tr.losses.clone())
+        torch.cuda.synchronize()
+        res[name] = (torch.stack(hist), tr.theta.clone())
+    assert torch.isfinite(res["graph"][0]).all()
+    assert torch.equal(res["graph"][0], res["eager"][0]) and torch.equal(res["graph"][1], res["eager"][1])
