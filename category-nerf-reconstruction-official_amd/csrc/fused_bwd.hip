@@ -575,7 +575,10 @@ extern "C" int cnr_field_bwd(const float* pts, const float* B, const void* packe
 #undef CNR_LAUNCH_BWD
   CNR_LAUNCH_CHECK();
   hipLaunchKernelGGL(reduce_records_kernel, dim3(REC_FLOATS / 64, (unsigned)C), dim3(256), 0, (hipStream_t)stream,
-                     (const float*)workspace, (int)blocks, dtrunk, dB, dbiasrows, rows_per_class,
+                     (const float*)workspace, (int)blocks, dtrunk, dB, dbiasrows,
+                     // rows travel in the records only when these kernels keep them in LDS (<= ROWS_LDS per class);
+                     // otherwise they went to dbiasrows by atomics and the records hold none
+                     (rows_per_class >= 1 && rows_per_class <= ROWS_LDS) ? rows_per_class : 0,
                      dtrunk_stride > 0 ? dtrunk_stride : (int64_t)TRUNK, dB_stride > 0 ? dB_stride : (int64_t)63);
   CNR_LAUNCH_CHECK();
   return CNR_OK;

@@ -35,7 +35,7 @@ __device__ long long g_pipe8_stamps[8 * 48];
 #endif
 #define P8SYNC() do { P8STAMP(); role_barrier(); P8STAMP(); } while (0)
 constexpr int C8_BYTES = E1IMG_BYTES + E2IMG_BYTES + 2 * HSIMG_BYTES + 512;  // LDS per chain wave
-constexpr int L8_BL = PK_BYTES, L8_BR = L8_BL + 272, L8_CHAIN = L8_BR + ROWS_LDS * 128 * 4;
+constexpr int L8_BL = PK_BYTES, L8_BR = L8_BL + 272, L8_CHAIN = L8_BR + cnr_rec::ROWS_MAX * 128 * 4;
 constexpr int RS8_REGION = NBLOCKS;
 constexpr int BK_RS = 100;  // pseudo kind of the row-sum block in the ownership tables
 __host__ __device__ constexpr int l8_total(int nch) {
@@ -61,7 +61,9 @@ template <> __host__ __device__ constexpr int local8<4>(int kind) {
        : kind == BK_S1 ? 0 : kind == BK_CAT_E1 ? 1 : 2 /* BK_CAT_E2 */;
 }
 
-template <int NCH, int NDW>
+// WIDE: more than four object rows per class (up to ROWS_MAX): the row stride of the row-sum block is then a run-time
+// value; with <= 4 rows it is the constant 4 and the index arithmetic folds (1 us of the kernel at 2048 x 64).
+template <int NCH, int NDW, bool WIDE>
 __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
     const float* __restrict__ pts, const float* __restrict__ Bdir, const unsigned char* __restrict__ packed,
     const float* __restrict__ biasrows, const int* __restrict__ ray_row, float inv_scale,
@@ -90,7 +92,7 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
       const int hh = i / 33, k = i % 33, d = k / 3;
       Bl[i] = (hh == 1 && d == 10) ? 0.0f : Bdir[(size_t)c * B_stride + (11 * hh + d) * 3 + (k % 3)];
     }
-    float* br = reinterpret_cast<float*>(smem + L8_BR);  // host guarantees 1 <= rows_per_class <= ROWS_LDS
+    float* br = reinterpret_cast<float*>(smem + L8_BR);  // host guarantees 1 <= rows_per_class <= ROWS_MAX
     for (int i = threadIdx.x; i < rows_per_class * 128; i += NTHR) br[i] = biasrows[(size_t)c * rows_per_class * 128 + i];
   }
   __syncthreads();
@@ -127,7 +129,8 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
     unsigned char* E2img = cw + K_E2;
     unsigned char* Dimg = cw + K_D;
     unsigned char* Ximg = cw + K_X;
-    _Float16* rowoh = reinterpret_cast<_Float16*>(cw + K_SMALL);  // [5][32]: (object row of sample k == r), row 4 ones
+    // [rows_per_class + 1][32] (<= 8 rows): (object row of sample k == r), last row ones
+    _Float16* rowoh = reinterpret_cast<_Float16*>(cw + K_SMALL);
     const float* Bl_h = reinterpret_cast<const float*>(smem + L8_BL) + 33 * h;
 
     // one lane's inputs of a tile; past the end: a dead tile (all-zero gradients, any valid row)
@@ -210,9 +213,11 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
       acc = acc_init(cf + CF_B_XYZ, h);
       {
         const int rl = row - c * rows_per_class;
-        rowoh[(2 * h + 0) * 32 + col] = rl == 2 * h + 0 ? (_Float16)1 : (_Float16)0;
-        rowoh[(2 * h + 1) * 32 + col] = rl == 2 * h + 1 ? (_Float16)1 : (_Float16)0;
-        if (h == 0) rowoh[4 * 32 + col] = (_Float16)1;
+        const int rs = WIDE ? rows_per_class : 4;  // rows per latent slot in the row-sum block; the ones row follows
+#pragma unroll
+        for (int r = 0; r < (WIDE ? cnr_rec::ROWS_MAX : 4); r += 2)  // lane half h writes rows h, h + 2, ...
+          if (!WIDE || r + h < rs) rowoh[(r + h) * 32 + col] = rl == r + h ? (_Float16)1 : (_Float16)0;
+        if (h == 0) rowoh[rs * 32 + col] = (_Float16)1;
       }
       {
         unsigned char* b1 = E1img + col * ST_E1 + h * 96;
@@ -420,7 +425,14 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
     // ===================================================================================================
     // dW role: 8 accumulator blocks per wave, six tiles per step
     // ===================================================================================================
-    const int m_row = col < 16 ? (col & 3) : 4, m_grp = col < 16 ? (col >> 2) : (col - 12);
+    // row m of the row-sum block: m = rs * latent slot + object row for the four latent layers, then one
+    // "ones" row each for the two plain biases (encoding_shape: group 4, rgb.0: group 5)
+    const int rs = WIDE ? rows_per_class : 4;  // rows per latent slot (a constant unless WIDE)
+    const int nlat_rows = 4 * rs;
+    const int rpc_inv = (65536 + rs - 1) / rs;  // m / rs = (m * rpc_inv) >> 16 for m < 32
+    const int col_slot = (col * rpc_inv) >> 16;
+    const int m_row = col < nlat_rows ? col - col_slot * rs : rs,
+              m_grp = col < nlat_rows ? col_slot : 4 + (col - nlat_rows);
     // Where this lane's column of each owned block goes in the record: every block kind is affine in the output row,
     // idx(o) = i0 + o * st (weights: st = the layer's row length; a bias column: st = 1), i0 < 0 = not a parameter.
     // Computed here, while the chain waves recompute the first forward: the flush then stores accumulators straight to
@@ -558,15 +570,16 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
         if (o >= 0 && o < 3) rec[r2i0 + o * r2st] = Wacc[li][reg] * inv_gs;
       }
     }
-    if (dwid == owner8<NDW>(BK_RS)) {  // the row-sum block: [m][feature], m = 4 * latent slot + object row | 16, 17: biases
+    if (dwid == owner8<NDW>(BK_RS)) {  // the row-sum block: [m][feature], m = rows_per_class * latent slot + object row | then the two biases
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int m = acc_row(reg, h);
         const float v = Wacc[LI_RS][reg] * inv_gs;
-        if (m == 16) rec[OFF_ES_B + col] = v;
-        else if (m == 17) { if (col < 16) rec[OFF_R0_B + col] = v; }
-        else if (m < 16 && (m & 3) < rows_per_class) {
-          const int i = (m & 3) * 128 + (m >> 2) * 32 + col;  // dbiasrows [row][latent slot][feature]
+        if (m == nlat_rows) rec[OFF_ES_B + col] = v;
+        else if (m == nlat_rows + 1) { if (col < 16) rec[OFF_R0_B + col] = v; }
+        else if (m < nlat_rows && m - ((m * rpc_inv) >> 16) * rs < rows_per_class) {
+          const int slot = (m * rpc_inv) >> 16;
+          const int i = (m - slot * rs) * 128 + slot * 32 + col;  // dbiasrows [row][latent slot][feature]
           rec[TRUNK + 126 + i] = v;
           if (rows_fix)
             atomicAdd(reinterpret_cast<unsigned long long*>(
@@ -605,16 +618,22 @@ extern "C" int cnr_field_bwd_pipe8_launch(const float* pts, const float* B, cons
                                           void* workspace, int64_t B_stride, long long* rows_fix, void* stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t er = hipFuncSetAttribute((const void*)field_bwd_pipe8_kernel<4, 4>,
+    hipError_t er = hipFuncSetAttribute((const void*)field_bwd_pipe8_kernel<4, 4, false>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, l8_total(4));
+    if (er != hipSuccess) return (int)er;
+    er = hipFuncSetAttribute((const void*)field_bwd_pipe8_kernel<4, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                             l8_total(4));
     if (er != hipSuccess) return (int)er;
     attr_set = true;
   }
   const int64_t N = (int64_t)R * S;
-hipLaunchKernelGGL((field_bwd_pipe8_kernel<4, 4>), dim3((unsigned)blocks, (unsigned)C), dim3(512), l8_total(4),
-                     (hipStream_t)stream, pts, B, (const unsigned char*)packed, biasrows, ray_row, 1.0f / scale, d_sigma,
-                     d_rgb, grad_scale, (float*)workspace, (int)N, S, R, rows_per_class,
-                     B_stride > 0 ? B_stride : (int64_t)63, rows_fix);
+#define CNR_LAUNCH_P8(WIDE)                                                                                        \
+  hipLaunchKernelGGL((field_bwd_pipe8_kernel<4, 4, WIDE>), dim3((unsigned)blocks, (unsigned)C), dim3(512),           \
+                     l8_total(4), (hipStream_t)stream, pts, B, (const unsigned char*)packed, biasrows, ray_row,      \
+                     1.0f / scale, d_sigma, d_rgb, grad_scale, (float*)workspace, (int)N, S, R, rows_per_class,       \
+                     B_stride > 0 ? B_stride : (int64_t)63, rows_fix)
+  if (rows_per_class > 4) CNR_LAUNCH_P8(true); else CNR_LAUNCH_P8(false);
+#undef CNR_LAUNCH_P8
   CNR_LAUNCH_CHECK();
   return CNR_OK;
 }

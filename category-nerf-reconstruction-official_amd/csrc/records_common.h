@@ -5,8 +5,11 @@
 
 namespace cnr_rec {
 using namespace cnr;
-constexpr int ROWS_LDS = 4;  // rows_per_class <= 4: per-object bias-row sums travel in the record / the fixed-point table
-constexpr int REC_FLOATS = ((TRUNK + 126 + ROWS_LDS * 128 + 255) / 256) * 256;  // one workgroup's record
+constexpr int ROWS_LDS = 4;  // rows_per_class <= 4: what the 4-wave and block-split kernels keep in their LDS row tables
+// rows_per_class <= 7: per-object bias-row sums travel in the record / the fixed-point table (the 8-wave kernel's
+// row-sum block has 32 rows = 4 latent slots x 7 objects + 2 bias rows)
+constexpr int ROWS_MAX = 7;
+constexpr int REC_FLOATS = ((TRUNK + 126 + ROWS_MAX * 128 + 255) / 256) * 256;  // one workgroup's record
 constexpr double ROWS_FIX_SCALE = 1099511627776.0;  // 2^40: bias-row sums as int64 fixed point (order-free atomics)
 constexpr int ROWS_FIX_COPIES = 8;  // the table is replicated: a workgroup adds into copy (its index & 7), which
                                     // cuts the same-address atomic queue 8-fold; consumers add the copies (exact)
@@ -18,7 +21,7 @@ __device__ __forceinline__ bool rec_entry_written(int i, int rows_per_class) {
     return !((i >= OFF_S1_B && i < OFF_S1_B + 32) || (i >= OFF_CAT_B && i < OFF_CAT_B + 32) ||
              (i >= OFF_S2_B && i < OFF_S2_B + 32) || (i >= OFF_T1_B && i < OFF_T1_B + 32));
   if (i < TRUNK + 126) return true;
-  return rows_per_class <= ROWS_LDS && (i - (TRUNK + 126)) < rows_per_class * 128;
+  return rows_per_class <= ROWS_MAX && (i - (TRUNK + 126)) < rows_per_class * 128;
 }
 // sum of entry i over records [w0, w1) of one class (r = that class's first record + i).  32 loads in flight per
 // thread: the reducing kernels run a few waves per CU, so the loads in flight per thread are what hides the memory

@@ -251,7 +251,7 @@ extern "C" int cnr_step_tail(const float* theta_in, float* theta_out, float* gra
       !losses || !flags || R <= 0)
     return CNR_E_ARG;
   if (do_latent && (!zl || !dbiasrows)) return CNR_E_ARG;
-  if (records && (!do_latent || !rows_fix || nwg <= 0 || n_obj > cnr_rec::ROWS_LDS)) return CNR_E_ARG;
+  if (records && (!do_latent || !rows_fix || nwg <= 0 || n_obj > cnr_rec::ROWS_MAX)) return CNR_E_ARG;
   if (rows_fix && !do_latent) return CNR_E_ARG;
   if (n_obj > 64) return CNR_E_SHAPE;
   if (next_max_bound && (!depth || pool_rows < R)) return CNR_E_ARG;
@@ -292,7 +292,7 @@ extern "C" int cnr_step_grad(const float* theta, float* grad, int64_t class_stri
   if (!theta || !grad || class_stride <= 0 || L <= 0 || n_obj <= 0 || C <= 0 || !zl || !dbiasrows || !records ||
       nwg <= 0 || !rows_fix)
     return CNR_E_ARG;
-  if (n_obj > cnr_rec::ROWS_LDS) return CNR_E_SHAPE;
+  if (n_obj > cnr_rec::ROWS_MAX) return CNR_E_SHAPE;
   TailArgs a{};
   a.theta_in = theta; a.grad = grad;
   a.lay = FlatLayout{class_stride, off_latW, off_latb, off_shape, off_tex, L, n_obj};

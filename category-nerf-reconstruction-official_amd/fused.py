@@ -98,7 +98,7 @@ class FusedCategoryTrainer:
         # the field backward leaves per-workgroup records + the fixed-point table; ONE later launch reduces them next to
         # the latent backward: with AdamW and the epilogue on a single GPU (cnr_step_tail), gradient only with a process
         # group (cnr_step_grad: the all-reduce comes between gradient and optimiser)
-        self.use_records = n_obj <= 4 and ops.FIELD_BWD_VARIANT.startswith("pipe")
+        self.use_records = n_obj <= (7 if ops.FIELD_BWD_VARIANT == "pipe4" else 4) and ops.FIELD_BWD_VARIANT.startswith("pipe")
         self.fused_tail = process_group is None and self.use_records
         fix_off = (n_th + n_db + 3) // 4 * 4                      # 16-byte aligned
         self._gbuf = torch.zeros(fix_off + (2 * 8 * n_db if self.use_records else 0), device=self.device)  # 8 copies

@@ -340,14 +340,15 @@ def test_forward_render_one_launch_equals_two(cnr, dev, C, R, S, L):
                 ds1, dc1, d1, v1, r1, o1, C, R, 48, 0, ws1, ws1.numel(), None)
 
 
-@pytest.mark.parametrize("C,R,S", [(1, 2048, 64), (2, 1000, 96), (1, 8192, 128), (1, 77, 240), (2, 50, 33), (1, 1, 1)])
-def test_field_bwd_full_size_all_variants_agree_and_repeat(cnr, dev, C, R, S):
+@pytest.mark.parametrize("C,R,S,n_obj", [(1, 2048, 64, 4), (2, 1000, 96, 4), (1, 8192, 128, 4), (1, 77, 240, 4), (2, 50, 33, 4),
+                                         (1, 1, 1, 4), (2, 700, 64, 7), (1, 2048, 64, 5), (1, 300, 32, 1)])
+def test_field_bwd_full_size_all_variants_agree_and_repeat(cnr, dev, C, R, S, n_obj):
     """BASELINE sizes: every cnr_field_bwd implementation computes the same f16 pipeline, so the gradients agree to
     fp32 summation order (1e-5 relative L2 per output against the block-split kernels), and a repeated call returns
     the same bits (records + fixed-order reduction).  The repeat is the check that caught a register hazard which the
     small fixtures never showed: hundreds of workgroups with several iterations each are needed to hit it."""
     ops, _C = cnr.ops, cnr._C
-    n_obj, L = 4, 256
+    L = 256
     gen = torch.Generator().manual_seed(3)
     theta, lay = cnr.fused.init_params(C, L, n_obj, gen, dev)
     v = lay.views(theta)
@@ -372,6 +373,8 @@ def test_field_bwd_full_size_all_variants_agree_and_repeat(cnr, dev, C, R, S):
         first = run(variant)
         for name, a, b in zip(("dtrunk", "dB", "dbiasrows"), first, ref):
             assert rel_l2(a, b) < 1e-5, (variant, name, rel_l2(a, b))
+        if n_obj > 4 and variant != "pipe4":
+            continue  # more than four rows per class: these delegate to the block-split kernels (rows by float atomics)
         for rep in range(3):
             again = run(variant)
             for name, a, b in zip(("dtrunk", "dB", "dbiasrows"), again, first):

@@ -327,8 +327,9 @@ def test_full_size_step_sampling_invariants(cnr, dev, C, R, n1, n2):
         assert state.max() <= 2
 
 
-def test_many_epochs_graph_equals_eager(cnr, dev):
-    """Sixty steps over a pool of eight slices (a reshuffle every seven steps: new permutation, new per-slice max-depth
+@pytest.mark.parametrize("n_obj", [4, 6])
+def test_many_epochs_graph_equals_eager(cnr, dev, n_obj):
+    """(Four objects per class, and six: up to seven stay on the record path of the 8-wave backward.)  Sixty steps over a pool of eight slices (a reshuffle every seven steps: new permutation, new per-slice max-depth
     table, cursor back to zero) -- the captured graphs must keep following the device-side state across epochs: same
     losses and parameters, bitwise, as the eager trainer."""
     res = {}
@@ -336,8 +337,9 @@ def test_many_epochs_graph_equals_eager(cnr, dev):
         torch.manual_seed(77)          # epoch permutations come from the default generator
         cfg = cnr.cfg.synthetic_config(device=str(dev), latent_dim=64, n_bins_cam2surface=4, n_bins=28)
         gen = torch.Generator().manual_seed(3)
-        pools = [cnr.scene_cateogries.synthetic_pool(8 * 128, 4, gen, "cpu") for _ in range(2)]
-        tr = cnr.fused.FusedCategoryTrainer(cfg, 2, 4, pools, 128, dev, seed=1, generator=gen, use_graph=graph)
+        pools = [cnr.scene_cateogries.synthetic_pool(8 * 128, n_obj, gen, "cpu") for _ in range(2)]
+        tr = cnr.fused.FusedCategoryTrainer(cfg, 2, n_obj, pools, 128, dev, seed=1, generator=gen, use_graph=graph)
+        assert tr.fused_tail
         hist = []
         for _ in range(60):
             tr.step()
