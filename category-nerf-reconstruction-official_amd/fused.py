@@ -92,7 +92,7 @@ class FusedCategoryTrainer:
         self.theta2 = torch.stack([theta0, theta0.clone()])
         self.parity = 0
         # gradient of the flat parameters and of the per-object bias rows in ONE allocation: one fill per step
-        # ... plus (single GPU, <= 4 objects per class) the int64 fixed-point table of the per-object bias-row sums
+        # ... plus (<= 7 objects per class with the 8-wave backward, <= 4 otherwise) the int64 fixed-point table of the per-object bias-row sums
         # that the field backward fills with integer atomics for cnr_step_tail
         n_th, n_db = self.theta.numel(), n_cls * n_obj * 128
         # the field backward leaves per-workgroup records + the fixed-point table; ONE later launch reduces them next to
@@ -235,7 +235,7 @@ class FusedCategoryTrainer:
                 _C.call("cnr_latent_bwd", self.theta, *lat_args, zl, self.dbias, self._reg, self.grad)
 
     def _step_back(self):
-        """Last launch (cnr_step_tail): the fixed-order reduction of the field backward's records (single GPU, <= 4
+        """Last launch (cnr_step_tail): the fixed-order reduction of the field backward's records (single GPU, <= 7
         objects per class; otherwise cnr_field_bwd_pipe did it), latent backward + code regulariser (single GPU; with a
         process group it ran before the all-reduce), AdamW out of place into the other parameter copy, and the
         epilogue (loss values +
