@@ -32,7 +32,7 @@ for name in sorted(set(fetch) | set(write)):
         call += hbm
 out["cnr_field_bwd_pipe_call_hbm_bytes"] = call
 out["cnr_field_bwd_algorithmic_bytes"] = R * S * 28
-out["note"] = ("backward call = field kernel + reduce_records; the per-workgroup records (one 58 KB record per workgroup, "
+out["note"] = ("backward call = field kernel + reduce_records; the per-workgroup records (one 59 KB record per workgroup, "
                "written once, read once) dominate; the 28 B/sample of algorithmic input are the rest")
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))
