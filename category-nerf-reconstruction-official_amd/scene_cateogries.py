@@ -15,6 +15,7 @@ import numpy as np
 import torch
 
 from . import ops, trainer
+from .utils import get_tensor_from_transform_sim3
 
 
 # ---- free functions (reference signatures) -------------------------------------------------------
@@ -68,11 +69,11 @@ class cameraInfo:
         self.rays_dir_cache = self.get_rays_dirs()
 
     def get_rays_dirs(self, depth_type="z"):
-        if depth_type != "z":
-            raise Exception("Get camera rays directions with euclidean depth not yet implemented")
         dirs = torch.ones((self.width, self.height, 3))
         dirs[:, :, 0] = ((torch.arange(end=self.width) - self.cx) / self.fx)[:, None]
         dirs[:, :, 1] = ((torch.arange(end=self.height) - self.cy) / self.fy)
+        if depth_type == "euclidean":   # the reference raises here as well (:623-626)
+            raise Exception("Get camera rays directions with euclidean depth not yet implemented")
         return dirs
 
 
@@ -149,12 +150,16 @@ class sceneCategory():
         crops, T_crop, areas = [], [], []
         if cls_id != 0:
             self.extent_dict, self.object_tensor_dict = {}, {}
+            self._T_obj = {}                 # the 4x4 itself, for the pool poses below (not part of the checkpoint)
         for inst_id in obj_ids:
             info = infos[inst_id]
             if cls_id != 0:
                 self.extent_dict[inst_id] = info["bbox3D"].extent if "bbox3D" in info else np.array([2.0, 2.0, 2.0])
                 T_obj = torch.from_numpy(np.asarray(info["T_obj"]).astype(np.float32)).to(dev)
-                self.object_tensor_dict[inst_id] = T_obj      # the 4x4 sim3 itself (the reference keeps scale+quat+t)
+                self._T_obj[inst_id] = T_obj
+                # [scale, qw, qx, qy, qz, t]: what the reference keeps and checkpoints (:179-181), read back as
+                # obj_tensor[0] = scale, obj_tensor[1:] = rigid transform (train.py:231-234)
+                self.object_tensor_dict[inst_id] = get_tensor_from_transform_sim3(np.copy(info["T_obj"])).to(dev)
             index = 0 if len(obj_ids) == 1 else obj_ids.index(inst_id)
             sl = [slot[fi["frame"]] for fi in info["frame_info"]]
             t_wc = T_wc[sl]                                                        # (n_frames_of_inst, 4, 4)
@@ -276,51 +281,82 @@ class sceneCategory():
         return (rgbs[:, :3], depth, out["depth_mask"][0].bool(), out["labels"][0], out["pts"][0],
                 out["z"][0], batch_indices)
 
-    # ---- checkpoint interchange (src/scene_cateogries.py:548-597): same file name, same dict keys -------------
+    # ---- checkpoint interchange (src/scene_cateogries.py:548-597) ------------------------------------------------------
+    # File name and key schema of the reference:
+    #   global_step int | cls_id int | obj_scale float | instance_id_to_index {inst_id: row}
+    #   PE_state_dict {scale, B_layer.weight} | FC_state_dict {<layer>.weight / .bias}
+    #   background (cls_id 0):  bound = trainer.bound (the scene's bbox3D object)
+    #   object category:        obj_tensor_dict {inst_id: (8,) sim3 vector}, extent_dict {inst_id: (3,)} (only with > 1
+    #                           object), shape_code_state_dict / texture_code_state_dict {weight}, bound = trainer.extent_dict
+    CKPT_KEYS_BG = ("global_step", "PE_state_dict", "FC_state_dict", "cls_id", "instance_id_to_index", "obj_scale", "bound")
+    CKPT_KEYS_OBJ = CKPT_KEYS_BG + ("obj_tensor_dict", "shape_code_state_dict", "texture_code_state_dict")
+
+    def checkpoint_dict(self, iter):
+        t = self.trainer
+        d = {"global_step": iter, "PE_state_dict": t.pe.state_dict(), "FC_state_dict": t.fc_occ_map.state_dict(),
+             "cls_id": self.cls_id, "instance_id_to_index": t.inst_id_to_index, "obj_scale": t.obj_scale}
+        if self.cls_id == 0:
+            d["bound"] = getattr(t, "bound", None)
+            return d
+        d["obj_tensor_dict"] = getattr(self, "object_tensor_dict", {})
+        if len(self.obj_ids) > 1:
+            d["extent_dict"] = getattr(self, "extent_dict", None)
+        d["shape_code_state_dict"] = t.shape_codes.state_dict()
+        d["texture_code_state_dict"] = t.texture_codes.state_dict()
+        d["bound"] = t.extent_dict
+        return d
+
     def save_checkpoints(self, path, iter):
         import os
         ckpt_file = os.path.join(path, "cls_" + str(self.cls_id) + "_iteration_{:05d}.pth".format(iter))
-        save_dict = {
-            "global_step": iter,
-            "PE_state_dict": self.trainer.pe.state_dict(),
-            "FC_state_dict": self.trainer.fc_occ_map.state_dict(),
-            "cls_id": self.cls_id,
-            "instance_id_to_index": self.trainer.inst_id_to_index,
-            "obj_scale": self.trainer.obj_scale,
-        }
-        if self.cls_id == 0:
-            save_dict["bound"] = getattr(self.trainer, "bound", None)
-        else:
-            save_dict["obj_tensor_dict"] = getattr(self, "object_tensor_dict", {})
-            if len(self.obj_ids) > 1:
-                save_dict["extent_dict"] = getattr(self, "extent_dict", None)
-            save_dict["shape_code_state_dict"] = self.trainer.shape_codes.state_dict()
-            save_dict["texture_code_state_dict"] = self.trainer.texture_codes.state_dict()
-            save_dict["bound"] = self.trainer.extent_dict
-        torch.save(save_dict, ckpt_file)
+        torch.save(self.checkpoint_dict(iter), ckpt_file)
         return ckpt_file
 
-    def load_checkpoints(self, ckpt_file):
+    def load_checkpoints(self, ckpt_file, allow_pickle=False):
+        """Restore from a checkpoint in the reference's format (written by either code base).  The file is read with
+        ``weights_only=True`` (tensors, containers, numbers, numpy arrays): nothing in it is executed.  A reference
+        checkpoint of the BACKGROUND carries an open3d bounding box under ``bound``; pass ``allow_pickle=True`` to
+        unpickle such a file -- only for files you trust.  A missing file prints a note and returns, as the reference
+        does.  The reference assigns ``bound`` / ``extent_dict`` to the opposite trainer attribute of the one its saver
+        read them from (:585-593); here each goes back where it came from, so save -> load -> save is the identity."""
         import os
         if not os.path.exists(ckpt_file):
             print("ckpt not exist ", ckpt_file)
             return
-        checkpoint = torch.load(ckpt_file, map_location=self.training_device, weights_only=False)
-        self.cls_id = checkpoint["cls_id"]
-        self.trainer.fc_occ_map.load_state_dict(checkpoint["FC_state_dict"])
-        self.trainer.pe.load_state_dict(checkpoint["PE_state_dict"])
-        self.trainer.fc_occ_map.to(self.training_device)
-        self.trainer.pe.to(self.training_device)
-        if self.cls_id != 0:
-            self.object_tensor_dict = checkpoint["obj_tensor_dict"]
-            self.trainer.shape_codes.load_state_dict(checkpoint["shape_code_state_dict"])
-            self.trainer.texture_codes.load_state_dict(checkpoint["texture_code_state_dict"])
-            self.trainer.shape_codes.to(self.training_device)
-            self.trainer.texture_codes.to(self.training_device)
-            self.trainer.bound = checkpoint["bound"]
+        if allow_pickle:
+            ck = torch.load(ckpt_file, map_location=self.training_device, weights_only=False)
         else:
-            self.trainer.extent_dict = checkpoint["bound"]
-        self.trainer.inst_id_to_index = checkpoint["instance_id_to_index"]
-        self.trainer.obj_scale = checkpoint["obj_scale"]
-        self.start = checkpoint["global_step"]
-
+            try:
+                import numpy._core.multiarray as _ma
+            except ImportError:                                       # numpy < 2
+                import numpy.core.multiarray as _ma
+            with torch.serialization.safe_globals([_ma._reconstruct, np.ndarray, np.dtype, type(np.dtype(np.float64)),
+                                                   type(np.dtype(np.float32)), type(np.dtype(np.int64))]):
+                ck = torch.load(ckpt_file, map_location=self.training_device, weights_only=True)
+        want = self.CKPT_KEYS_BG if ck["cls_id"] == 0 else self.CKPT_KEYS_OBJ
+        missing = [k for k in want if k not in ck]
+        if missing:
+            raise KeyError(f"{ckpt_file}: not a category checkpoint, missing {missing}")
+        t, dev = self.trainer, self.training_device
+        self.cls_id = ck["cls_id"]
+        t.fc_occ_map.load_state_dict(ck["FC_state_dict"])
+        t.pe.load_state_dict(ck["PE_state_dict"])
+        t.fc_occ_map.to(dev)
+        t.pe.to(dev)
+        # ("bound" lands on both attributes: trainer.bound is where the reference's loader puts an object category's
+        #  value, trainer.extent_dict where its saver read it from -- and the other way round for the background)
+        t.bound = ck["bound"]
+        if self.cls_id == 0:
+            t.extent_dict = ck["bound"]
+        else:
+            self.object_tensor_dict = ck["obj_tensor_dict"]
+            if "extent_dict" in ck:
+                self.extent_dict = ck["extent_dict"]
+            t.shape_codes.load_state_dict(ck["shape_code_state_dict"])
+            t.texture_codes.load_state_dict(ck["texture_code_state_dict"])
+            t.shape_codes.to(dev)
+            t.texture_codes.to(dev)
+            t.extent_dict = ck["bound"]
+        t.inst_id_to_index = ck["instance_id_to_index"]
+        t.obj_scale = ck["obj_scale"]
+        self.start = ck["global_step"]

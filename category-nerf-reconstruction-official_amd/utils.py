@@ -29,3 +29,38 @@ def update_vmap(models, optimiser):
     [p.requires_grad_() for p in params]
     optimiser.add_param_group({"params": params})
     return (fmodel, params, buffers)
+
+
+# ---- sim3 <-> 8-vector [scale, qw, qx, qy, qz, tx, ty, tz] ------------------------------------------------------------
+# The form the reference keeps per object in ``sceneCategory.object_tensor_dict`` and writes into checkpoints
+# (src/utils.py:367-447 get_tensor_from_transform_sim3 / get_transform_from_tensor_sim3; consumers read element 0 as the
+# scale and elements 1: as quaternion + translation, train.py:231-234, src/scene_cateogries.py:378-379).
+def get_tensor_from_transform_sim3(RT):
+    """(4,4) sim3 (numpy or tensor) -> float32 tensor (8,).  scale = det(R s)^(1/3); the quaternion comes from scipy's
+    Rotation (w first), the same third-party routine the reference calls, so the numbers are identical."""
+    import numpy as np
+    from scipy.spatial.transform import Rotation
+    M = np.array(RT.detach().cpu().numpy() if torch.is_tensor(RT) else RT, dtype=np.float64)
+    scale = np.linalg.det(M[:3, :3]) ** (1.0 / 3.0)
+    scale32 = torch.tensor([scale], dtype=torch.float32)
+    Rm = M[:3, :3] / scale32.numpy()                      # the reference divides by the float32 scale tensor
+    x, y, z, w = Rotation.from_matrix(Rm).as_quat()
+    vec = np.concatenate([[w, x, y, z], M[:3, 3]])
+    return torch.cat([scale32, torch.from_numpy(vec).float()], 0)
+
+
+def get_transform_from_tensor_sim3(vec):
+    """(8,) or (n,8) [scale, qw, qx, qy, qz, t] -> (4,4) / (n,4,4) sim3 matrices (differentiable torch ops)."""
+    single = vec.dim() == 1
+    v = vec[None] if single else vec
+    s, q, t = v[:, 0], v[:, 1:5], v[:, 5:8]
+    qr, qi, qj, qk = q.unbind(-1)
+    two_s = 2.0 / (q * q).sum(-1)
+    R = torch.stack([1 - two_s * (qj * qj + qk * qk), two_s * (qi * qj - qk * qr), two_s * (qi * qk + qj * qr),
+                     two_s * (qi * qj + qk * qr), 1 - two_s * (qi * qi + qk * qk), two_s * (qj * qk - qi * qr),
+                     two_s * (qi * qk - qj * qr), two_s * (qj * qk + qi * qr), 1 - two_s * (qi * qi + qj * qj)],
+                    -1).view(-1, 3, 3)
+    T = torch.eye(4, device=v.device, dtype=v.dtype).repeat(v.shape[0], 1, 1)
+    T[:, :3, :3] = R * s[:, None, None]
+    T[:, :3, 3] = t
+    return T[0] if single else T

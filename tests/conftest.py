@@ -22,7 +22,7 @@ def _all_golden():
 
 def golden_names():
     """object-branch fixtures (CodeNeRF train step)"""
-    return [n for n in _all_golden() if not n.startswith("bg_") and not n.startswith("pool_")]
+    return [n for n in _all_golden() if not n.startswith(("bg_", "pool_", "ckpt_", "cam_"))]
 
 
 def pool_golden_names():

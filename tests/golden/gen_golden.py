@@ -398,7 +398,95 @@ def run_pool_case(name, seed, W=24, H=20, n_frames=6):
           f"-> {os.path.getsize(path) / 1e6:.2f} MB")
 
 
+def run_ckpt_case(name, seed, W=16, H=12, n_frames=4):
+    """Checkpoint interchange: the reference's own sceneCategory.save_checkpoints (src/scene_cateogries.py:
+    548-571) on reference-built categories -- one with three instances, one with a single instance, the background --
+    read back with torch.load and stored as plain arrays: every state_dict entry, the per-object sim3 vectors the
+    reference derives from T_obj (get_tensor_from_transform_sim3), extents, id -> row map, scalars; plus what
+    Trainer.eval_points (src/trainer.py:125-151) returns for those weights on a fixed set of points."""
+    import copy as _copy
+    import tempfile
+    rng = np.random.RandomState(seed)
+    gen = torch.Generator().manual_seed(4000 + seed)
+    cfg = SimpleNamespace(data_device="cpu", training_device="cpu", bg_scale=5.0, obj_scale=2.0,
+                          hidden_feature_size=32, hidden_feature_size_bg=32, n_bins_cam2surface=1,
+                          n_bins_cam2surface_bg=5, n_bins=9, min_depth=0.0, max_depth=10.0, surface_eps=0.1,
+                          stop_eps=0.05, n_unidir_funcs=5,
+                          net_hyperparams=dict(shape_blocks=2, texture_blocks=1, W=32, latent_dim=32))
+    sample_dict = {}
+    for f in range(n_frames):
+        sample_dict[f] = dict(image=rng.randint(0, 256, size=(W, H, 3)).astype(np.uint8),
+                              depth=(rng.rand(W, H) * 4).astype(np.float32),
+                              T=rand_pose(gen, False).numpy().astype(np.float32),
+                              obj_mask=rng.choice([-1, 0, 3, 7, 12, 20], size=(W, H)).astype(np.int64))
+    rays_dir = torch.randn(W, H, 3, generator=gen)
+
+    def inst(extent):
+        return dict(T_obj=rand_pose(gen, True).numpy().astype(np.float64), bbox3D=SimpleNamespace(extent=np.array(extent)),
+                    frame_info=[dict(frame=f, bbox=[1, 6, 2, 7]) for f in range(2)])
+    multi = {3: inst([1.0, 2.0, 1.5]), 7: inst([0.5, 0.6, 0.7]), 12: inst([2.0, 1.0, 1.0])}
+    single = {20: inst([1.2, 1.1, 1.0])}
+    bg_dict = dict(bbox3D=np.array([6.0, 6.0, 3.0]), frame_info=[dict(frame=f, bbox=[0, W, 0, H]) for f in range(2)])
+    torch.manual_seed(seed)
+    cats = dict(multi=ref_sc.sceneCategory(cfg, 5, _copy.deepcopy(multi), sample_dict, rays_dir),
+                single=ref_sc.sceneCategory(cfg, 6, _copy.deepcopy(single), sample_dict, rays_dir),
+                bg=ref_sc.sceneCategory(cfg, 0, _copy.deepcopy(bg_dict), sample_dict, rays_dir))
+    cats["multi"].trainer.extent_dict = cats["multi"].extent_dict        # what train.py's category set-up leaves there
+    cats["single"].trainer.extent_dict = cats["single"].extent_dict
+    pts = (torch.rand(300, 3, generator=gen) * 2 - 1)
+    f = lambda t: t.detach().cpu().numpy()
+    d = dict(meta=np.array([W, H, n_frames, seed], dtype=np.int64), points=f(pts), rays_dir=f(rays_dir),
+             frames_image=np.stack([sample_dict[k]["image"] for k in range(n_frames)]),
+             frames_depth=np.stack([sample_dict[k]["depth"] for k in range(n_frames)]),
+             frames_mask=np.stack([sample_dict[k]["obj_mask"] for k in range(n_frames)]),
+             frames_T=np.stack([sample_dict[k]["T"] for k in range(n_frames)]))
+    with tempfile.TemporaryDirectory() as tmp:
+        for tag, sc in cats.items():
+            sc.save_checkpoints(tmp, 123)
+            ck = torch.load(os.path.join(tmp, "cls_%d_iteration_00123.pth" % sc.cls_id), weights_only=False)
+            d[tag + ".keys"] = np.array(sorted(ck.keys()))
+            d[tag + ".scalars"] = np.array([ck["global_step"], ck["cls_id"], ck["obj_scale"]], dtype=np.float64)
+            ids = sorted(ck["instance_id_to_index"].keys())
+            d[tag + ".inst_ids"] = np.array(ids, dtype=np.int64)
+            d[tag + ".inst_rows"] = np.array([ck["instance_id_to_index"][i] for i in ids], dtype=np.int64)
+            for sd in ("PE_state_dict", "FC_state_dict", "shape_code_state_dict", "texture_code_state_dict"):
+                if sd in ck:
+                    d[tag + "." + sd + ".keys"] = np.array(list(ck[sd].keys()))
+                    for k, v in ck[sd].items():
+                        d[tag + "." + sd + "." + k] = f(v)
+            if tag == "bg":
+                d[tag + ".bound"] = np.asarray(ck["bound"], dtype=np.float64)
+                occ, col = sc.trainer.eval_points(pts)
+            else:
+                src = multi if tag == "multi" else single
+                d[tag + ".T_obj"] = np.stack([src[i]["T_obj"] for i in ids])
+                d[tag + ".obj_tensor"] = np.stack([f(ck["obj_tensor_dict"][i]) for i in ids])
+                d[tag + ".bound"] = np.stack([np.asarray(ck["bound"][i], dtype=np.float64) for i in ids])
+                if "extent_dict" in ck:
+                    d[tag + ".extent"] = np.stack([np.asarray(ck["extent_dict"][i], dtype=np.float64) for i in ids])
+                occ, col = sc.trainer.eval_points(pts, inst_id=ids[-1])
+            d[tag + ".eval_occ"], d[tag + ".eval_color"] = f(occ), f(col)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **d)
+    print(f"{name}: {len(d)} arrays -> {os.path.getsize(path) / 1e6:.2f} MB")
+
+
+def run_camera_case(name):
+    """a1: cameraInfo.get_rays_dirs (src/scene_cateogries.py:600-629) for two small cameras; the oracle must equal it."""
+    d = {}
+    for i, cam in enumerate((dict(W=9, H=6, fx=4.0, fy=3.5, cx=4.25, cy=2.5), dict(W=31, H=17, fx=577.87, fy=577.87, cx=15.5, cy=8.0))):
+        ref = ref_sc.cameraInfo(SimpleNamespace(**cam)).rays_dir_cache
+        mine = O.get_rays_dirs(cam["W"], cam["H"], cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+        assert torch.equal(ref, mine), "oracle get_rays_dirs != reference"
+        d["cam%d" % i] = np.array([cam[k] for k in ("W", "H", "fx", "fy", "cx", "cy")], dtype=np.float64)
+        d["dirs%d" % i] = ref.numpy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
+    print(f"{name}: ok")
+
+
 def main():
+    run_camera_case("cam_rays")
+    run_ckpt_case("ckpt_ref", 9)
     run_case("s0_c1_r64_s16_l256", 0, 1, 64, 16, 256)
     run_case("s1_c1_r64_s16_l256", 1, 1, 64, 16, 256, keep_emb=False)
     run_case("s2_c1_r64_s16_l256", 2, 1, 64, 16, 256, keep_emb=False)
@@ -416,6 +504,9 @@ def main():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "pool":
         run_pool_case("pool_w24_h20_f6", 8)
+    elif len(sys.argv) > 1 and sys.argv[1] == "ckpt":    # only the checkpoint + camera fixtures
+        run_camera_case("cam_rays")
+        run_ckpt_case("ckpt_ref", 9)
     elif len(sys.argv) > 1 and sys.argv[1] == "bg":      # only the background fixtures
         run_bg_case("bg_r240_s14_h128", 6, 240)
         run_bg_case("bg_r100_s14_h32", 7, 100, hidden=32)

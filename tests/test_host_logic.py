@@ -117,3 +117,32 @@ def test_checkpoint_round_trip_in_the_reference_format(cnr, tmp_path):
         assert b.start == 42 and b.trainer.inst_id_to_index == a.trainer.inst_id_to_index
         if cls_id != 0:
             assert torch.equal(a.trainer.shape_codes.weight, b.trainer.shape_codes.weight)
+
+
+def test_camera_rays_dirs_match_the_oracle(cnr):
+    """a1, cameraInfo.get_rays_dirs (src/scene_cateogries.py:613-629): [(u - cx) / fx, (v - cy) / fy, 1] indexed [w, h],
+    not normalised -- against the oracle's restatement, for the Replica intrinsics and a cropped ScanNet-like camera."""
+    from oracle import ref_cpu as O
+    from types import SimpleNamespace
+    for cam in (dict(W=1200, H=680, fx=600.0, fy=600.0, cx=599.5, cy=339.5),
+                dict(W=620, H=460, fx=577.87, fy=577.87, cx=309.5, cy=229.5), dict(W=7, H=5, fx=3.0, fy=2.0, cx=1.25, cy=4.0)):
+        info = cnr.scene_cateogries.cameraInfo(SimpleNamespace(**cam))
+        want = O.get_rays_dirs(cam["W"], cam["H"], cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+        assert info.rays_dir_cache.shape == (cam["W"], cam["H"], 3)
+        assert torch.equal(info.rays_dir_cache, want)
+        assert torch.equal(info.rays_dir_cache[..., 2], torch.ones(cam["W"], cam["H"]))
+        with pytest.raises(Exception):
+            info.get_rays_dirs(depth_type="euclidean")
+
+
+def test_camera_rays_dirs_match_the_reference_fixture(cnr):
+    """... and against what the reference's own cameraInfo produced (tests/golden/cam_rays.npz)."""
+    import os
+    import numpy as np
+    from types import SimpleNamespace
+    from conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "cam_rays.npz"))
+    for i in range(2):
+        W, H, fx, fy, cx, cy = z["cam%d" % i]
+        info = cnr.scene_cateogries.cameraInfo(SimpleNamespace(W=int(W), H=int(H), fx=fx, fy=fy, cx=cx, cy=cy))
+        assert np.array_equal(info.rays_dir_cache.numpy(), z["dirs%d" % i])
