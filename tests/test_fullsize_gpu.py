@@ -4,11 +4,12 @@ checks of the latent backward / record reduction / fixed-point row sums that the
 Bars (also in DESIGN.md section 3.3):
   * losses of the step: 2e-3 of the oracle's (f16 forward);
   * every gradient tensor against autograd of a torch restatement of the SAME f16 pipeline (same ReLU masks up to fp32
-    summation order): 2e-2 per tensor, 5e-3 on the whole trunk -- this is the bar that proves the kernel computes the
-    gradient of what it evaluates, at full size;
-  * every gradient tensor against the oracle's fp32 autograd: 0.15 relative L2 / cosine 0.995 per tensor group -- the
-    distance between an f16 and an fp32 forward (flipped ReLU units), not a kernel error: the convergence test
-    (tests/test_convergence_gpu.py) shows it is harmless to training;
+    summation order): 1e-2 per tensor, 1e-3 on the whole trunk (measured at configs[1]: 4.4e-3 worst tensor, 1e-4
+    trunk) -- this is the bar that proves the kernel computes the gradient of what it evaluates, at full size;
+  * every gradient tensor against the oracle's fp32 autograd: 0.06 relative L2 per tensor, cosine of the whole
+    gradient > 0.9995 (measured at configs[1]: 0.032 worst tensor, cosine 0.99992) -- the distance between an f16 and
+    an fp32 forward (flipped ReLU units), not a kernel error: the convergence test (tests/test_convergence_gpu.py) shows
+    it is harmless to training;
   * AdamW: exp_avg = 0.1 g and exp_avg_sq = 0.001 g^2 of the kernel's own gradient to 1e-6, the parameter update
     against the oracle's AdamW where the gradient is not rounding noise.
 """
@@ -112,12 +113,12 @@ def test_full_size_train_step_against_oracle(cnr, dev, C, R, n1, n2, L):
         e = rel_l2(got[k], ref[k])
         report.append(f"{k}={e:.3f}")
         worst = max(worst, e)
-        assert e < 0.15, (k, e)
+        assert e < 0.06, (k, e)
         a_, b_ = got[k].double().reshape(-1), ref[k].double().reshape(-1)
         dot += float(a_ @ b_); na += float(a_ @ a_); nb += float(b_ @ b_)
     cos = dot / (na * nb) ** 0.5
     print(f"full-size step C{C} R{R} S{n1 + n2} L{L} vs fp32 oracle: cos={cos:.5f} worst={worst:.3f}  " + " ".join(report))
-    assert cos > 0.995
+    assert cos > 0.9995
 
     # ---- the same f16 pipeline restated in torch (device): the kernel must return ITS gradient ------------------------
     g = _Batch(cnr, tr, theta0, bd, idx, dev)
@@ -135,16 +136,16 @@ def test_full_size_train_step_against_oracle(cnr, dev, C, R, n1, n2, L):
             continue
         e = rel_l2(got[k], emu[k])
         rep2.append(f"{k}={e:.4f}")
-        assert e < 2e-2, (k, e)
+        assert e < 1e-2, (k, e)
         if k in trunk_names:
             num += float((got[k] - emu[k]).double().pow(2).sum()); den += float(emu[k].double().pow(2).sum())
     print(f"   vs emulated f16 pipeline: trunk={(num / den) ** 0.5:.4f}  " + " ".join(rep2))
-    assert (num / den) ** 0.5 < 5e-3
+    assert (num / den) ** 0.5 < 1e-3
 
     # ---- AdamW (step 1): moments of the kernel's own gradient, update against the oracle's optimiser ------------------
     g_flat = tr.grad.cpu()
     assert rel_l2(tr.exp_avg.cpu(), 0.1 * g_flat) < 1e-6
-    assert rel_l2(tr.exp_avg_sq.cpu(), 0.001 * g_flat * g_flat) < 1e-5
+    assert rel_l2(tr.exp_avg_sq.cpu(), 0.001 * g_flat * g_flat) < 1e-4    # (1 - beta2 is not exactly 1e-3 in fp32)
     params = list(mlp.values()) + [B] + sh + tx
     opt = torch.optim.AdamW(params, lr=cfg.learning_rate, weight_decay=cfg.weight_decay)
     opt.step()
