@@ -40,7 +40,7 @@ SIGNATURES = {
     "cnr_pack_weights_lo": [_vp, _vp, _i, _vp],
     "cnr_field_bwd": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i64, _i64, _i64,
                       _i64, _vp],
-    "cnr_field_bwd_pipe": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i64, _i64, _i64, _i64, _vp, _i, _vp],
+    "cnr_field_bwd_pipe": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i64, _i64, _i64, _i64, _vp, _i, _vp, _vp],
     "cnr_field_bwd_workspace_bytes": [_i, _i],
     "cnr_field_bwd_pipe_blocks": [_i, _i, _i, _i],
     "cnr_gather_pool": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -49,21 +49,22 @@ SIGNATURES = {
     "cnr_dense_bwd_workspace_bytes": [_i, _i, _i],
     "cnr_step_prologue": [_vp, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _i64,
                           _vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64, _vp, _i64, _vp, _i, _i, _i, _i, _f, _f, _f,
-                          _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+                          _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "cnr_slice_maskcounts": [_vp, _vp, _vp, _i64, _i, _i, _i, _f, _vp, _vp],
     "cnr_slice_maxdepth": [_vp, _vp, _i64, _i, _i, _i, _vp, _vp],
     "cnr_adamw_epilogue": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64,
                            _vp, _vp, _i, _i, _vp],
     "cnr_step_tail": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _vp, _vp, _f, _i, _f, _f, _f,
-                      _f, _f, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i, _vp, _i, _vp, _i, _vp],
+                      _f, _f, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp],
     "cnr_step_grad": [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _vp, _vp, _f, _vp, _i, _vp, _vp],
     "cnr_field_fwd_render_blocks": [_i, _i],
     "cnr_field_fwd_render_workspace_bytes": [_i, _i, _i],
     "cnr_field_fwd_render": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp,
-                             _vp, _i, _i, _i, _i64, _vp, _i64, _vp, _vp],
+                             _vp, _i, _i, _i, _i64, _vp, _i64, _vp, _vp, _vp, _vp],
     "cnr_param_prep": [_vp, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp],
     "cnr_render_loss_workspace_bytes": [_i, _i],
     "cnr_render_loss": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp,
-                        _i64, _vp],
+                        _i64, _vp, _vp, _vp],
     "cnr_render_loss_finish": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "cnr_step_epilogue": [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i, _i, _vp],
 }
@@ -132,6 +133,12 @@ def call(name, *args):
             conv.append(_ptr(a))
         else:
             conv.append(a)
+    # trailing arguments a caller leaves out are the optional ones the C-ABI grew over time: NULL / 0
+    types = SIGNATURES[name][:-1]
+    if len(conv) > len(types):
+        raise CnrError(f"{name}: {len(conv)} arguments for {len(types)} parameters")
+    for t in types[len(conv):]:
+        conv.append(None if t is _vp else 0)
     rc = getattr(lib, name)(*conv, _stream())
     if rc != 0:
         raise CnrError(f"{name} failed with code {rc}" + (" (argument error)" if rc < 0 else " (hipError_t)"))

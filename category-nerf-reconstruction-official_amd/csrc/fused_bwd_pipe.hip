@@ -608,7 +608,8 @@ extern "C" int cnr_pipe_read_stamps(long long* host) {
 extern "C" int cnr_field_bwd_pipe8_launch(const float* pts, const float* B, const void* packed, const float* biasrows,
                                           const int* ray_row, float scale, const float* d_sigma, const float* d_rgb,
                                           float grad_scale, int C, int R, int S, int rows_per_class, int blocks,
-                                          void* workspace, int64_t B_stride, long long* rows_fix, void* stream);
+                                          void* workspace, int64_t B_stride, long long* rows_fix, int* clamp_flags,
+                                          void* stream);
 
 static bool pipe_waves_ok(int chain_waves) { return chain_waves == 2 || chain_waves == 3 || chain_waves == 4; }
 
@@ -625,7 +626,7 @@ extern "C" int cnr_field_bwd_pipe(const float* pts, const float* B, const void* 
                                   float grad_scale, float* dtrunk, float* dB, float* dbiasrows, int C, int R, int S,
                                   int rows_per_class, int max_blocks, int chain_waves, void* workspace,
                                   int64_t workspace_bytes, int64_t B_stride, int64_t dtrunk_stride, int64_t dB_stride,
-                                  long long* rows_fix, int skip_reduce, void* stream) {
+                                  long long* rows_fix, int skip_reduce, int* clamp_flags, void* stream) {
   if (!pts || !B || !packed || !biasrows || !d_sigma || !d_rgb || !dtrunk || !dB || !dbiasrows || !workspace)
     return CNR_E_ARG;
   if (C <= 0 || R <= 0 || S <= 0 || !(scale > 0.f) || !(grad_scale > 0.f)) return CNR_E_ARG;
@@ -653,7 +654,8 @@ extern "C" int cnr_field_bwd_pipe(const float* pts, const float* B, const void* 
   if (workspace_bytes < need) return CNR_E_ARG;
   if (chain_waves == 4) {  // the 8-wave kernel
     const int rc = cnr_field_bwd_pipe8_launch(pts, B, packed, biasrows, ray_row, scale, d_sigma, d_rgb, grad_scale, C, R, S,
-                                              rows_per_class, (int)blocks, workspace, B_stride, rows_fix, stream);
+                                              rows_per_class, (int)blocks, workspace, B_stride, rows_fix, clamp_flags,
+                                              stream);
     if (rc != CNR_OK) return rc;
     if (skip_reduce) return CNR_OK;
     hipLaunchKernelGGL(reduce_records_kernel, dim3(REC_FLOATS / 64, (unsigned)C), dim3(256), 0, (hipStream_t)stream,

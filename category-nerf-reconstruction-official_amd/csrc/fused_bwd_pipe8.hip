@@ -68,7 +68,8 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
     const float* __restrict__ pts, const float* __restrict__ Bdir, const unsigned char* __restrict__ packed,
     const float* __restrict__ biasrows, const int* __restrict__ ray_row, float inv_scale,
     const float* __restrict__ d_sigma, const float* __restrict__ d_rgb, float gscale, float* __restrict__ records,
-    int N, int S, int R, int rows_per_class, int64_t B_stride, long long* __restrict__ rows_fix) {
+    int N, int S, int R, int rows_per_class, int64_t B_stride, long long* __restrict__ rows_fix,
+    int* __restrict__ clamp_flags) {
   constexpr int NCHW = NCH, NTHR = (NCH + NDW) * 64, NACC = 5, LI_RS = local8<NDW>(BK_RS);
   // per chain wave: E1 image, E2 image, dPre / input slot, row one-hot table (the flush reuses it for the wave's
   // partial sums)
@@ -165,7 +166,11 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
       // ---- this lane's sample (fetched during the previous iteration's shape_layer_2 step) -------------------
       const float t0x = cur.px * inv_scale, t1x = cur.py * inv_scale, t2x = cur.pz * inv_scale;
       const int row = cur.row;
-      const float draw = fminf(fmaxf(cur.dsg * gscale, -8192.0f), 8192.0f) * 10.0f;  // sigmas = raw * 10 (src/model.py:75)
+      const float dsg_s = cur.dsg * gscale;
+      // the f16 data-gradient chain needs |d sigma| * gscale <= 8192; a hit (a ray whose termination is one sample: var -> 0,
+      // info -> 1e4) is clipped and REPORTED: bit 4 of the step's flags (cnr_step_tail or-s this word in and clears it)
+      if (clamp_flags && fabsf(dsg_s) > 8192.0f) atomicOr(clamp_flags + c, 16);
+      const float draw = fminf(fmaxf(dsg_s, -8192.0f), 8192.0f) * 10.0f;  // sigmas = raw * 10 (src/model.py:75)
       const float dr0 = cur.dr0 * gscale, dr1 = cur.dr1 * gscale, dr2 = cur.dr2 * gscale;
       const float* brow_l = reinterpret_cast<const float*>(smem + L8_BR) + (row - c * rows_per_class) * 128;
 
@@ -618,7 +623,8 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
 extern "C" int cnr_field_bwd_pipe8_launch(const float* pts, const float* B, const void* packed, const float* biasrows,
                                           const int* ray_row, float scale, const float* d_sigma, const float* d_rgb,
                                           float grad_scale, int C, int R, int S, int rows_per_class, int blocks,
-                                          void* workspace, int64_t B_stride, long long* rows_fix, void* stream) {
+                                          void* workspace, int64_t B_stride, long long* rows_fix, int* clamp_flags,
+                                          void* stream) {
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t er = hipFuncSetAttribute((const void*)field_bwd_pipe8_kernel<4, 4, false>,
@@ -634,7 +640,7 @@ extern "C" int cnr_field_bwd_pipe8_launch(const float* pts, const float* B, cons
   hipLaunchKernelGGL((field_bwd_pipe8_kernel<4, 4, WIDE>), dim3((unsigned)blocks, (unsigned)C), dim3(512),           \
                      l8_total(4), (hipStream_t)stream, pts, B, (const unsigned char*)packed, biasrows, ray_row,      \
                      1.0f / scale, d_sigma, d_rgb, grad_scale, (float*)workspace, (int)N, S, R, rows_per_class,       \
-                     B_stride > 0 ? B_stride : (int64_t)63, rows_fix)
+                     B_stride > 0 ? B_stride : (int64_t)63, rows_fix, clamp_flags)
   if (rows_per_class > 4) CNR_LAUNCH_P8(true); else CNR_LAUNCH_P8(false);
 #undef CNR_LAUNCH_P8
   CNR_LAUNCH_CHECK();

@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void field_fwd_render_kernel(
     float* __restrict__ d_sigmas, float* __restrict__ d_colors, float* __restrict__ depth_out,
     float* __restrict__ var_out, float* __restrict__ rgb_out, float* __restrict__ opacity_out, int C, int R,
     int64_t B_stride, float* __restrict__ partials, const unsigned char* __restrict__ packed_lo,
-    const float* __restrict__ counts_ext) {
+    const float* __restrict__ counts_ext, const float* __restrict__ counts_tab, const int64_t* __restrict__ d_state) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ float cnt[12];
   __shared__ float cntw[4][3 * 16];  // per wave, per class: the three mask counts (register path below)
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void field_fwd_render_kernel(
   // C <= 16; anything else takes the loop further down.
   constexpr int MAXW = 8;
   const int nw = (R + 1023) / 1024;
-  const bool counts_in_regs = !counts_ext && C * nw <= MAXW && (R & 3) == 0 && C <= 16;
+  const bool counts_in_regs = !counts_tab && !counts_ext && C * nw <= MAXW && (R & 3) == 0 && C <= 16;
   unsigned int lw[MAXW], mw[MAXW];
   if (counts_in_regs) {
 #pragma unroll
@@ -417,6 +417,12 @@ __global__ __launch_bounds__(256, 2) void field_fwd_render_kernel(
       empty_d |= (a == 0.f); empty_c |= (b == 0.f); empty_o |= (d == 0.f);
       if (cc == c) { nd = a; nc = b; no = d; }
     }
+  } else if (counts_tab) {  // per-epoch table (cnr_slice_maskcounts): this slice's counts and the any-class-empty flags,
+                            // possibly summed / or-ed over GPUs by the host -- the kernel never looks at other classes
+    const float* t = counts_tab + (size_t)(d_state ? d_state[0] / R : 0) * (size_t)(C + 1) * 4;
+    nd = t[c * 4 + 0]; nc = t[c * 4 + 1]; no = t[c * 4 + 2];
+    empty_d = t[C * 4 + 0] != 0.f; empty_c = t[C * 4 + 1] != 0.f; empty_o = t[C * 4 + 2] != 0.f;
+    __syncthreads();  // the weight fragments are in LDS
   } else if (counts_ext) {  // counted by mask_counts_kernel just before this launch
     for (int cc = 0; cc < C; ++cc) {
       const float a = counts_ext[cc * 3 + 0], b = counts_ext[cc * 3 + 1], d = counts_ext[cc * 3 + 2];
@@ -593,7 +599,8 @@ extern "C" int cnr_field_fwd_render(const float* pts, const float* B, const void
                                     float color_scaling, float opacity_scaling, float grad_scale, float* d_sigmas,
                                     float* d_colors, float* depth, float* var, float* rgb, float* opacity, int C, int R,
                                     int S, int64_t B_stride, void* workspace, int64_t workspace_bytes,
-                                    const void* packed_lo, void* stream) {
+                                    const void* packed_lo, const float* counts_tab, const int64_t* d_state,
+                                    void* stream) {
   if (!pts || !B || !packed || !biasrows || !z || !gt_depth || !gt_rgb || !labels || !depth_mask || !d_sigmas ||
       !d_colors || !workspace || C <= 0 || R <= 0 || !(scale > 0.f))
     return CNR_E_ARG;
@@ -607,7 +614,7 @@ extern "C" int cnr_field_fwd_render(const float* pts, const float* B, const void
   // mask counts: inside the kernel from registers when they fit (few classes / rays), else by a one-block-per-class
   // kernel into the workspace's tail
   const float* counts_ext = nullptr;
-  if (!(C * ((R + 1023) / 1024) <= 8 && (R & 3) == 0 && C <= 16)) {
+  if (!counts_tab && !(C * ((R + 1023) / 1024) <= 8 && (R & 3) == 0 && C <= 16)) {
     float* cx = (float*)workspace + (size_t)C * nb * 3 + (size_t)C * 4;
     hipLaunchKernelGGL(mask_counts_kernel, dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream, labels, depth_mask, R, cx);
     counts_ext = cx;
@@ -620,7 +627,7 @@ extern "C" int cnr_field_fwd_render(const float* pts, const float* B, const void
                        (const unsigned char*)packed, biasrows, ray_row, 1.0f / scale, z, gt_depth, gt_rgb, labels,   \
                        depth_mask, color_scaling, opacity_scaling, grad_scale, d_sigmas, d_colors, depth, var, rgb,  \
                        opacity, C, R, B_stride > 0 ? B_stride : (int64_t)63, (float*)workspace,                      \
-                       (const unsigned char*)packed_lo, counts_ext);                                                \
+                       (const unsigned char*)packed_lo, counts_ext, counts_tab, d_state);                           \
   } while (0)
   if (packed_lo) {
     switch (S / 32) {
@@ -669,7 +676,9 @@ extern "C" int cnr_step_prologue(
     const float* g, uint64_t seed, uint64_t offset, const int64_t* d_state, int64_t pool_rows, const float* max_bound,
     int world_frame, int R, int n1, int n2, float eps, float stop_eps, float min_bound, float* z, float* pts,
     float* origins, float* dirs_o, float* gt_rgb, float* gt_depth, uint8_t* depth_mask, uint8_t* labels,
-    const int64_t* pool_indices, int* ray_row, const int* perm, int max_bound_slices, void* stream) {
+    const int64_t* pool_indices, int* ray_row, const int* perm, int max_bound_slices, int rng_c0, int rng_cstride,
+    int rng_R, int rng_r0, void* stream) {
+  if (rng_c0 < 0 || rng_cstride < 0 || rng_R < 0 || rng_r0 < 0 || (rng_R > 0 && rng_r0 + R > rng_R)) return CNR_E_ARG;
   if (max_bound_slices < 0 || (max_bound_slices > 1 && (pool_rows <= 0 || !d_state))) return CNR_E_ARG;
   if (!theta || !packed || !zl || !biasrows || L <= 0 || n_obj <= 0 || C <= 0 || zero_count < 0 ||
       (zero_count > 0 && !zero_buf))
@@ -689,7 +698,7 @@ extern "C" int cnr_step_prologue(
   const int nsample = (R + 3) / 4;
   cnr_sample::SampleArgs sa{rgbs, depth, dirs_c, T, u, g, seed, offset, d_state, pool_rows, max_bound, world_frame,
                             C, R, n1, n2, eps, stop_eps, min_bound, z, pts, origins, dirs_o, gt_rgb, gt_depth,
-                            depth_mask, labels, pool_indices, n_obj, ray_row, perm, max_bound_slices};
+                            depth_mask, labels, pool_indices, n_obj, ray_row, perm, max_bound_slices, rng_c0, rng_cstride, rng_R, rng_r0};
   dim3 grid(fz::NKK_FWD + fz::NKK_BWD + 1 + 4 * n_obj + nzero + nsample, (unsigned)C);
   hipLaunchKernelGGL(param_prep_kernel, grid, dim3(256), 0, (hipStream_t)stream, theta, lay, off_trunk,
                      (unsigned char*)packed, zl, biasrows, zero_buf, zero_count, nzero, sa, nsample);

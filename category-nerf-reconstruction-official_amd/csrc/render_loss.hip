@@ -50,14 +50,20 @@ __global__ __launch_bounds__(RL_THREADS) void render_loss_kernel(
     const uint8_t* __restrict__ depth_mask, float color_scaling, float opacity_scaling, float grad_scale,
     float* __restrict__ d_sigmas, float* __restrict__ d_colors, float* __restrict__ depth_out,
     float* __restrict__ var_out, float* __restrict__ rgb_out, float* __restrict__ opacity_out, int C, int R, int S,
-    float* __restrict__ partials, int rays_per_block) {
+    float* __restrict__ partials, int rays_per_block, const float* __restrict__ counts_tab,
+    const int64_t* __restrict__ d_state) {
   __shared__ float cnt[3 * RL_WAVES];
   __shared__ float wsum[3 * RL_WAVES];
   const int c = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   // ---- mask counts of every class: the empty-mask rule of render_rays.py:67-72 couples the classes --------
   bool empty_d = false, empty_c = false, empty_o = false;
   float nd = 0.f, nc = 0.f, no = 0.f;
-  for (int cc = 0; cc < C; ++cc) {
+  if (counts_tab) {  // per-epoch table (cnr_slice_maskcounts), see cnr_field_fwd_render
+    const float* t = counts_tab + (size_t)(d_state ? d_state[0] / R : 0) * (size_t)(C + 1) * 4;
+    nd = t[c * 4 + 0]; nc = t[c * 4 + 1]; no = t[c * 4 + 2];
+    empty_d = t[C * 4 + 0] != 0.f; empty_c = t[C * 4 + 1] != 0.f; empty_o = t[C * 4 + 2] != 0.f;
+  }
+  for (int cc = 0; cc < (counts_tab ? 0 : C); ++cc) {
     float a = 0.f, b = 0.f, d = 0.f;
     for (int r = threadIdx.x; r < R; r += RL_THREADS) {
       const uint8_t lab = labels[(size_t)cc * R + r];
@@ -327,7 +333,8 @@ extern "C" int cnr_render_loss(const float* sigmas, const float* colors, const f
                                const float* gt_rgb, const uint8_t* labels, const uint8_t* depth_mask,
                                float color_scaling, float opacity_scaling, float grad_scale, float* d_sigmas,
                                float* d_colors, float* depth, float* var, float* rgb, float* opacity, int C, int R,
-                               int S, void* workspace, int64_t workspace_bytes, void* stream) {
+                               int S, void* workspace, int64_t workspace_bytes, const float* counts_tab,
+                               const int64_t* d_state, void* stream) {
   if (!sigmas || !colors || !z || !gt_depth || !gt_rgb || !labels || !depth_mask || !d_sigmas || !d_colors ||
       !workspace || C <= 0 || R <= 0 || S <= 0)
     return CNR_E_ARG;
@@ -337,7 +344,7 @@ extern "C" int cnr_render_loss(const float* sigmas, const float* colors, const f
   const int nb = (R + rpb - 1) / rpb;
   hipLaunchKernelGGL(render_loss_kernel, dim3(nb, C), dim3(RL_THREADS), 0, (hipStream_t)stream, sigmas, colors, z,
                      gt_depth, gt_rgb, labels, depth_mask, color_scaling, opacity_scaling, grad_scale, d_sigmas,
-                     d_colors, depth, var, rgb, opacity, C, R, S, (float*)workspace, rpb);
+                     d_colors, depth, var, rgb, opacity, C, R, S, (float*)workspace, rpb, counts_tab, d_state);
   CNR_LAUNCH_CHECK();
   return CNR_OK;
 }

@@ -50,6 +50,39 @@ __global__ __launch_bounds__(256) void slice_maxdepth_kernel(const float* __rest
   if (threadIdx.x == 0) out[(int64_t)c * nsl + s] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
 }
 
+// mask counts of every slice of an epoch: block s -> out[s][c][0..2] = #(valid depth & label != 0), #(label != 0),
+// #(label != 2) over the R rows of slice s of class c (what cnr_render_loss / cnr_field_fwd_render count per step),
+// out[s][C][0..2] = 1 where ANY class of the slice has a zero count (the empty-mask rule, src/render_rays.py:67-72)
+__global__ __launch_bounds__(256) void slice_maskcounts_kernel(const uint8_t* __restrict__ rgbs,
+                                                               const float* __restrict__ depth,
+                                                               const int* __restrict__ perm, int64_t pool_rows, int C,
+                                                               int R, float min_bound, float* __restrict__ out) {
+  const int s = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  __shared__ float sm[12];
+  float* o = out + (size_t)s * (C + 1) * 4;
+  float e0 = 0.f, e1 = 0.f, e2 = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const int64_t cbase = (int64_t)c * pool_rows, base = cbase + (int64_t)s * R;
+    float a = 0.f, b = 0.f, d = 0.f;
+    for (int r = threadIdx.x; r < R; r += 256) {
+      const int64_t at = perm ? cbase + perm[base + r] : base + r;
+      const uint8_t lab = rgbs[at * 4 + 3];
+      const bool mo = lab != 0, ms = lab != 2, md = depth[at] > min_bound;
+      a += (md && mo) ? 1.f : 0.f; b += mo ? 1.f : 0.f; d += ms ? 1.f : 0.f;
+    }
+    a = cnr::wave_sum(a); b = cnr::wave_sum(b); d = cnr::wave_sum(d);
+    __syncthreads();
+    if (lane == 0) { sm[wv] = a; sm[4 + wv] = b; sm[8 + wv] = d; }
+    __syncthreads();
+    a = (sm[0] + sm[1]) + (sm[2] + sm[3]); b = (sm[4] + sm[5]) + (sm[6] + sm[7]); d = (sm[8] + sm[9]) + (sm[10] + sm[11]);
+    if (threadIdx.x == 0) { o[c * 4 + 0] = a; o[c * 4 + 1] = b; o[c * 4 + 2] = d; o[c * 4 + 3] = 0.f; }
+    if (a == 0.f) e0 = 1.f;
+    if (b == 0.f) e1 = 1.f;
+    if (d == 0.f) e2 = 1.f;
+  }
+  if (threadIdx.x == 0) { o[C * 4 + 0] = e0; o[C * 4 + 1] = e1; o[C * 4 + 2] = e2; o[C * 4 + 3] = 0.f; }
+}
+
 __global__ __launch_bounds__(256) void sample_kernel(cnr_sample::SampleArgs a) {
   const int lane = threadIdx.x & 63;
   const int64_t ray = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -88,6 +121,15 @@ extern "C" int cnr_slice_maxdepth(const float* depth, const int* perm, int64_t p
   return CNR_OK;
 }
 
+extern "C" int cnr_slice_maskcounts(const uint8_t* rgbs, const float* depth, const int* perm, int64_t pool_rows, int C, int R,
+                                    int slices, float min_bound, float* out, void* stream) {
+  if (!rgbs || !depth || !out || C <= 0 || R <= 0 || slices <= 0 || pool_rows < (int64_t)slices * R) return CNR_E_ARG;
+  hipLaunchKernelGGL(slice_maskcounts_kernel, dim3((unsigned)slices), dim3(256), 0, (hipStream_t)stream, rgbs, depth, perm,
+                     pool_rows, C, R, min_bound, out);
+  CNR_LAUNCH_CHECK();
+  return CNR_OK;
+}
+
 extern "C" int cnr_sample_rays(const uint8_t* rgbs, const float* depth, const float* dirs_c, const float* T,
                                const float* u, const float* g, uint64_t seed, uint64_t offset,
                                const int64_t* d_state, int64_t pool_rows,
@@ -108,7 +150,7 @@ extern "C" int cnr_sample_rays(const uint8_t* rgbs, const float* depth, const fl
   const int64_t blocks = (rays + waves_per_block - 1) / waves_per_block;
   cnr_sample::SampleArgs args{rgbs, depth, dirs_c, T, u, g, seed, offset, d_state, pool_rows, max_bound, world_frame,
                               C, R, n1, n2, eps, stop_eps, min_bound, z, pts, origins, dirs_o, gt_rgb, gt_depth,
-                              depth_mask, labels, pool_indices, n_obj, ray_row, perm, 0};
+                              depth_mask, labels, pool_indices, n_obj, ray_row, perm, 0, 0, 0, 0, 0};
   hipLaunchKernelGGL(sample_kernel, dim3((unsigned)blocks), dim3(64 * waves_per_block), 0, (hipStream_t)stream, args);
   CNR_LAUNCH_CHECK();
   return CNR_OK;

@@ -14,6 +14,11 @@ struct SampleArgs {
   // max_bound layout: mb_slices <= 1: one value per class (this step's slice); mb_slices > 1: a (C, mb_slices) table
   // over the epoch's slices, indexed by device cursor / R (filled once per reshuffle by cnr_slice_maxdepth)
   int mb_slices;
+  // Philox counter of ray r of local class c: ((c * rng_cstride + rng_c0) * rng_R + rng_r0 + r) * 64 + lane -- the
+  // index the ray has in the GLOBAL batch when classes (rng_c0 = first global class, rng_cstride = ranks) or rays
+  // (rng_R = global rays per class, rng_r0 = this rank's first ray) are sharded over GPUs, so that N ranks draw
+  // exactly what one rank would.  All zero: the local index c * R + r.
+  int rng_c0, rng_cstride, rng_R, rng_r0;
 };
 
 
@@ -82,6 +87,9 @@ __device__ __forceinline__ void sample_ray(const SampleArgs& a, int64_t ray, int
   (void)C;
   const int c = (int)(ray / R);
   const int S = n1 + n2;
+  const uint64_t rng_ray = a.rng_R > 0 ? ((uint64_t)c * (uint64_t)(a.rng_cstride > 0 ? a.rng_cstride : 1) + (uint64_t)a.rng_c0) * (uint64_t)a.rng_R
+                                             + (uint64_t)a.rng_r0 + (uint64_t)(ray - (int64_t)c * R)
+                                       : (uint64_t)ray;
   // pool row of this ray: either the slice itself (pool_rows == 0) or row cursor + r of a device-resident
   // (C, pool_rows, ...) pool whose cursor lives on the device (hipGraph replay advances it, no host work)
   int64_t prow = ray;
@@ -143,7 +151,7 @@ __device__ __forceinline__ void sample_ray(const SampleArgs& a, int64_t ray, int
       if (lane + 64 < n2) g1 = g[ray * n2 + lane + 64];
     } else {
       uint32_t rnd[4];
-      philox4(seed, (uint64_t)ray * 64 + lane, offset ^ 0x9E3779B97F4A7C15ull, rnd);
+      philox4(seed, rng_ray * 64 + lane, offset ^ 0x9E3779B97F4A7C15ull, rnd);
       const float sd = eps / 3.0f;
       const float r0 = sqrtf(-2.0f * __logf(1.0f - u01(rnd[0]))), a0 = 6.28318530718f * u01(rnd[1]);
       const float r1 = sqrtf(-2.0f * __logf(1.0f - u01(rnd[2]))), a1 = 6.28318530718f * u01(rnd[3]);
@@ -174,7 +182,7 @@ __device__ __forceinline__ void sample_ray(const SampleArgs& a, int64_t ray, int
       if (live) uu = u[ray * S + s];
     } else {
       uint32_t rnd[4];
-      philox4(seed, (uint64_t)ray * 64 + lane, offset + 1 + (s0 >> 6), rnd);
+      philox4(seed, rng_ray * 64 + lane, offset + 1 + (s0 >> 6), rnd);
       uu = u01(rnd[0]);
     }
     const int i = s - n1;

@@ -38,6 +38,7 @@ struct TailArgs {
   const float* records; int nwg; const long long* rows_fix; int NR;
   // grad_only: stop at the finished gradient (no AdamW, no epilogue blocks): the multi-GPU step all-reduces it first
   int grad_only;
+  int* clamp_flags;  // optional (C,): bits the field backward raised this step (cnr_field_bwd_pipe); or-ed into flags, cleared
 };
 
 __device__ __forceinline__ void adam_one(const TailArgs& a, int64_t e, float g, float step_size, float inv_bc2_sqrt) {
@@ -207,7 +208,10 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
   const int c = b, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   float* red = sm;
   const int64_t cursor = a.state_cur[0] + a.add_rows;
-  if (wv == 0) cnr_rl::finish_class(a.partials, a.nb, a.losses, a.flags, C, c, lane);
+  if (wv == 0) {
+    cnr_rl::finish_class(a.partials, a.nb, a.losses, a.flags, C, c, lane);
+    if (a.clamp_flags && lane == 0) { a.flags[c] |= a.clamp_flags[c]; a.clamp_flags[c] = 0; }   // same lane wrote flags[c]
+  }
   if (a.max_bound) {
     float mx = -INFINITY;
     const int64_t cbase = (int64_t)c * a.pool_rows, base = cbase + cursor;
@@ -245,7 +249,7 @@ extern "C" int cnr_step_tail(const float* theta_in, float* theta_out, float* gra
                              float weight_decay, const int64_t* state_cur, int64_t* state_next, int64_t add_rows,
                              const void* rl_workspace, float* losses, int32_t* flags, const float* depth,
                              int64_t pool_rows, const int* perm, float* next_max_bound, int R, const void* records,
-                             int nwg, const long long* rows_fix, int rl_blocks, void* stream) {
+                             int nwg, const long long* rows_fix, int rl_blocks, int* clamp_flags, void* stream) {
   if (!theta_in || !theta_out || theta_in == theta_out || !grad || !exp_avg || !exp_avg_sq || class_stride <= 0 ||
       L <= 0 || n_obj <= 0 || C <= 0 || !state_cur || !state_next || state_cur == state_next || !rl_workspace ||
       !losses || !flags || R <= 0)
@@ -274,6 +278,7 @@ extern "C" int cnr_step_tail(const float* theta_in, float* theta_out, float* gra
   if (na > 2048) na = 2048;
   a.NA = (int)na;
   a.records = (const float*)records; a.nwg = nwg; a.rows_fix = rows_fix; a.NR = cnr_rec::REC_FLOATS / 64;
+  a.clamp_flags = clamp_flags;
   const unsigned grid = (unsigned)((a.do_latent ? a.NL * C : 0) + (records ? a.NR * C : a.NA) + C);
   const size_t lds = (size_t)(2 * n_obj * 128 + 2 * n_obj + 520) * sizeof(float);
   hipLaunchKernelGGL(tail_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);

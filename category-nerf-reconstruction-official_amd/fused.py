@@ -72,11 +72,27 @@ def init_params(C, L, n_obj, generator=None, device="cpu"):
 
 
 class FusedCategoryTrainer:
-    """C classes x n_obj objects, R rays per class per step, S = n1 + n2 samples per ray."""
+    """C classes x n_obj objects, R rays per class per step, S = n1 + n2 samples per ray.
+
+    Multi-GPU (one process per GPU, ``process_group`` = a torch.distributed group; backend "nccl" is RCCL), two ways --
+    SURVEY.md section 8(e):
+
+    * ``shard="class"``: this rank owns the classes ``class_ids`` (default ``rank::world`` of ``n_cls_global``); ``n_cls``
+      and ``pools`` are the LOCAL classes.  Classes share nothing (train.py:58-64, src/loss.py:70), so there is NO
+      gradient collective and the step stays one captured graph.  The one coupling, the any-class-empty rule of
+      src/render_rays.py:67-72, crosses ranks once per EPOCH: three flags per slice, all-reduced when the pool is
+      reshuffled (see ``_reshuffle``).
+    * ``shard="ray"``: every rank holds the same pools and parameters and takes rows ``[rank R, rank R + R)`` of each
+      global slice of ``world * R`` rows.  Masked means divide by the class's GLOBAL mask counts and the invalid-depth
+      rays use the global slice's max depth -- both come from per-epoch tables every rank computes from its own copy of
+      the pool, no collective -- the Philox draws are indexed by the global ray, and the flat gradient is summed by ONE
+      all-reduce per step: N ranks x R rays are one rank x N R rays to fp32 summation order (tests/test_multigpu_gpu.py).
+    """
 
     def __init__(self, cfg, n_cls, n_obj, pools, rays_per_step, device, seed=0, generator=None,
                  grad_scale=None, bwd_blocks=0, process_group=None, use_graph=True, split_graph=False,
-                 fuse_render=True, split_weights=None):
+                 fuse_render=True, split_weights=None, shard=None, n_cls_global=None, class_ids=None,
+                 check_every=0, world_frame=None, dp_rank=None, dp_world=None):
         self.cfg, self.C, self.n_obj, self.R = cfg, n_cls, n_obj, rays_per_step
         self.device = torch.device(device)
         self.n1, self.n2 = cfg.n_bins_cam2surface, cfg.n_bins
@@ -86,7 +102,27 @@ class FusedCategoryTrainer:
         self.lr, self.wd = cfg.learning_rate, cfg.weight_decay
         assert cfg.code_learning_rate == cfg.learning_rate and cfg.code_weight_decay == cfg.weight_decay, \
             "one flat AdamW group: the shipped configs use identical lr / weight decay for codes and networks"
-        theta0, self.lay = init_params(n_cls, self.L, n_obj, generator, self.device)
+        # ---- sharding ---------------------------------------------------------------------------------------------
+        self.pg = process_group
+        pg_world = 1 if process_group is None else torch.distributed.get_world_size(process_group)
+        pg_rank = 0 if process_group is None else torch.distributed.get_rank(process_group)
+        # (dp_rank / dp_world without a process group: one rank of a ray-sharded world, the gradient exchange left to the
+        #  caller -- tests emulate N ranks in one process this way)
+        self.world = int(dp_world) if dp_world is not None else pg_world
+        self.rank = int(dp_rank) if dp_rank is not None else pg_rank
+        self.shard = shard if shard is not None else ("ray" if self.world > 1 else None)
+        assert self.shard in (None, "ray", "class")
+        self.ray_world = self.world if self.shard == "ray" else 1       # ranks that share one class's rays
+        self.ray_rank = self.rank if self.shard == "ray" else 0
+        self.Rg = self.R * self.ray_world                                # rows of a global slice
+        if self.shard == "class":
+            self.n_cls_global = int(n_cls_global) if n_cls_global is not None else n_cls * self.world
+            self.class_ids = list(class_ids) if class_ids is not None else list(range(self.rank, self.n_cls_global, self.world))
+            assert len(self.class_ids) == n_cls
+        else:
+            self.n_cls_global, self.class_ids = n_cls, list(range(n_cls))
+        theta_all, self.lay = init_params(self.n_cls_global, self.L, n_obj, generator, "cpu")
+        theta0 = theta_all[self.class_ids].contiguous().to(self.device)
         # parameters in two copies, like the step state: step k reads copy k & 1, its last launch (AdamW, out of place)
         # writes copy (k + 1) & 1 -- gradient kernels and the optimiser never touch the same copy in one launch
         self.theta2 = torch.stack([theta0, theta0.clone()])
@@ -96,40 +132,55 @@ class FusedCategoryTrainer:
         # that the field backward fills with integer atomics for cnr_step_tail
         n_th, n_db = self.theta.numel(), n_cls * n_obj * 128
         # the field backward leaves per-workgroup records + the fixed-point table; ONE later launch reduces them next to
-        # the latent backward: with AdamW and the epilogue on a single GPU (cnr_step_tail), gradient only with a process
-        # group (cnr_step_grad: the all-reduce comes between gradient and optimiser)
+        # the latent backward: with AdamW and the epilogue when no gradient exchange follows (cnr_step_tail: single GPU,
+        # class sharding), gradient only when rays are sharded (cnr_step_grad: the all-reduce comes between gradient and
+        # optimiser)
         self.use_records = n_obj <= (7 if ops.FIELD_BWD_VARIANT == "pipe4" else 4) and ops.FIELD_BWD_VARIANT.startswith("pipe")
-        self.fused_tail = process_group is None and self.use_records
+        self.grad_exchange = self.shard == "ray" and self.world > 1
+        self.fused_tail = not self.grad_exchange and self.use_records
         fix_off = (n_th + n_db + 3) // 4 * 4                      # 16-byte aligned
         self._gbuf = torch.zeros(fix_off + (2 * 8 * n_db if self.use_records else 0), device=self.device)  # 8 copies
         self.rows_fix = self._gbuf[fix_off:].view(torch.int64) if self.use_records else None
         self.grad = self._gbuf[:self.theta.numel()].view_as(self.theta)
         self.exp_avg = torch.zeros_like(self.theta)
         self.exp_avg_sq = torch.zeros_like(self.theta)
-        self.pg = process_group
-        self.world = 1 if process_group is None else torch.distributed.get_world_size(process_group)
-        # device-resident pools stacked over classes: (C, Npool, ...)
+        # device-resident pools stacked over classes: (C, Npool, ...).  A class that trains in the WORLD frame (the
+        # reference does that for single-object categories: origin_dirs_W on T_wc, src/scene_cateogries.py:427-432) keeps
+        # inv(T_wc) in the pose slot: the sampler's origin_dirs_O inverts it back (rigid, so exact to fp32 rounding)
+        if world_frame is None:
+            world_frame = n_obj == 1 and all("T_wc" in p for p in pools)
+        self.world_frame = [bool(world_frame)] * n_cls if isinstance(world_frame, (bool, int)) else [bool(w) for w in world_frame]
         st = lambda k: torch.stack([p[k] for p in pools]).to(self.device).contiguous()
-        self.pool = dict(rgbs=st("rgbs"), depth=st("depth"), dirs=st("dirs"), T=st("T_co"), indices=st("indices"))
+        T = torch.stack([torch.linalg.inv(p["T_wc"]) if wf else p["T_co"] for p, wf in zip(pools, self.world_frame)])
+        self.pool = dict(rgbs=st("rgbs"), depth=st("depth"), dirs=st("dirs"), T=T.to(self.device).contiguous(),
+                         indices=st("indices"))
         self.pool_rows = self.pool["depth"].shape[1]
-        assert self.pool_rows >= 2 * self.R
+        assert self.pool_rows >= 2 * self.Rg
         # device-side step state {pool cursor, rng step, optimiser step}, two copies: step k reads copy k & 1 and its
         # last kernel writes copy (k + 1) & 1 -- no kernel ever writes a state another kernel of the same step reads
         self.d_state2 = torch.zeros(2, 3, device=self.device, dtype=torch.int64)
-        # epoch shuffle as an index permutation (C, pool_rows): the pool itself never moves
+        # epoch shuffle as an index permutation (C, pool_rows): the pool itself never moves.  Drawn from a generator of
+        # its own so that every rank of a sharded run draws the same permutations, whatever else uses the default one
         self.perm = torch.empty(n_cls, self.pool_rows, device=self.device, dtype=torch.int32)
-        self._zero64 = torch.zeros(1, device=self.device, dtype=torch.int64)
-        # max depth of every slice of the epoch (scene_cateogries.py:486 needs the current slice's): one table per
-        # reshuffle, indexed on the device by cursor / R -- no step computes a maximum
-        self.n_slices = self.pool_rows // self.R
+        self._perm_gen = torch.Generator(device=self.device)
+        self._perm_gen.manual_seed(0x5EED + 7919 * int(seed))
+        self._cursor0 = torch.tensor([self.ray_rank * self.R], device=self.device, dtype=torch.int64)
+        # per-epoch tables, one entry per LOCAL slice (index = device cursor / R): the max depth of the (global) slice
+        # (scene_cateogries.py:486) and the mask counts + any-class-empty flags of the (global) slice
+        # (render_rays.py:66-95) -- no step computes a maximum or counts a mask
+        self.n_gslices = self.pool_rows // self.Rg
+        self.n_slices = self.n_gslices * self.ray_world
         self.slice_max = torch.zeros(n_cls, self.n_slices, device=self.device)
+        self.counts_tab = torch.zeros(self.n_slices, n_cls + 1, 4, device=self.device)
         self.cursor = 0
         self.seed = int(seed) + 1
-        self.grad_scale = float(grad_scale) if grad_scale else float(2 ** round(math.log2(max(self.R, 2))))
+        self.grad_scale = float(grad_scale) if grad_scale else float(2 ** round(math.log2(max(self.Rg, 2))))
         self.bwd_blocks = int(bwd_blocks)
         self.bufs = {}
         self.losses = torch.zeros(3, n_cls, device=self.device)
         self.flags = torch.zeros(n_cls, device=self.device, dtype=torch.int32)
+        self.clamp = torch.zeros(n_cls, device=self.device, dtype=torch.int32)
+        self.check_every = int(check_every)
         self.dbias = self._gbuf[n_th:n_th + n_db].view(n_cls * n_obj, 4, 32)
         self._nwg = int(_C.load().cnr_field_bwd_pipe_blocks(self.R, self.S, int(ops.FIELD_BWD_VARIANT[-1]), self.bwd_blocks)) \
             if self.use_records else 0
@@ -158,8 +209,8 @@ class FusedCategoryTrainer:
 
     def _step_body(self):
         self._step_front()
-        if self.pg is not None:
-            parallel.allreduce_mean_(self.grad, self.pg, prescaled=True)   # one flat buffer, one collective
+        if self.grad_exchange and self.pg is not None:
+            parallel.allreduce_sum_(self.grad, self.pg)                    # one flat buffer, one collective
         self._step_back()
 
     def _step_front(self):
@@ -199,7 +250,8 @@ class FusedCategoryTrainer:
         b = ops.step_prologue(self.theta, lay, L, n_obj, packed, zl, brows, self._gbuf, self.pool["rgbs"],
                               self.pool["depth"], self.pool["dirs"], self.pool["T"], self.n1, self.n2, cfg.surface_eps,
                               cfg.stop_eps, cfg.min_depth, self.seed, self.d_state2[self.parity], R, self.bufs,
-                              self.slice_max, self.pool["indices"], self.perm, max_bound_slices=self.n_slices)
+                              self.slice_max, self.pool["indices"], self.perm, max_bound_slices=self.n_slices,
+                              rng=self._rng_map())
         ray_row = b["ray_row"]
         lo = None
         if self.split_weights:
@@ -207,26 +259,30 @@ class FusedCategoryTrainer:
                 o["packed_lo"] = torch.empty(C, int(_C.load().cnr_pack_lo_bytes()), device=self.device, dtype=torch.uint8)
             lo = o["packed_lo"]
             _C.call("cnr_pack_weights_lo", v["trunk"] if C == 1 else v["trunk"].contiguous(), lo, C)
-        inv_w = 1.0 / self.world
+        # the loss gradient of a ray carries 1 / (GLOBAL mask count of its class) out of counts_tab: ray shards add up to
+        # the whole batch's gradient, nothing to rescale; the code regulariser is formed on every ray shard -> 1 / world
+        inv_w = 1.0
+        st = self.d_state2[self.parity]
         if self._rl_blocks:
             # a8-a15 in one launch (S = 32 k): field forward, composite, losses, their gradient, composite backward;
             # sigma / colour per sample never leave registers
             _C.call("cnr_field_fwd_render", b["pts"], Bc, packed, brows, ray_row, self.scale, b["z"], b["gt_depth"],
                     b["gt_rgb"], b["labels"], b["depth_mask"], 5.0, 10.0, inv_w, o["dsig"], o["drgb"], o["depth"],
-                    o["var"], o["rgb"], o["opa"], C, R, S, P, o["rl_ws"], o["rl_ws"].numel(), lo)
+                    o["var"], o["rgb"], o["opa"], C, R, S, P, o["rl_ws"], o["rl_ws"].numel(), lo, self.counts_tab, st)
         else:
             # a8 + a9 fused forward, then a11-a15 in one launch
             sig, rgb = o["sig"], o["rgbs"]
             _C.call("cnr_field_fwd", b["pts"], Bc, packed, brows, ray_row, self.scale, sig, rgb, C, R, S, P, lo)
             _C.call("cnr_render_loss", sig, rgb, b["z"], b["gt_depth"], b["gt_rgb"], b["labels"], b["depth_mask"],
                     5.0, 10.0, inv_w, o["dsig"], o["drgb"], o["depth"], o["var"], o["rgb"], o["opa"], C, R, S,
-                    o["rl_ws"], o["rl_ws"].numel())
+                    o["rl_ws"], o["rl_ws"].numel(), self.counts_tab, st)
         # fused backward: dtrunk, dB, dbiasrows straight into the flat gradient buffer views
         ops.field_bwd(b["pts"], Bc, packed, brows, ray_row, self.scale, o["dsig"], o["drgb"], self.grad_scale,
                       g_trunk, g_B, self.dbias, C, R, S, n_obj, self.bwd_blocks, o["bwd_ws"],
-                      B_stride=P, dtrunk_stride=P, dB_stride=P, rows_fix=self.rows_fix, skip_reduce=self.use_records)
-        self._reg = 0.0005 * inv_w               # code regulariser scale: loss.py:5-15, train.py:165-167
-        if self.pg is not None:                  # data parallel: the all-reduce needs the complete gradient first
+                      B_stride=P, dtrunk_stride=P, dB_stride=P, rows_fix=self.rows_fix, skip_reduce=self.use_records,
+                      clamp_flags=self.clamp)
+        self._reg = 0.0005 / self.ray_world      # code regulariser scale: loss.py:5-15, train.py:165-167
+        if self.grad_exchange:                   # ray shards: the all-reduce needs the complete gradient first
             if self.use_records:                 # record reduction + latent backward in one launch, gradient only
                 _C.call("cnr_step_grad", self.theta, self.grad, lay.total, lay.B[0], lay.latW[0], lay.latb[0],
                         lay.shape[0], lay.tex[0], L, n_obj, C, zl, self.dbias, self._reg, o["bwd_ws"], self._nwg,
@@ -244,11 +300,11 @@ class FusedCategoryTrainer:
         C, R, o, par, lay = self.C, self.R, self.bufs, self.parity, self.lay
         _C.call("cnr_step_tail", self.theta2[par], self.theta2[1 - par], self.grad, self.exp_avg, self.exp_avg_sq,
                 lay.total, lay.B[0], lay.latW[0], lay.latb[0], lay.shape[0], lay.tex[0], self.L, self.n_obj, C,
-                o["zl"], self.dbias, self._reg, 0 if self.pg is not None else 1, self.lr, 0.9, 0.999, 1e-8, self.wd,
-                self.d_state2[par], self.d_state2[1 - par], R, o["rl_ws"], self.losses, self.flags,
+                o["zl"], self.dbias, self._reg, 0 if self.grad_exchange else 1, self.lr, 0.9, 0.999, 1e-8, self.wd,
+                self.d_state2[par], self.d_state2[1 - par], self.Rg, o["rl_ws"], self.losses, self.flags,
                 None, self.pool_rows, None, None, R,
                 o["bwd_ws"] if self.fused_tail else None, self._nwg if self.fused_tail else 0,
-                self.rows_fix if self.fused_tail else None, self._rl_blocks)
+                self.rows_fix if self.fused_tail else None, self._rl_blocks, self.clamp)
 
     def step(self):
         """One train step.  Returns nothing; ``self.losses`` (3,C) / ``self.flags`` (C,) hold the device-side
@@ -257,9 +313,8 @@ class FusedCategoryTrainer:
         After two eager steps the step is captured, once per state parity: one hipGraph on a single GPU; with a
         process group TWO graphs around the all-reduce (front graph, eager RCCL call, back graph) -- three host
         calls per step, and no collective inside a capture."""
-        if self.cursor + 2 * self.R > self.pool_rows:   # epoch end: reshuffle (scene_cateogries.py:439-449)
-            self._reshuffle()
-        split = self.pg is not None or self.split_graph
+        self._pre_step()
+        split = self.grad_exchange or self.split_graph
         par = self.parity
         if not self.use_graph or self.steps_done < 2:
             self._step_body()
@@ -269,8 +324,8 @@ class FusedCategoryTrainer:
                 with torch.cuda.graph(ga):
                     self._step_front()
                 ga.replay()                  # capture only records: run the part it stands for
-                if self.pg is not None:
-                    parallel.allreduce_mean_(self.grad, self.pg, prescaled=True)
+                if self.grad_exchange and self.pg is not None:
+                    parallel.allreduce_sum_(self.grad, self.pg)
                 with torch.cuda.graph(gb, pool=ga.pool()):
                     self._step_back()
                 gb.replay()
@@ -283,14 +338,54 @@ class FusedCategoryTrainer:
                 self.graphs[par] = g
         elif split:
             self.graphs[par][0].replay()
-            if self.pg is not None:
-                parallel.allreduce_mean_(self.grad, self.pg, prescaled=True)
+            if self.grad_exchange and self.pg is not None:
+                parallel.allreduce_sum_(self.grad, self.pg)
             self.graphs[par][1].replay()
         else:
             self.graphs[par].replay()
+        self._post_step()
+
+    def _pre_step(self):
+        if self.cursor >= self.pool_rows - self.Rg:    # epoch end: reshuffle (i_batch >= N - n, scene_cateogries.py:439-449)
+            self._reshuffle()
+
+    def _post_step(self):
         self.parity ^= 1
-        self.cursor += self.R
+        self.cursor += self.Rg
         self.steps_done += 1
+        if self.check_every and self.steps_done % self.check_every == 0:
+            self.check_flags()
+
+    def _rng_map(self):
+        """(first global class, class stride, global rays per class, first ray of this rank): the Philox counter of a ray
+        is its index in the GLOBAL batch, so shards draw what a single GPU would (include/cnr_hip.h, cnr_step_prologue)."""
+        if self.shard == "class":
+            ids = self.class_ids
+            stride = ids[1] - ids[0] if len(ids) > 1 else 1
+            if all(ids[k] == ids[0] + k * stride for k in range(len(ids))):
+                return (ids[0], stride, self.R, 0)
+            return (0, 0, 0, 0)       # irregular ownership: local indices (still a valid stream, just not the single-GPU one)
+        if self.shard == "ray":
+            return (0, 1, self.Rg, self.ray_rank * self.R)
+        return (0, 0, 0, 0)
+
+    def check_flags(self):
+        """The reference exits on a loss above 1e5 (src/render_rays.py:87-89); the step itself never syncs, so the
+        explode bit is looked at here (a host sync: call at the logging cadence, or pass check_every=k).  Returns the
+        flag words; bit 4 = the field backward clipped a scaled gradient this step (reported, not fatal)."""
+        from .render_rays import LossExplode
+        fl = self.flags.cpu()
+        if bool((fl & 1).any()):
+            raise LossExplode(f"loss explode: step {self.steps_done}, losses {self.losses.cpu().tolist()}")
+        return fl
+
+    def loss_values(self):
+        """(3, C) depth / colour / opacity terms of the last step over the WHOLE batch: with ray shards every rank holds its
+        rays' share of the class sums (already divided by the global counts), so the values add up over ranks."""
+        out = self.losses.clone()
+        if self.grad_exchange and self.pg is not None:
+            torch.distributed.all_reduce(out, group=self.pg)
+        return out
 
     def time_field_bwd(self, iters=50):
         """Average duration (ms) of the dominant call -- the fused field backward on the live buffers of the last step
@@ -313,13 +408,27 @@ class FusedCategoryTrainer:
         return e0.elapsed_time(e1) / iters
 
     def _reshuffle(self):
-        """New permutation, cursor back to 0 (scene_cateogries.py:439-449); all on the device, no host sync."""
-        for c in range(self.C):
-            self.perm[c].copy_(torch.randperm(self.pool_rows, device=self.device))
+        """New permutation, cursor back to this rank's first row (scene_cateogries.py:439-449), and the epoch's tables:
+        per GLOBAL slice of world * R rows the max depth (cnr_slice_maxdepth) and the mask counts + any-class-empty flags
+        (cnr_slice_maskcounts), each entry repeated for the ray ranks that share the slice (the kernels index by their own
+        cursor / R).  All on the device; the only communication is, with class shards, one all-reduce (MAX) of the
+        (slices, 3) empty flags per epoch."""
+        for cg in range(self.n_cls_global):        # every rank draws every class's permutation: same epoch everywhere
+            p = torch.randperm(self.pool_rows, device=self.device, generator=self._perm_gen)
+            if cg in self.class_ids:
+                self.perm[self.class_ids.index(cg)].copy_(p)
         self.cursor = 0
-        self.d_state2[self.parity, 0:1].copy_(self._zero64)
-        _C.call("cnr_slice_maxdepth", self.pool["depth"], self.perm, self.pool_rows, self.C, self.R, self.n_slices,
-                self.slice_max)
+        self.d_state2[self.parity, 0:1].copy_(self._cursor0)
+        C, ng, w = self.C, self.n_gslices, self.ray_world
+        smax = torch.empty(C, ng, device=self.device)
+        _C.call("cnr_slice_maxdepth", self.pool["depth"], self.perm, self.pool_rows, C, self.Rg, ng, smax)
+        tab = torch.empty(ng, C + 1, 4, device=self.device)
+        _C.call("cnr_slice_maskcounts", self.pool["rgbs"], self.pool["depth"], self.perm, self.pool_rows, C, self.Rg, ng,
+                float(self.cfg.min_depth), tab)
+        if self.shard == "class" and self.pg is not None and self.world > 1:
+            parallel.allreduce_any_(tab[:, C, :3], self.pg)
+        self.slice_max.copy_(smax.repeat_interleave(w, dim=1))
+        self.counts_tab.copy_(tab.repeat_interleave(w, dim=0))
 
     # ---- reference-named export ------------------------------------------------------------------------
     def state_dicts(self, c=0):
@@ -334,3 +443,23 @@ class FusedCategoryTrainer:
         return dict(FC_state_dict=fc, PE_state_dict={"B_layer.weight": v["B"][c].clone(), "scale": torch.tensor(self.scale)},
                     shape_code_state_dict={"weight": v["shape"][c].clone()},
                     texture_code_state_dict={"weight": v["tex"][c].clone()}, obj_scale=self.scale)
+
+    def load_state_dicts(self, d, c=0):
+        """Inverse of :meth:`state_dicts` for local class ``c``: a checkpoint dict in the reference's key schema
+        (src/scene_cateogries.py:548-571: FC_state_dict, PE_state_dict, shape_code_state_dict, texture_code_state_dict)
+        goes into BOTH parameter copies; optimiser moments are reset (the reference does not save them)."""
+        fc = d["FC_state_dict"]
+        for th in (self.theta2[0], self.theta2[1]):
+            v = self.lay.views(th)
+            off = 0
+            for n, o, i in TRUNK_LAYERS:
+                v["trunk"][c, off:off + o * i].copy_(fc[n + ".weight"].reshape(-1)); off += o * i
+                v["trunk"][c, off:off + o].copy_(fc[n + ".bias"]); off += o
+            for k, n in enumerate(LATENT_LAYERS):
+                v["latW"][c, k].copy_(fc[n + ".weight"])
+                v["latb"][c, k].copy_(fc[n + ".bias"])
+            v["B"][c].copy_(d["PE_state_dict"]["B_layer.weight"])
+            v["shape"][c].copy_(d["shape_code_state_dict"]["weight"])
+            v["tex"][c].copy_(d["texture_code_state_dict"]["weight"])
+        self.exp_avg[c].zero_()
+        self.exp_avg_sq[c].zero_()

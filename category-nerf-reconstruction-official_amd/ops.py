@@ -270,7 +270,8 @@ def sample_rays(rgbs, depth, dirs_c, T, n1, n2, eps, stop_eps, min_bound=0.0, wo
 
 
 def step_prologue(theta, lay, L, n_obj, packed, zl, brows, zero_buf, rgbs, depth, dirs_c, T, n1, n2, eps, stop_eps,
-                  min_bound, seed, d_state, rays, out, max_bound, pool_indices, perm, max_bound_slices=0):
+                  min_bound, seed, d_state, rays, out, max_bound, pool_indices, perm, max_bound_slices=0,
+                  rng=(0, 0, 0, 0)):
     """cnr_step_prologue: the parameter-only jobs (pack | latent rows | gradient zero fill) and the sampler of one
     fused-trainer step in ONE launch.  Same outputs dict as :func:`sample_rays` (device pools, device cursor).
     max_bound: (C,) max depth of this step's slice, or with max_bound_slices = k > 1 a (C, k) table over the epoch's
@@ -289,7 +290,7 @@ def step_prologue(theta, lay, L, n_obj, packed, zl, brows, zero_buf, rgbs, depth
             L, n_obj, C, packed, zl, brows, zero_buf, zero_buf.numel(),
             rgbs, depth, dirs_c, T, None, None, int(seed), 0, d_state, depth.shape[1], max_bound, 0, R, n1, n2,
             float(eps), float(stop_eps), float(min_bound), z, pts, None, None, gt, gd, dm, lab, pool_indices, rr, perm,
-            int(max_bound_slices))
+            int(max_bound_slices), int(rng[0]), int(rng[1]), int(rng[2]), int(rng[3]))
     return out
 
 
@@ -370,7 +371,7 @@ FIELD_BWD_VARIANT = os.environ.get("CNR_FIELD_BWD", "pipe4")
 
 def field_bwd(pts, B, packed, biasrows, ray_row, scale, d_sig, d_rgb, grad_scale, dtrunk, dB, dbiasrows, C, R, S,
               rows_per_class, max_blocks, workspace, variant=None, B_stride=0, dtrunk_stride=0, dB_stride=0,
-              rows_fix=None, skip_reduce=False):
+              rows_fix=None, skip_reduce=False, clamp_flags=None):
     """strides (floats, 0 = dense): B / dtrunk / dB may be views into a flat (C, P) buffer, see cnr_hip.h"""
     v = variant or FIELD_BWD_VARIANT
     if v == "split":
@@ -380,7 +381,7 @@ def field_bwd(pts, B, packed, biasrows, ray_row, scale, d_sig, d_rgb, grad_scale
     elif v in ("pipe2", "pipe3", "pipe4"):
         _C.call("cnr_field_bwd_pipe", pts, B, packed, biasrows, ray_row, scale, d_sig, d_rgb, grad_scale, dtrunk,
                 dB, dbiasrows, C, R, S, rows_per_class, max_blocks, int(v[-1]), workspace, workspace.numel(), int(B_stride),
-                int(dtrunk_stride), int(dB_stride), rows_fix, int(bool(skip_reduce)))
+                int(dtrunk_stride), int(dB_stride), rows_fix, int(bool(skip_reduce)), clamp_flags)
     else:
         raise ValueError(f"unknown cnr_field_bwd variant {v!r}")
 

@@ -58,6 +58,29 @@ def allreduce_mean_(flat_grad, group, prescaled=True):
     return flat_grad
 
 
+def allreduce_sum_(flat_grad, group):
+    """ONE collective on the flat gradient of all classes: with ray shards every rank's gradient already carries
+    1 / (global mask count), so the sum over ranks IS the gradient of the whole batch."""
+    if group is not None:
+        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
+    return flat_grad
+
+
+def allreduce_any_(flags, group):
+    """Logical OR over ranks of a 0/1 float table (the per-slice any-class-empty flags of render_rays.py:67-72 when
+    classes live on different GPUs): once per epoch, a few hundred bytes."""
+    if group is not None:
+        t = flags.contiguous()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        flags.copy_(t)
+    return flags
+
+
+def class_shard(n_cls_global, rank, world):
+    """Classes rank ``rank`` owns: ``rank, rank + world, ...`` (classes share nothing: no gradient ever crosses ranks)."""
+    return list(range(rank, n_cls_global, world))
+
+
 def params_in_sync(flat_params, group, atol=0.0):
     """Debug check: every rank holds the same parameters (max |p - p_rank0| <= atol)."""
     if group is None:
@@ -67,3 +90,21 @@ def params_in_sync(flat_params, group, atol=0.0):
     bad = torch.tensor([float((flat_params - ref).abs().max() > atol)], device=flat_params.device)
     dist.all_reduce(bad, group=group)
     return bool(bad.item() == 0)
+
+
+def mask_count_table(labels, depth_mask):
+    """Host mirror of one entry of cnr_slice_maskcounts, for tables built outside the trainer and for CPU tests:
+    labels (C,R) uint8, depth_mask (C,R) bool -> (C + 1, 4) floats: rows c = {#(depth & label != 0), #(label != 0),
+    #(label != 2), 0}, row C = {1 where any class has a zero count, ..., ..., 0} (src/render_rays.py:66-72)."""
+    mo, ms = labels != 0, labels != 2
+    cnt = torch.stack([(depth_mask.bool() & mo).sum(-1), mo.sum(-1), ms.sum(-1), torch.zeros_like(mo.sum(-1))], -1).float()
+    empty = torch.cat([(cnt[:, :3] == 0).any(0).float(), torch.zeros(1)])
+    return torch.cat([cnt, empty[None]], 0)
+
+
+def combine_ray_shard_tables(tables):
+    """Per-rank tables of the ray shards of ONE global slice -> the table every rank must use: counts summed, empty flags
+    recomputed from the sums (a rank-local count of zero means nothing)."""
+    cnt = torch.stack([t[:-1] for t in tables]).sum(0)
+    empty = torch.cat([(cnt[:, :3] == 0).any(0).float(), torch.zeros(1)])
+    return torch.cat([cnt, empty[None]], 0)

@@ -124,7 +124,8 @@ int cnr_composite_bwd(const float* alpha, const float* color, const float* z,
  * inputs (C,R): depth, var, opacity, gt_depth ; rgb, gt_rgb (C,R,3) ; labels, depth_mask (C,R) u8.
  * outputs: losses (3,C) [depth,color,opacity]; flags (C,) i32: bit0 = "loss explode" (> 1e5,
  *   render_rays.py:87-89 -- reported, never exit()), bits1-3 = the depth / colour / opacity term was
- *   zeroed because some class has an empty mask; d_depth/d_opacity (C,R), d_rgb (C,R,3) = dLoss/d(render),
+ *   zeroed because some class has an empty mask, bit4 (fused trainer only) = the field backward clipped a scaled
+ *   gradient (cnr_step_tail); d_depth/d_opacity (C,R), d_rgb (C,R,3) = dLoss/d(render),
  *   already multiplied by color_scaling / opacity_scaling and by `grad_scale`. */
 int cnr_loss_fwd_bwd(const float* depth, const float* var, const float* rgb, const float* opacity,
                      const float* gt_depth, const float* gt_rgb, const uint8_t* labels,
@@ -248,7 +249,19 @@ int cnr_field_fwd_render(const float* pts, const float* B, const void* packed, c
                          const uint8_t* labels, const uint8_t* depth_mask, float color_scaling, float opacity_scaling,
                          float grad_scale, float* d_sigmas, float* d_colors, float* depth, float* var, float* rgb,
                          float* opacity, int C, int R, int S, int64_t B_stride, void* workspace,
-                         int64_t workspace_bytes, const void* packed_lo, void* stream);
+                         int64_t workspace_bytes, const void* packed_lo, const float* counts_tab,
+                         const int64_t* d_state, void* stream);
+
+/* Mask counts of every slice of an epoch in one launch (the per-step counts of src/render_rays.py:66-95 depend on the pool
+ * rows only: label = pool state, depth mask = depth > min_bound): out (slices, C + 1, 4) floats,
+ *   out[s][c] = {#(valid depth & label != 0), #(label != 0), #(label != 2), 0} over rows perm[c][s R .. s R + R) of class c,
+ *   out[s][C] = {1 if ANY class has a zero depth / colour / opacity count in slice s, ..., ..., 0}   (render_rays.py:67-72).
+ * cnr_field_fwd_render / cnr_render_loss take such a table as `counts_tab` (NULL: they count the step's labels
+ * themselves) and read entry d_state[0] / R (d_state NULL: entry 0).  The host may combine tables between GPUs before
+ * use -- sum the counts of ray shards of one class, or the flags of class shards -- which is how N ranks x R rays equal
+ * one rank x N R rays, and how the empty-mask rule spans ranks, with no collective inside the step. */
+int cnr_slice_maskcounts(const uint8_t* rgbs, const float* depth, const int* perm, int64_t pool_rows, int C, int R,
+                         int slices, float min_bound, float* out, void* stream);
 
 /* Max depth of every slice of an epoch in one launch: out[c][s] = max over r < R of depth[c][perm[c][s R + r]]
  * (perm NULL: identity), s < slices, slices * R <= pool_rows.  cnr_step_prologue takes such a table as max_bound when
@@ -268,7 +281,12 @@ int cnr_step_prologue(const float* theta, int64_t class_stride, int64_t off_trun
                       const float* max_bound, int world_frame, int R, int n1, int n2, float eps, float stop_eps,
                       float min_bound, float* z, float* pts, float* origins, float* dirs_o, float* gt_rgb,
                       float* gt_depth, uint8_t* depth_mask, uint8_t* labels, const int64_t* pool_indices,
-                      int* ray_row, const int* perm, int max_bound_slices, void* stream);
+                      int* ray_row, const int* perm, int max_bound_slices, int rng_c0, int rng_cstride, int rng_R,
+                      int rng_r0, void* stream);
+/* rng_*: the Philox counter of ray r of local class c is ((c * rng_cstride + rng_c0) * rng_R + rng_r0 + r) * 64 + lane,
+ * i.e. the ray's index in the GLOBAL batch when classes (rng_c0 = rank, rng_cstride = ranks) or rays (rng_R = global rays
+ * per class, rng_r0 = rank * R) are sharded over GPUs: N ranks then draw exactly the samples one rank would.  All zero:
+ * the local index c * R + r. */
 
 /* a11-a15 fused for the render + loss step of the fused trainer: cnr_composite_fwd -> cnr_loss_fwd_bwd ->
  * cnr_composite_bwd in ONE kernel (src/render_rays.py:3-7,25-33,46-95; src/loss.py:18-74).  Possible because the
@@ -287,7 +305,7 @@ int cnr_render_loss(const float* sigmas, const float* colors, const float* z, co
                     const float* gt_rgb, const uint8_t* labels, const uint8_t* depth_mask, float color_scaling,
                     float opacity_scaling, float grad_scale, float* d_sigmas, float* d_colors, float* depth,
                     float* var, float* rgb, float* opacity, int C, int R, int S, void* workspace,
-                    int64_t workspace_bytes, void* stream);
+                    int64_t workspace_bytes, const float* counts_tab, const int64_t* d_state, void* stream);
 int cnr_render_loss_finish(const void* workspace, float* losses, int32_t* flags, int C, int R, int rl_blocks,
                            void* stream);   /* rl_blocks: partials per class, 0 = cnr_render_loss's own count */
 /* Last node of the fused trainer's captured step, one launch: cnr_render_loss_finish, then (next_max_bound !=
@@ -330,7 +348,10 @@ int cnr_step_tail(const float* theta_in, float* theta_out, float* grad, float* e
                   const int64_t* state_cur, int64_t* state_next, int64_t add_rows, const void* rl_workspace,
                   float* losses, int32_t* flags, const float* depth, int64_t pool_rows, const int* perm,
                   float* next_max_bound, int R, const void* records, int nwg, const long long* rows_fix,
-                  int rl_blocks, void* stream);
+                  int rl_blocks, int* clamp_flags, void* stream);
+/* clamp_flags (optional, (C,) int32, zero before the first step): what cnr_field_bwd_pipe raised during this step -- bit 4
+ * (16) = a scaled upstream gradient |d sigma| * grad_scale exceeded 8192 and was clipped for the f16 chain; the epilogue
+ * or-s the word into flags[c] and clears it. */
 
 /* The gradient half of cnr_step_tail on its own (records reduction + latent backward + code regulariser in one launch,
  * no optimiser, no epilogue): for hosts that need the finished gradient first, e.g. to all-reduce it across GPUs.
@@ -360,7 +381,7 @@ int cnr_field_bwd_pipe(const float* pts, const float* B, const void* packed, con
                        int rows_per_class, int max_blocks, int chain_waves, void* workspace,
                        int64_t workspace_bytes, int64_t B_stride,
                        int64_t dtrunk_stride, int64_t dB_stride, long long* rows_fix, int skip_reduce,
-                       void* stream);
+                       int* clamp_flags, void* stream);
 
 #ifdef __cplusplus
 }

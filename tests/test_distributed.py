@@ -1,6 +1,12 @@
-"""CPU, world_size 2, gloo: the N > 1 path -- rank-private ray shards, ONE all-reduce of the flat gradient, identical
-AdamW on every rank (parameters stay bitwise equal).  Gradients come from the oracle here (no GPU); on the GPU box the
-same parallel.allreduce_mean_ call sits in FusedCategoryTrainer._step_body over RCCL."""
+"""CPU, world_size 2, gloo: the N > 1 paths of SURVEY.md section 8(e) against a SINGLE-rank oracle step on the whole batch.
+
+No GPU here, so the arithmetic of a rank is the oracle's (torch fp32) with the one thing the sharded kernels do
+differently restated in this file: the masked means take their normalisers and the any-class-empty flags from a TABLE
+(cnr_slice_maskcounts / parallel.mask_count_table) instead of counting the rank's own labels.  What is exercised for real
+is the host logic of category-nerf-reconstruction-official_amd/parallel.py over a gloo process group: class ownership,
+the per-epoch OR of the empty flags, the combination of ray-shard tables, the ONE all-reduce of the flat gradient, and that
+every rank applies the identical AdamW step.  (On the GPU box tests/test_multigpu_gpu.py runs the same comparisons
+through the HIP kernels, in one process and in two.)"""
 import os
 import socket
 import sys
@@ -17,59 +23,161 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, out):
+def _table_loss(O, mlp, B, shape, tex, batch, table, reg_scale):
+    """oracle.forward_loss with src/render_rays.py:66-95 reading counts / empty flags from `table` ((C+1,4), see
+    parallel.mask_count_table) -- the semantics of cnr_field_fwd_render / cnr_render_loss with counts_tab."""
+    C = batch["pts"].shape[0]
+    cs = torch.stack([shape[c][batch["indices"][c]][:, None, :] for c in range(C)])
+    ct = torch.stack([tex[c][batch["indices"][c]][:, None, :] for c in range(C)])
+    e = O.unidirs_embed(batch["pts"], B, 2.0)
+    sig, col = O.codenerf_forward(mlp, e, cs, ct)
+    _, _, depth, var, rgb, opa = O.composite(sig.squeeze(-1), col, batch["z"])
+    mo, ms = batch["labels"] != 0, batch["labels"] != 2
+    md = batch["depth_mask"] & mo
+    cnt, empty = table[:C], table[C]
+    red = lambda l, k: torch.zeros(C) if empty[k] != 0 else l.sum(-1) / (cnt[:, k] + 1e-10)
+    ld = red((depth - batch["gt_depth"]).abs() * md / (torch.sqrt(var) + 1e-4), 0)
+    lc = red((rgb - batch["gt_rgb"]).abs().sum(-1) * mo, 1)
+    lo = red((opa - mo.float()).abs() * ms, 2)
+    reg = sum(torch.norm(s, dim=-1).sum() + torch.norm(t, dim=-1).sum() for s, t in zip(shape, tex) if s.shape[0] > 1)
+    return (ld + 5.0 * lc + 10.0 * lo).sum() + reg_scale * reg, torch.stack([ld, lc, lo])
+
+
+def _setup(cnr, O, C, R, n_obj, L, empty_class=None):
+    """parameters + one sampled batch (C,R,...) from seeded pools -- identical on every rank and in the parent"""
+    theta, lay = cnr.fused.init_params(C, L, n_obj, torch.Generator().manual_seed(0))
+    n1, n2 = 2, 14
+    bs = []
+    for c in range(C):
+        pool = cnr.scene_cateogries.synthetic_pool(R, n_obj, torch.Generator().manual_seed(9 + c), "cpu")
+        if c == empty_class:
+            pool["rgbs"][:, 3] = 0                       # no ray of this class sees its object: colour / depth masks empty
+        gen = torch.Generator().manual_seed(5 + c)
+        o_, d_ = O.origin_dirs_O(pool["T_co"], pool["dirs"])
+        u, g = torch.rand(R, n1 + n2, generator=gen), torch.randn(R, n2, generator=gen) * (0.1 / 3)
+        gt_rgb, gt_d, mask, lab, pts, z = O.sample_3d_points(pool["rgbs"], pool["depth"], o_, d_, u, g, n1, n2, 0.1, 0.05)
+        bs.append(dict(pts=pts, z=z, gt_depth=gt_d, gt_rgb=gt_rgb / 255.0, labels=lab, depth_mask=mask, indices=pool["indices"]))
+    batch = {k: torch.stack([b[k] for b in bs]) for k in bs[0]}
+    return theta, lay, batch
+
+
+def _params(cnr, lay, th):
+    vv = lay.views(th)
+    C = th.shape[0]
+    mlp, off = {}, 0
+    for n, o, i in cnr.ops.TRUNK_LAYERS:
+        mlp[n + ".weight"] = vv["trunk"][:, off:off + o * i].reshape(C, o, i); off += o * i
+        mlp[n + ".bias"] = vv["trunk"][:, off:off + o]; off += o
+    for k, n in enumerate(cnr.ops.LATENT_LAYERS):
+        mlp[n + ".weight"], mlp[n + ".bias"] = vv["latW"][:, k], vv["latb"][:, k]
+    return mlp, vv["B"], [vv["shape"][c] for c in range(C)], [vv["tex"][c] for c in range(C)]
+
+
+def _adamw(theta, grad):
+    p = theta.clone().requires_grad_()
+    p.grad = grad.clone()
+    torch.optim.AdamW([p], lr=1e-3, weight_decay=0.013).step()
+    return p.detach()
+
+
+def _single_rank_reference(cnr, O, theta, lay, batch):
+    th = theta.clone().requires_grad_()
+    mlp, B, sh, tx = _params(cnr, lay, th)
+    loss, aux = O.forward_loss(mlp, B, 2.0, sh, tx, batch)
+    loss.backward()
+    return th.grad.clone(), torch.stack([aux["loss_depth"], aux["loss_color"], aux["loss_opacity"]]).detach()
+
+
+def _worker(rank, world, port, out, mode, empty_class):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     import cnr_amd as cnr
     from oracle import ref_cpu as O
     torch.set_num_threads(2)
-    r, lr, w, pg = cnr.parallel.init_from_env(backend="gloo")
+    par = cnr.parallel
+    r, lr, w, pg = par.init_from_env(backend="gloo")
     assert (r, w) == (rank, world) and pg is not None
-    R, n1, n2, L, n_obj = 32, 2, 14, 32, 4
-    theta, lay = cnr.fused.init_params(1, L, n_obj, torch.Generator().manual_seed(0))      # same weights everywhere
-    full = cnr.scene_cateogries.synthetic_pool(2 * 64, n_obj, torch.Generator().manual_seed(9), "cpu")
-    pool = cnr.parallel.shard_pool(full, rank, world)                                        # rank-private rays
-    m, v2 = torch.zeros_like(theta), torch.zeros_like(theta)
-    for step in range(1, 3):
-        th = theta.clone().requires_grad_()
-        vv = lay.views(th)
-        mlp, off = {}, 0
-        for n, o, i in cnr.ops.TRUNK_LAYERS:
-            mlp[n + ".weight"] = vv["trunk"][:, off:off + o * i].reshape(1, o, i); off += o * i
-            mlp[n + ".bias"] = vv["trunk"][:, off:off + o]; off += o
-        for k, n in enumerate(cnr.ops.LATENT_LAYERS):
-            mlp[n + ".weight"], mlp[n + ".bias"] = vv["latW"][:, k], vv["latb"][:, k]
-        gen = torch.Generator().manual_seed(5 + step)
-        o_, d_ = O.origin_dirs_O(pool["T_co"][:R], pool["dirs"][:R])
-        u, g = torch.rand(R, n1 + n2, generator=gen), torch.randn(R, n2, generator=gen) * (0.1 / 3)
-        gt_rgb, gt_d, mask, lab, pts, z = O.sample_3d_points(pool["rgbs"][:R], pool["depth"][:R], o_, d_, u, g, n1, n2, 0.1, 0.05)
-        batch = dict(pts=pts[None], z=z[None], gt_depth=gt_d[None], gt_rgb=(gt_rgb / 255.0)[None], labels=lab[None],
-                     depth_mask=mask[None], indices=pool["indices"][:R][None])
-        loss, _ = O.forward_loss(mlp, vv["B"], 2.0, [vv["shape"][0]], [vv["tex"][0]], batch)
-        (loss / world).backward()                      # the fused trainer folds 1/world into the loss kernel
-        grad = th.grad.clone()
-        local = grad.clone()
-        cnr.parallel.allreduce_mean_(grad, pg, prescaled=True)        # ONE collective on the flat buffer
+    C, R, n_obj, L = 4, 48, 3, 32
+    theta, lay, batch = _setup(cnr, O, C, R, n_obj, L, empty_class)
+    if mode == "class":
+        mine = par.class_shard(C, rank, world)                                   # rank, rank + world, ...
+        assert mine == list(range(rank, C, world))
+        lb = {k: v[mine] for k, v in batch.items()}
+        table = par.mask_count_table(lb["labels"], lb["depth_mask"])             # local classes only ...
+        par.allreduce_any_(table[len(mine), :3], pg)                             # ... the empty flags span the ranks
+        th = theta[mine].clone().requires_grad_()
+        mlp, B, sh, tx = _params(cnr, lay, th)
+        loss, terms = _table_loss(O, mlp, B, sh, tx, lb, table, 0.0005)
+        loss.backward()
+        new = _adamw(theta[mine], th.grad)                                       # NO gradient collective
+        torch.save(dict(ids=mine, grad=th.grad, theta=new, terms=terms.detach()), out + f".{rank}")
+    else:
+        lo, hi = par.shard_rows(R, rank, world)
+        lb = {k: v[:, lo:hi].contiguous() for k, v in batch.items()}
+        # every rank holds the whole pool, so it knows the global slice's table without talking to anyone; the per-rank
+        # tables are combined here as well to check that both ways give the same numbers
+        table = par.mask_count_table(batch["labels"], batch["depth_mask"])
+        local = par.mask_count_table(lb["labels"], lb["depth_mask"])
         gathered = [torch.zeros_like(local) for _ in range(world)]
         dist.all_gather(gathered, local, group=pg)
-        assert torch.allclose(grad, sum(gathered), atol=1e-7)
-        # identical AdamW on every rank
-        p = theta.clone().requires_grad_(); p.grad = grad
-        opt = torch.optim.AdamW([p], lr=1e-3, weight_decay=0.013)
-        if step > 1:
-            opt.state[p] = dict(step=torch.tensor(float(step - 1)), exp_avg=m, exp_avg_sq=v2)
-        opt.step()
-        m, v2 = opt.state[p]["exp_avg"], opt.state[p]["exp_avg_sq"]
-        theta = p.detach()
-        assert cnr.parallel.params_in_sync(theta, pg, atol=0.0)
-    if rank == 0:
-        torch.save(dict(theta=theta, loss=float(loss)), out)
+        assert torch.equal(par.combine_ray_shard_tables(gathered), table)
+        th = theta.clone().requires_grad_()
+        mlp, B, sh, tx = _params(cnr, lay, th)
+        loss, terms = _table_loss(O, mlp, B, sh, tx, lb, table, 0.0005 / world)
+        loss.backward()
+        grad = th.grad.clone()
+        par.allreduce_sum_(grad, pg)                                             # ONE collective on the flat buffer
+        terms = terms.detach().clone()
+        dist.all_reduce(terms, group=pg)
+        new = _adamw(theta, grad)
+        assert par.params_in_sync(new, pg, atol=0.0)                             # replicas stay bitwise identical
+        if rank == 0:
+            torch.save(dict(grad=grad, theta=new, terms=terms), out + ".0")
     dist.destroy_process_group()
 
 
-def test_two_rank_flat_allreduce_keeps_replicas_identical(tmp_path):
-    out = str(tmp_path / "r0.pt")
-    port = _free_port()
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
-    res = torch.load(out)
-    assert torch.isfinite(res["theta"]).all() and res["loss"] > 0
+@pytest.mark.parametrize("mode,empty_class", [("class", None), ("class", 3), ("ray", None), ("ray", 1)])
+def test_two_ranks_equal_one_rank_on_the_whole_batch(tmp_path, mode, empty_class):
+    out = str(tmp_path / "res")
+    mp.spawn(_worker, args=(2, _free_port(), out, mode, empty_class), nprocs=2, join=True)
+    sys.path.insert(0, ROOT)
+    import cnr_amd as cnr
+    from oracle import ref_cpu as O
+    C, R, n_obj, L = 4, 48, 3, 32
+    theta, lay, batch = _setup(cnr, O, C, R, n_obj, L, empty_class)
+    g_ref, terms_ref = _single_rank_reference(cnr, O, theta, lay, batch)
+    th_ref = _adamw(theta, g_ref)
+    if empty_class is not None:      # render_rays.py:67-72: depth and colour terms vanish for EVERY class
+        assert float(terms_ref[0].abs().sum()) == 0.0 and float(terms_ref[1].abs().sum()) == 0.0 and float(terms_ref[2].sum()) > 0
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    if mode == "class":
+        for rank in range(2):
+            res = torch.load(out + f".{rank}")
+            ids = res["ids"]
+            assert rel(res["grad"], g_ref[ids]) < 1e-5 and rel(res["theta"], th_ref[ids]) < 1e-6
+            assert torch.allclose(res["terms"], terms_ref[:, ids], rtol=1e-5, atol=1e-7)
+    else:
+        res = torch.load(out + ".0")
+        assert rel(res["grad"], g_ref) < 1e-5 and rel(res["theta"], th_ref) < 1e-6
+        assert torch.allclose(res["terms"], terms_ref, rtol=1e-5, atol=1e-7)
+
+
+def test_local_counts_are_not_the_global_batch():
+    """What the tables are for: normalising each ray shard by its OWN mask counts (the usual data-parallel convention)
+    does not give the gradient of the whole batch."""
+    sys.path.insert(0, ROOT)
+    import cnr_amd as cnr
+    from oracle import ref_cpu as O
+    C, R, n_obj, L = 2, 48, 3, 32
+    theta, lay, batch = _setup(cnr, O, C, R, n_obj, L)
+    g_ref, _ = _single_rank_reference(cnr, O, theta, lay, batch)
+    g = torch.zeros_like(theta)
+    for rank in range(2):
+        lo, hi = cnr.parallel.shard_rows(R, rank, 2)
+        lb = {k: v[:, lo:hi].contiguous() for k, v in batch.items()}
+        th = theta.clone().requires_grad_()
+        mlp, B, sh, tx = _params(cnr, lay, th)
+        loss, _ = _table_loss(O, mlp, B, sh, tx, lb, cnr.parallel.mask_count_table(lb["labels"], lb["depth_mask"]), 0.0005)
+        (loss / 2).backward()
+        g += th.grad
+    assert float((g - g_ref).norm() / g_ref.norm()) > 1e-3

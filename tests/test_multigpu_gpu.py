@@ -1,0 +1,120 @@
+"""GPU: the sharded train step through the HIP kernels against a single-GPU step on the whole batch.
+
+* in one process: N trainer objects play the ranks of a ray-sharded / class-sharded world (the gradient sum and the OR
+  of the empty flags done by hand), compared step by step with ONE trainer on the whole batch: identical samples
+  (Philox indexed by the global ray), gradients to fp32 summation order, parameters after AdamW;
+* in two processes over a gloo group (both on this box's one GPU; on a node the launcher gives each rank its own GPU and
+  the backend is RCCL): the product path, hipGraph replay and epoch reshuffles included, against the single-process run.
+"""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from conftest import ROOT, rel_l2
+from mp_fused_worker import build
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cnr(dev):
+    import cnr_amd
+    return cnr_amd
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_ray_shards_add_up_to_the_single_gpu_step(cnr, dev, world):
+    C, Rg, n_obj, L = 2, 512, 4, 32
+    one = build(cnr, dev, "ray", 0, 1, None, C, Rg, n_obj, L, False)
+    ranks = [build(cnr, dev, "ray", r, world, None, C, Rg, n_obj, L, False) for r in range(world)]
+    R = Rg // world
+    for r, tr in enumerate(ranks):
+        assert tr.grad_exchange and not tr.fused_tail and tr.R == R and tr.Rg == Rg
+        assert torch.equal(tr.perm, one.perm) and torch.equal(tr.theta, one.theta)
+    for step in range(7):                                   # pool of six slices: an epoch reshuffle on the way
+        one.step()
+        for tr in ranks:
+            tr._pre_step()
+            tr._step_front()
+        g = sum(tr.grad for tr in ranks)                    # what the all-reduce leaves on every rank
+        for tr in ranks:
+            tr.grad.copy_(g)
+            tr._step_back()
+            tr._post_step()
+        torch.cuda.synchronize()
+        for r, tr in enumerate(ranks):                      # same rays, same samples
+            sl = slice(r * R, (r + 1) * R)
+            for k in ("z", "pts", "gt_rgb", "gt_depth", "labels", "depth_mask", "ray_row"):
+                assert torch.equal(tr.bufs[k], one.bufs[k][:, sl]), (step, r, k)
+        assert rel_l2(g, one.grad) < 2e-5, (step, rel_l2(g, one.grad))
+        assert rel_l2(sum(tr.losses for tr in ranks), one.losses) < 1e-5
+        for tr in ranks:
+            assert torch.equal(tr.theta, ranks[0].theta)    # replicas bitwise identical
+        assert rel_l2(ranks[0].theta, one.theta) < 1e-5, (step, rel_l2(ranks[0].theta, one.theta))
+        assert int(ranks[1].d_state[0]) == int(one.d_state[0]) + R
+
+
+@pytest.mark.parametrize("empty_class", [None, 2])
+def test_class_shards_equal_the_single_gpu_step_bitwise(cnr, dev, empty_class):
+    """Classes share nothing but the any-class-empty rule: rank r trains classes r, r + 2 with NO gradient exchange and
+    ends with the very bits the single-GPU run of all four classes has -- also when one class's masks are empty, which
+    zeroes the depth and colour terms of every class on every rank (src/render_rays.py:67-72)."""
+    C, R, n_obj, L, world = 4, 256, 4, 32, 2
+    one = build(cnr, dev, "class", 0, 1, None, C, R, n_obj, L, False, empty_class)
+    ranks = [build(cnr, dev, "class", r, world, None, C, R, n_obj, L, False, empty_class) for r in range(world)]
+    # the flags' OR over ranks (the trainers have no process group here; with one, _reshuffle does this)
+    flags = torch.stack([tr.counts_tab[:, tr.C, :3] for tr in ranks]).amax(0)
+    for tr in ranks:
+        tr.counts_tab[:, tr.C, :3] = flags
+        assert tr.fused_tail and not tr.grad_exchange
+    assert torch.equal(flags, one.counts_tab[:, C, :3])
+    if empty_class is not None:
+        assert float(flags[:, :2].min()) == 1.0 and float(flags[:, 2].max()) == 0.0
+    for step in range(4):                                   # within the first epoch
+        one.step()
+        for tr in ranks:
+            tr.step()
+    torch.cuda.synchronize()
+    for tr in ranks:
+        ids = tr.class_ids
+        assert torch.equal(tr.theta, one.theta[ids]) and torch.equal(tr.losses, one.losses[:, ids])
+        if empty_class is not None:
+            assert float(tr.losses[:2].abs().sum()) == 0.0 and bool(((tr.flags & 6) == 6).all())
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+@pytest.mark.parametrize("mode,empty", [("ray", None), ("class", None), ("class", 1)])
+def test_two_processes_match_the_single_process_run(cnr, dev, tmp_path, mode, empty):
+    steps, world = 9, 2                                     # six slices per epoch: the reshuffle + its tables are crossed
+    out = str(tmp_path / "res")
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                   WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mp_fused_worker.py"), mode, out,
+                                       str(steps), "-" if empty is None else str(empty)], env=env))
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    one = build(cnr, dev, mode, 0, 1, None, 4, 256, 4, 32, True, empty)
+    hist = []
+    for _ in range(steps):
+        one.step()
+        hist.append(one.losses.cpu().clone())
+    torch.cuda.synchronize()
+    hist = torch.stack(hist)
+    res = [torch.load(f"{out}.{r}") for r in range(world)]
+    if mode == "ray":
+        assert all(r["in_sync"] for r in res)
+        assert torch.equal(res[0]["theta"], res[1]["theta"])
+        assert rel_l2(res[0]["theta"], one.theta) < 1e-4 and rel_l2(res[0]["hist"], hist) < 1e-3
+    else:
+        for r in res:
+            assert torch.equal(r["theta"], one.theta.cpu()[r["ids"]]) and torch.equal(r["hist"], hist[:, :, r["ids"]])
