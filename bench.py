@@ -4,8 +4,10 @@
 One step = sample (a2-a6) -> latent rows (a7) -> PE + CodeNeRF trunk (a8, a9) -> composite (a11-a13) -> loss
 (a14-a16) -> backward of all of it -> AdamW (a18), on synthetic random-pose ray pools resident in HBM
 (SURVEY.md section 8(d)).  N = 1 runs BASELINE.json configs[1] (Replica room_0 shape: 1 category, 2048 rays x 64
-samples, L = 256); N > 1 is launched by torch.distributed.run, every rank runs the same per-GPU workload on its
-own rays of the same category and the flat gradient is all-reduced over RCCL (weak scaling).
+samples, L = 256).  N > 1 is launched by torch.distributed.run, one rank per GPU over RCCL; by default every GPU owns whole
+categories (--shard class: one more category of the same shape per GPU, no gradient collective -- categories share nothing,
+train.py:58-64 -- weak scaling; --scaling strong --classes 16 is BASELINE.json configs[2] on a fixed global batch);
+--shard ray splits the rays of every category instead (one all-reduce of the flat gradient per step).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -23,8 +25,29 @@ FLOP_PER_SAMPLE_STEP = 82140          # 3 x 13 648 MAC +
 PEAK_MFMA_F16_TFLOPS = 2500.0         # MI355X dense bf16/f16 MFMA peak (MI355X_MICROARCH.md, chip-level table)
 
 
+def _cpu_info():
+    """CPU model string, physical cores (sockets x cores per socket) and logical CPUs of this host."""
+    model, phys, sockets, cores = "unknown", None, set(), None
+    try:
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name" and model == "unknown":
+                model = v
+            elif k == "physical id":
+                sockets.add(v)
+            elif k == "cpu cores" and cores is None:
+                cores = int(v)
+        if cores:
+            phys = cores * max(len(sockets), 1)
+    except OSError:
+        pass
+    return model, phys, os.cpu_count()
+
+
 def cpu_baseline(cfg_shape, seconds=12.0):
-    """The oracle's train step (reference op structure, fp32) on the host cores: rays/s on the same shape."""
+    """The oracle's train step (reference op structure, fp32) on the host cores: rays/s on the same shape, with the
+    per-phase split SURVEY.md section 8(d) asks for (sample / PE / MLP forward / loss / backward / optimiser)."""
     from oracle import ref_cpu as O
     C, R, n1, n2, L, n_obj = cfg_shape
     S = n1 + n2
@@ -37,48 +60,67 @@ def cpu_baseline(cfg_shape, seconds=12.0):
     opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=0.013)
     import cnr_amd
     pool = cnr_amd.scene_cateogries.synthetic_pool(4 * R, n_obj, gen, "cpu")
+    PH = ("sample", "pe", "mlp_fwd", "loss", "backward", "optim")
 
-    def step(i):
+    def step(i, ph=None):
+        t = [time.perf_counter()]
+        mark = lambda: t.append(time.perf_counter())
         sl = slice((i % 3) * R, (i % 3) * R + R)
         rgbs, depth, dirs, T, idx = pool["rgbs"][sl], pool["depth"][sl], pool["dirs"][sl], pool["T_co"][sl], pool["indices"][sl]
         o, d = O.origin_dirs_O(T, dirs)
         u = torch.rand(R, S, generator=gen)
         g = torch.randn(R, n2, generator=gen) * (0.1 / 3)
         gt_rgb, gt_depth, mask, labels, pts, z = O.sample_3d_points(rgbs, depth, o, d, u, g, n1, n2, 0.1, 0.05)
-        batch = dict(pts=pts[None].repeat(C, 1, 1, 1), z=z[None].repeat(C, 1, 1), gt_depth=gt_depth[None].repeat(C, 1),
-                     gt_rgb=(gt_rgb / 255.0)[None].repeat(C, 1, 1), labels=labels[None].repeat(C, 1),
-                     depth_mask=mask[None].repeat(C, 1), indices=idx[None].repeat(C, 1))
-        loss, _ = O.forward_loss(mlp, B, 2.0, sh, tx, batch)
+        pts, z = pts[None].repeat(C, 1, 1, 1), z[None].repeat(C, 1, 1)
+        idxc = idx[None].repeat(C, 1)
+        mark()
+        e = O.unidirs_embed(pts, B, 2.0)                                        # materialised (C,R,S,129), as the reference
+        mark()
+        cs = torch.stack([sh[c][idxc[c]][:, None, :] for c in range(C)])        # train.py:136-137
+        ct = torch.stack([tx[c][idxc[c]][:, None, :] for c in range(C)])
+        sig, col = O.codenerf_forward(mlp, e, cs, ct)
+        mark()
+        loss, _, _ = O.step_batch_loss(sig, col, gt_depth[None].repeat(C, 1), (gt_rgb / 255.0)[None].repeat(C, 1, 1),
+                                       labels[None].repeat(C, 1), mask[None].repeat(C, 1), z)
+        rs, rt = O.step_batch_loss_reg(sh, tx)
+        loss = loss + 0.0005 * (rs + rt).sum()
+        mark()
         opt.zero_grad(set_to_none=True)
         loss.backward()
+        mark()
         opt.step()
+        mark()
+        if ph is not None:
+            for k, name in enumerate(PH):
+                ph[name].append(t[k + 1] - t[k])
+        return t[-1] - t[0]
 
     # pick the thread count that is fastest for THIS workload (a 128-thread box is slower with all threads on
-    # these small GEMMs than with 16-32): the baseline is the CPU's best, not its default
+    # these small GEMMs than with 16-32), on the median of three steps each: the baseline is the CPU's best
+    model, phys, logical = _cpu_info()
     best = None
     for nt in sorted({8, 16, 32, 64, torch.get_num_threads()}):
-        if nt > (os.cpu_count() or 1):
+        if nt > (logical or 1):
             continue
         torch.set_num_threads(nt)
         step(0)
-        t0 = time.perf_counter()
-        step(1)
-        dt = time.perf_counter() - t0
-        if best is None or dt < best[0]:
-            best = (dt, nt)
+        ts = sorted(step(1 + k) for k in range(3))
+        if best is None or ts[1] < best[0]:
+            best = (ts[1], nt)
     cores = best[1]
     torch.set_num_threads(cores)
+    ph = {k: [] for k in PH}
     times, t_end, i = [], time.perf_counter() + seconds, 0
     while time.perf_counter() < t_end or len(times) < 3:
-        t0 = time.perf_counter()
-        step(i)
-        times.append(time.perf_counter() - t0)
+        times.append(step(i, ph))
         i += 1
     times.sort()
     med = times[len(times) // 2]
+    phase_ms = {k: round(sorted(v)[len(v) // 2] * 1e3, 2) for k, v in ph.items()}
     return {"value": C * R / med, "unit": "rays/s", "cores": cores, "kind": "port",
+            "cpu_model": model, "physical_cores": phys, "logical_cpus": logical, "phase_ms": phase_ms,
             "sample": f"{len(times)} steps of the same {C}x{R}x{S} (L={L}) train step, median {med * 1e3:.1f} ms, "
-                      f"torch fp32 oracle with {cores} threads"}
+                      f"torch fp32 oracle with {cores} threads (best of 8/16/32/64/default on 3-step medians)"}
 
 
 def main():
@@ -86,13 +128,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--rays", type=int, default=2048)
+    ap.add_argument("--rays", type=int, default=2048, help="rays per class and step (per GPU with --scaling weak)")
     ap.add_argument("--samples", type=int, default=64)
-    ap.add_argument("--classes", type=int, default=1)
+    ap.add_argument("--classes", type=int, default=1, help="classes per GPU (weak) or in total (strong)")
     ap.add_argument("--latent", type=int, default=256)
+    ap.add_argument("--shard", choices=("class", "ray"), default="class",
+                    help="N > 1: 'class' = every GPU owns whole categories, no gradient collective (north_star's "
+                         "per-category sharding); 'ray' = the rays of every category are split, one all-reduce per step")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--bwd-blocks", type=int, default=0)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -118,15 +165,35 @@ def main():
     dbg("process group up")
     import cnr_amd
     info = cnr_amd._C.device_info()
-    C, R, S, L, n_obj = args.classes, args.rays, args.samples, args.latent, 4
+    S, L, n_obj = args.samples, args.latent, 4
     n1, n2 = S // 8, S - S // 8
     cfg = cnr_amd.cfg.synthetic_config(device=str(dev), latent_dim=L, obj_scale=2.0 if L == 256 else 3.0,
                                        n_bins_cam2surface=n1, n_bins=n2)
-    gen = torch.Generator().manual_seed(1234)            # same weights on every rank
-    pgen = torch.Generator().manual_seed(1234 + 17 * (rank + 1))  # rank-private rays
-    pools = [cnr_amd.scene_cateogries.synthetic_pool(64 * R, n_obj, pgen, "cpu") for _ in range(C)]
-    tr = cnr_amd.fused.FusedCategoryTrainer(cfg, C, n_obj, pools, R, dev, seed=rank, generator=gen,
-                                            bwd_blocks=args.bwd_blocks, process_group=pg, use_graph=not args.no_graph)
+    gen = torch.Generator().manual_seed(1234)            # same parameters on every rank
+    # ---- what this rank trains -----------------------------------------------------------------------------------
+    shard = args.shard if world > 1 else None
+    if shard == "class":
+        # whole categories per GPU: classes share nothing (train.py:58-64), so NO gradient collective; the
+        # any-class-empty flags cross ranks once per epoch.  weak: --classes per GPU; strong: --classes in total
+        C_glob = args.classes * world if args.scaling == "weak" else args.classes
+        if C_glob < world:
+            raise SystemExit(f"--scaling strong with --shard class needs --classes >= {world}")
+        ids = cnr_amd.parallel.class_shard(C_glob, rank, world)
+        C, R, Rg = len(ids), args.rays, args.rays
+    else:
+        C_glob = args.classes
+        ids, C = list(range(C_glob)), C_glob
+        Rg = args.rays * world if args.scaling == "weak" else args.rays          # global rays per class and step
+        R = Rg // world
+        if R * world != Rg:
+            raise SystemExit("--rays must divide by the number of GPUs with --shard ray --scaling strong")
+    # pools: one per class, seeded by the GLOBAL class id -> ray shards hold identical copies, class shards their own
+    pools = [cnr_amd.scene_cateogries.synthetic_pool(64 * Rg, n_obj, torch.Generator().manual_seed(1234 + 17 * (c + 1)), "cpu")
+             for c in ids]
+    tr = cnr_amd.fused.FusedCategoryTrainer(cfg, C, n_obj, pools, R, dev, seed=0, generator=gen,
+                                            bwd_blocks=args.bwd_blocks, process_group=pg, use_graph=not args.no_graph,
+                                            shard=shard, n_cls_global=C_glob, class_ids=ids if shard == "class" else None)
+    rays_per_step_global = C_glob * Rg
 
     def sync():
         torch.cuda.synchronize()
@@ -134,31 +201,42 @@ def main():
             torch.distributed.barrier()
             torch.cuda.synchronize()
 
+    def timed(n_steps):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            tr.step()
+        sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
     dbg("trainer built")
     for _ in range(max(args.warmup, 4)):
         tr.step()
     dbg("warmup issued")
-    sync()
-    dbg("warmup done")
-    t0 = time.perf_counter()
-    for i_step in range(args.steps):
-        tr.step()
-        if i_step % 8 == 0:
-            dbg("timed step", i_step)
-    dbg("timed loop issued")
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = timed(args.steps)                      # EXACTLY --steps steps between barriers + synchronize, max over ranks
     dbg("timed region done")
     ms_per_step = dt / args.steps * 1e3
-    rays_per_s = world * C * R * args.steps / dt
+    rays_per_s = rays_per_step_global * args.steps / dt
+    # the same measurement over >= 0.5 s of steps (a 20-step region at 0.08 ms per step is 1.6 ms long): reported beside
+    # it, never instead of it
+    n_long = max(args.steps, int(0.5 / max(dt / args.steps, 1e-6)) + 1)
+    if world > 1:
+        tl = torch.tensor([n_long], device=dev, dtype=torch.int64)
+        torch.distributed.all_reduce(tl, op=torch.distributed.ReduceOp.MAX)
+        n_long = int(tl.item())
+    dt_long = timed(n_long)
+    long_run = {"steps": n_long, "seconds": dt_long, "ms_per_step": dt_long / n_long * 1e3,
+                "value": rays_per_step_global * n_long / dt_long}
 
     # ---- roofline leg: the dominant kernel (fused backward) timed with HIP events on its launch stream ----
     bwd_name = "cnr_field_bwd" if cnr_amd.ops.FIELD_BWD_VARIANT == "split" else "cnr_field_bwd_pipe"
-    names = [bwd_name, "cnr_field_fwd", "cnr_field_fwd_render", "cnr_step_prologue", "cnr_render_loss", "cnr_step_tail"]
+    names = [bwd_name, "cnr_field_fwd", "cnr_field_fwd_render", "cnr_step_prologue", "cnr_render_loss", "cnr_step_tail",
+             "cnr_step_grad"]
     tr.use_graph = False                                           # eager so that events bracket single launches
     cnr_amd._C.enable_kernel_timing(names)
     for _ in range(min(args.steps, 50)):
@@ -179,31 +257,62 @@ def main():
     # HBM bytes of that call from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc passes,
     # gfx950 corrections per MI355X_MICROARCH.md): measured offline on this shape, kept in profiles/
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if dom == bwd_name and (C, R, S) == (1, 2048, 64) and os.path.exists(tpath):
-        traffic = json.load(open(tpath)).get(bwd_name + "_call_hbm_bytes")
+    for tname in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        tpath = os.path.join(ROOT, "profiles", tname)
+        if dom == bwd_name and (C, R, S) == (1, 2048, 64) and os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(bwd_name + "_call_hbm_bytes")
+            break
     roofline = {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_MFMA_F16_TFLOPS, "traffic": traffic,
                 "variant": cnr_amd.ops.FIELD_BWD_VARIANT,
                 "kernel_ms": {k: round(v, 5) for k, v in avg.items()},
                 "kernel_ms_note": "HIP events on the launch stream; %s back to back x50 (one launch at a time in the "
                                   "eager step, gaps included: %.5f), the others one launch at a time" % (bwd_name, eager_bwd_ms),
-                "step_tflops": world * C * R * S * FLOP_PER_SAMPLE_STEP / (dt / args.steps) / 1e12}
+                "step_tflops": rays_per_step_global * S * FLOP_PER_SAMPLE_STEP / (dt / args.steps) / 1e12}
 
+    par = "1 GPU" if world == 1 else (
+        f"{world} GPUs, whole categories per GPU ({C_glob} in total), no gradient collective, empty-mask flags all-reduced once per epoch"
+        if shard == "class" else
+        f"{world} GPUs, rays of every category split ({Rg} per category and step in total), one all-reduce of the flat gradient per step")
     out = {"metric": "rays/sec (train step) Replica room_0, 2048 rays x 64 samples, 1/2/4/8 GPU",
            "value": rays_per_s, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "f16", "data": "synthetic",
-           "config": {"workload": f"Replica room_0 shape: {C} category x {n_obj} objects, {R} rays x {S} samples "
-                                  f"per GPU and step, latent {L}, W=32 CodeNeRF, random-pose synthetic pool, random init",
-                      "rays_per_gpu": C * R, "samples_per_ray": S, "parallelism": f"dp{world}",
-                      "hipgraph": ("one graph per state parity" if world == 1 else "two graphs around the all-reduce, per state parity") if not args.no_graph else False, "n_cu": info["n_cu"]},
-           "roofline": roofline}
-    if world > 1:   # outside the timed region: every rank must hold bitwise identical parameters after the run
+           "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak",
+           "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+           "config": {"workload": f"Replica room_0 shape: {C_glob} categor{'y' if C_glob == 1 else 'ies'} x {n_obj} objects, "
+                                  f"{Rg} rays x {S} samples per category and step, latent {L}, W=32 CodeNeRF, random-pose "
+                                  f"synthetic pool, random init",
+                      "rays_per_step_global": rays_per_step_global, "rays_per_gpu": C * R, "samples_per_ray": S,
+                      "parallelism": par, "shard": shard,
+                      "hipgraph": ("one graph per state parity" if not tr.grad_exchange else "two graphs around the all-reduce, per state parity") if not args.no_graph else False,
+                      "n_cu": info["n_cu"]},
+           "long_run": long_run, "roofline": roofline}
+    if world > 1 and shard == "ray":   # outside the timed region: every rank must hold bitwise identical parameters after the run
         try:
             out["config"]["params_in_sync"] = bool(cnr_amd.parallel.params_in_sync(tr.theta.contiguous(), pg))
         except Exception as e:      # never lose the bench line over the check
             out["config"]["params_in_sync"] = f"check failed: {e}"
+    if world == 1 and not args.no_extra_legs:
+        # the reference's REAL batch shape (configs/Replica/config_replica_room0.json:25-28: 120 rays per object, 1 + 9
+        # samples): S = 10 is not a multiple of 32, so this runs the two-launch forward / render path
+        try:
+            cfg2 = cnr_amd.cfg.synthetic_config(device=str(dev), latent_dim=L, n_bins_cam2surface=1, n_bins=9)
+            R2 = 120 * n_obj
+            pools2 = [cnr_amd.scene_cateogries.synthetic_pool(64 * R2, n_obj, torch.Generator().manual_seed(99), "cpu")]
+            tr2 = cnr_amd.fused.FusedCategoryTrainer(cfg2, 1, n_obj, pools2, R2, dev, seed=1,
+                                                     generator=torch.Generator().manual_seed(5))
+            for _ in range(10):
+                tr2.step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(2000):
+                tr2.step()
+            torch.cuda.synchronize()
+            d2 = time.perf_counter() - t0
+            out["extra_legs"] = {"real_config_480x10": {"workload": "1 category x 4 objects, 120 rays per object x 10 samples "
+                                                                    "(the reference's own batch shape), two-launch forward/render",
+                                                        "steps": 2000, "ms_per_step": d2 / 2000 * 1e3, "rays_per_s": R2 * 2000 / d2}}
+        except Exception as e:
+            out["extra_legs"] = {"real_config_480x10": f"failed: {e}"}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline((C, R, n1, n2, L, n_obj), args.cpu_seconds)
