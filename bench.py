@@ -235,8 +235,8 @@ def main():
 
     # ---- roofline leg: the dominant kernel (fused backward) timed with HIP events on its launch stream ----
     bwd_name = "cnr_field_bwd" if cnr_amd.ops.FIELD_BWD_VARIANT == "split" else "cnr_field_bwd_pipe"
-    names = [bwd_name, "cnr_field_fwd", "cnr_field_fwd_render", "cnr_step_prologue", "cnr_render_loss", "cnr_step_tail",
-             "cnr_step_grad"]
+    names = [bwd_name, "cnr_field_train", "cnr_field_fwd", "cnr_field_fwd_render", "cnr_step_prologue", "cnr_render_loss",
+             "cnr_step_tail", "cnr_step_grad"]
     tr.use_graph = False                                           # eager so that events bracket single launches
     cnr_amd._C.enable_kernel_timing(names)
     for _ in range(min(args.steps, 50)):
@@ -246,12 +246,18 @@ def main():
     avg = {k: (sum(v) / len(v) if v else 0.0) for k, v in tms.items()}
     # the dominant call again, back to back (no host gaps between launches): this is the duration rocprofv3 reports
     # for its kernels (field kernel + reduce_records), and the one the roofline entry uses
-    eager_bwd_ms = avg[bwd_name]
-    avg[bwd_name] = tr.time_field_bwd(50)
+    if tr._ft_blocks:        # the one-launch step body is the dominant call; the two-call form is not on this path
+        bwd_name = "cnr_field_train"
+        eager_bwd_ms = avg[bwd_name]
+        avg[bwd_name] = tr.time_field_train(50)
+    else:
+        eager_bwd_ms = avg[bwd_name]
+        avg[bwd_name] = tr.time_field_bwd(50)
     dom = max((bwd_name, "cnr_field_fwd", "cnr_field_fwd_render"), key=lambda k: avg[k])
     # the backward call = the field kernel(s) (pipe: one launch; split: texture + geometry launches) + reduce_records:
     # its duration is the sum of those (rocprof lists them separately, profiles/).
-    # algorithmic FLOP of that call: fwd = 27 422 / sample, bwd (recompute fwd + dX + dW) = 82 140
+    # algorithmic FLOP of that call: fwd = 27 422 / sample; backward (recomputes the forward) or the one-launch forward +
+    # backward = fwd + dX + dW = 82 140
     flop_per_sample = 82140 if dom == bwd_name else 27422
     achieved = C * R * S * flop_per_sample / (avg[dom] * 1e-3) / 1e12 if avg[dom] > 0 else 0.0
     # HBM bytes of that call from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc passes,

@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcnr_hip.so")
+# (CNR_HIP_LIB: another build of the same library, e.g. tools/exp's cycle-stamp build; never a different implementation)
+LIB_PATH = os.environ.get("CNR_HIP_LIB") or os.path.join(_HERE, "libcnr_hip.so")
 
 _vp, _i, _i64, _u64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_uint64, ctypes.c_float
 
@@ -61,6 +62,10 @@ SIGNATURES = {
     "cnr_field_fwd_render_workspace_bytes": [_i, _i, _i],
     "cnr_field_fwd_render": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp,
                              _vp, _i, _i, _i, _i64, _vp, _i64, _vp, _vp, _vp, _vp],
+    "cnr_field_train_blocks": [_i, _i, _i],
+    "cnr_field_train_workspace_bytes": [_i, _i, _i, _i],
+    "cnr_field_train": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _vp, _vp, _vp, _vp,
+                        _i, _i, _i, _i, _i, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp],
     "cnr_param_prep": [_vp, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp],
     "cnr_render_loss_workspace_bytes": [_i, _i],
     "cnr_render_loss": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp,
@@ -69,7 +74,7 @@ SIGNATURES = {
     "cnr_step_epilogue": [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i, _i, _vp],
 }
 _RESTYPE64 = {"cnr_pack_bytes", "cnr_pack_lo_bytes", "cnr_field_bwd_workspace_bytes", "cnr_render_loss_workspace_bytes",
-              "cnr_dense_bwd_workspace_bytes", "cnr_field_fwd_render_workspace_bytes"}
+              "cnr_dense_bwd_workspace_bytes", "cnr_field_fwd_render_workspace_bytes", "cnr_field_train_workspace_bytes"}
 
 _lib = None
 _double = None

@@ -151,6 +151,56 @@ __device__ __forceinline__ float half_sum_dpp(float v) {
   return __builtin_bit_cast(float, x);
 }
 
+// ---- 32-lane scans on DPP row operations (a __shfl is a ds_bpermute: ~130 dependent cycles each, a 32-lane scan of five of
+// them ~700; these are five VALU instructions).  Each works on both 32-lane halves of the wave independently.
+// inclusive prefix sum over lanes 0..i of the half = half_sum_dpp (lane 31 / 63: the half's total)
+__device__ __forceinline__ float half_scan_add(float v) { return half_sum_dpp(v); }
+// inclusive prefix product
+__device__ __forceinline__ float half_scan_mul(float v) {
+  int x = __builtin_bit_cast(int, v);
+  const int one = 0x3f800000;
+#define CNR_DPP_MUL(CTRL, ROWMASK)                                                                     \
+  x = __builtin_bit_cast(int, __builtin_bit_cast(float, x) *                                           \
+                                  __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(one, x, CTRL, ROWMASK, 0xf, false)))
+  CNR_DPP_MUL(0x111, 0xf);  // row_shr:1 (lanes without a source keep the neutral element)
+  CNR_DPP_MUL(0x112, 0xf);
+  CNR_DPP_MUL(0x114, 0xf);
+  CNR_DPP_MUL(0x118, 0xf);
+  CNR_DPP_MUL(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+#undef CNR_DPP_MUL
+  return __builtin_bit_cast(float, x);
+}
+// value of the lane below (wave_shr:1), lane 0 gets `first`
+__device__ __forceinline__ float lane_below(float v, float first) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, first), __builtin_bit_cast(int, v),
+                                                               0x138, 0xf, 0xf, false));
+}
+// inclusive SUFFIX sum over lanes i..31 of lane half 0 (row_shl inside the rows of 16, then row 1's total -- lane 16 --
+// onto row 0); lane half 1 is not meaningful
+__device__ __forceinline__ float half0_suffix_add(float v, int lane) {
+  int x = __builtin_bit_cast(int, v);
+#define CNR_DPP_ADDL(CTRL)                                                                             \
+  x = __builtin_bit_cast(int, __builtin_bit_cast(float, x) +                                           \
+                                  __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, true)))
+  CNR_DPP_ADDL(0x101);  // row_shl:1
+  CNR_DPP_ADDL(0x102);
+  CNR_DPP_ADDL(0x104);
+  CNR_DPP_ADDL(0x108);
+#undef CNR_DPP_ADDL
+  const float up = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 16));
+  const float r = __builtin_bit_cast(float, x);
+  return (lane & 16) ? r : r + up;
+}
+__device__ __forceinline__ float lane_value(float v, int l) {  // wave-uniform copy of lane l (l a constant)
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+// lanes 32..63 := lanes 0..31 (v_permlane32_swap, gfx950)
+__device__ __forceinline__ float low_half_to_both(float v) {
+  const unsigned x = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+  return __builtin_bit_cast(float, (unsigned)r[0]);
+}
+
 // For every trunk parameter: where its gradient sits in the two-region LDS image of the 16 dW blocks
 // ((kind << 10) | (row << 5) | col), or -1 when it does not come from a block.  Built once per process.
 __device__ int g_param_src[TRUNK];

@@ -22,13 +22,16 @@
 
 namespace {
 #ifdef CNR_PIPE_STAMPS  // tools/exp only: cycle stamps of every wave of workgroup 0 (its last iteration)
-__device__ long long g_pipe8_stamps[8 * 48];
+__device__ long long g_pipe8_stamps[8 * 64];
 #define P8STAMP() do { if (blockIdx.x == 0 && lane == 0) \
-    g_pipe8_stamps[wv * 48 + (pstamp_i++)] = (long long)__builtin_readcyclecounter(); } while (0)
+    g_pipe8_stamps[wv * 64 + (pstamp_i++)] = (long long)__builtin_readcyclecounter(); } while (0)
 #define P8STAMP_RESET() int pstamp_i = 0
 #define P8PHASE(k) do { if (blockIdx.x == 0 && lane == 0) \
-    g_pipe8_stamps[wv * 48 + 40 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
+    g_pipe8_stamps[wv * 64 + 56 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
+#define P8MARK(k) do { if (blockIdx.x == 0 && lane == 0) \
+    g_pipe8_stamps[wv * 64 + 44 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
+#define P8MARK(k) do {} while (0)
 #define P8PHASE(k) do {} while (0)
 #define P8STAMP() do {} while (0)
 #define P8STAMP_RESET() do {} while (0)
@@ -38,9 +41,19 @@ constexpr int C8_BYTES = E1IMG_BYTES + E2IMG_BYTES + 2 * HSIMG_BYTES + 512;  // 
 constexpr int L8_BL = PK_BYTES, L8_BR = L8_BL + 272, L8_CHAIN = L8_BR + cnr_rec::ROWS_MAX * 128 * 4;
 constexpr int RS8_REGION = NBLOCKS;
 constexpr int BK_RS = 100;  // pseudo kind of the row-sum block in the ownership tables
+constexpr int XCH_BYTES = 2 * 4 * 8 * 4;  // one-launch step: four chain waves x eight floats, two copies (iteration parity)
+__host__ __device__ constexpr int l8_xch(int nch) { return L8_CHAIN + nch * C8_BYTES; }
 __host__ __device__ constexpr int l8_total(int nch) {
-  return L8_CHAIN + nch * C8_BYTES > (RS8_REGION + 1) * 4096 ? L8_CHAIN + nch * C8_BYTES : (RS8_REGION + 1) * 4096;
+  return l8_xch(nch) + XCH_BYTES > (RS8_REGION + 1) * 4096 ? l8_xch(nch) + XCH_BYTES : (RS8_REGION + 1) * 4096;
 }
+// KR > 0 (cnr_field_train): the render / loss side of the step, so that ONE launch runs field forward -> composite ->
+// losses -> their gradient -> composite backward -> field backward with no second forward and no d sigma / d colour
+// round trip through HBM.  S = 32 KR: the KR chain waves wv, wv ^ 1, .. of a workgroup iteration hold one ray.
+struct TrainArgs {
+  const float* z; const float* gt_depth; const float* gt_rgb; const uint8_t* labels; const uint8_t* depth_mask;
+  const float* counts_tab; const int64_t* d_state; float color_scaling, opacity_scaling, loss_scale;
+  float* depth_out; float* var_out; float* rgb_out; float* opacity_out; float* partials;
+};
 static_assert(l8_total(4) <= 160 * 1024, "LDS budget");
 
 // Which dW wave owns a block kind, and the block's index among that wave's accumulators: at most 5 accumulators per
@@ -63,13 +76,14 @@ template <> __host__ __device__ constexpr int local8<4>(int kind) {
 
 // WIDE: more than four object rows per class (up to ROWS_MAX): the row stride of the row-sum block is then a run-time
 // value; with <= 4 rows it is the constant 4 and the index arithmetic folds (1 us of the kernel at 2048 x 64).
-template <int NCH, int NDW, bool WIDE>
+template <int NCH, int NDW, bool WIDE, int KR>
 __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
     const float* __restrict__ pts, const float* __restrict__ Bdir, const unsigned char* __restrict__ packed,
     const float* __restrict__ biasrows, const int* __restrict__ ray_row, float inv_scale,
     const float* __restrict__ d_sigma, const float* __restrict__ d_rgb, float gscale, float* __restrict__ records,
     int N, int S, int R, int rows_per_class, int64_t B_stride, long long* __restrict__ rows_fix,
-    int* __restrict__ clamp_flags) {
+    int* __restrict__ clamp_flags, TrainArgs ta) {
+  static_assert(KR == 0 || KR == 1 || KR == 2 || KR == 4, "tiles per ray");
   constexpr int NCHW = NCH, NTHR = (NCH + NDW) * 64, NACC = 5, LI_RS = local8<NDW>(BK_RS);
   // per chain wave: E1 image, E2 image, dPre / input slot, row one-hot table (the flush reuses it for the wave's
   // partial sums)
@@ -135,11 +149,25 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
     const float* Bl_h = reinterpret_cast<const float*>(smem + L8_BL) + 33 * h;
 
     // one lane's inputs of a tile; past the end: a dead tile (all-zero gradients, any valid row)
-    struct TileIn { float px, py, pz, dsg, dr0, dr1, dr2; int row; };
+    struct TileIn { float px, py, pz, dsg, dr0, dr1, dr2; int row; float z, gtd, g0, g1, g2; int lab, dm, live; };
     auto fetch = [&](int tile) {
       const bool tile_ok = tile < ntiles;
       const int tl = tile_ok ? tile : ntiles - 1;
       const int n0 = tl * 32;
+      TileIn t;
+      if constexpr (KR > 0) {
+        // S = 32 KR: tile tl is samples [32 (tl % KR), + 32) of ray tl / KR, never partial
+        const int64_t ray = (int64_t)c * R + tl / KR;
+        const int64_t gs = (int64_t)c * N + n0 + col;
+        const float* pp = pts + gs * 3;
+        t.px = pp[0]; t.py = pp[1]; t.pz = pp[2];
+        t.row = ray_row ? ray_row[ray] : (int)ray;
+        t.z = ta.z[gs]; t.gtd = ta.gt_depth[ray];
+        t.g0 = ta.gt_rgb[ray * 3 + 0]; t.g1 = ta.gt_rgb[ray * 3 + 1]; t.g2 = ta.gt_rgb[ray * 3 + 2];
+        t.lab = ta.labels[ray]; t.dm = ta.depth_mask[ray]; t.live = tile_ok ? 1 : 0;
+        t.dsg = t.dr0 = t.dr1 = t.dr2 = 0.0f;
+        return t;
+      }
       const int ray0 = (int)((unsigned)n0 / (unsigned)S);
       const int kk = n0 - ray0 * S + col;
       const int sl = (kk * slot_inv) >> 16;  // kk / S for kk < S + 32, S <= 240
@@ -149,15 +177,28 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
       const int64_t gs = (int64_t)c * N + nc;
       const float* pp = pts + gs * 3;
       const int64_t ray = (int64_t)c * R + rayc;
-      TileIn t;
       t.px = pp[0]; t.py = pp[1]; t.pz = pp[2];
       t.row = ray_row ? ray_row[ray] : (int)ray;
       t.dsg = live ? d_sigma[gs] : 0.0f;
       t.dr0 = live ? d_rgb[gs * 3 + 0] : 0.0f;
       t.dr1 = live ? d_rgb[gs * 3 + 1] : 0.0f;
       t.dr2 = live ? d_rgb[gs * 3 + 2] : 0.0f;
+      t.z = t.gtd = t.g0 = t.g1 = t.g2 = 0.0f; t.lab = t.dm = 0; t.live = live ? 1 : 0;
       return t;
     };
+    // ---- one-launch step: this class's loss weights from the epoch's mask-count table, loss partial sums ------------
+    float wd_c = 0.f, wc_c = 0.f, wo_c = 0.f, ld_acc = 0.f, lc_acc = 0.f, lo_acc = 0.f;
+    int tab_flags = 0;
+    if constexpr (KR > 0) {
+      const int Cn = gridDim.y;
+      const float* tb = ta.counts_tab + (size_t)(ta.d_state ? ta.d_state[0] / R : 0) * (size_t)(Cn + 1) * 4;
+      const bool e_d = tb[Cn * 4 + 0] != 0.f, e_c = tb[Cn * 4 + 1] != 0.f, e_o = tb[Cn * 4 + 2] != 0.f;
+      wd_c = e_d ? 0.f : 1.0f / (tb[c * 4 + 0] + 1e-10f);
+      wc_c = e_c ? 0.f : 1.0f / (tb[c * 4 + 1] + 1e-10f);
+      wo_c = e_o ? 0.f : 1.0f / (tb[c * 4 + 2] + 1e-10f);
+      tab_flags = (e_d ? 2 : 0) | (e_c ? 4 : 0) | (e_o ? 8 : 0);
+    }
+    float* xch = reinterpret_cast<float*>(smem + l8_xch(NCH));   // [4][8]
     TileIn cur = fetch(blockIdx.x * NCHW + wv), nxt = cur;
     for (int tile = blockIdx.x * NCHW + wv, t0 = blockIdx.x * NCHW; t0 < ntiles; t0 += tile_step, tile += tile_step) {
       asm volatile("" ::: "memory");
@@ -166,12 +207,19 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
       // ---- this lane's sample (fetched during the previous iteration's shape_layer_2 step) -------------------
       const float t0x = cur.px * inv_scale, t1x = cur.py * inv_scale, t2x = cur.pz * inv_scale;
       const int row = cur.row;
-      const float dsg_s = cur.dsg * gscale;
-      // the f16 data-gradient chain needs |d sigma| * gscale <= 8192; a hit (a ray whose termination is one sample: var -> 0,
-      // info -> 1e4) is clipped and REPORTED: bit 4 of the step's flags (cnr_step_tail or-s this word in and clears it)
-      if (clamp_flags && fabsf(dsg_s) > 8192.0f) atomicOr(clamp_flags + c, 16);
-      const float draw = fminf(fmaxf(dsg_s, -8192.0f), 8192.0f) * 10.0f;  // sigmas = raw * 10 (src/model.py:75)
-      const float dr0 = cur.dr0 * gscale, dr1 = cur.dr1 * gscale, dr2 = cur.dr2 * gscale;
+      // upstream gradients: given (KR == 0) or formed after this tile's forward by the composite / loss block below
+      float draw = 0.0f, dr0 = 0.0f, dr1 = 0.0f, dr2 = 0.0f;
+      auto scale_dsigma = [&](float dsg) {
+        const float dsg_s = dsg * gscale;
+        // the f16 data-gradient chain needs |d sigma| * gscale <= 8192; a hit (a ray whose termination is one sample:
+        // var -> 0, info -> 1e4) is clipped and REPORTED: bit 4 of the step's flags (cnr_step_tail or-s the word in)
+        if (clamp_flags && fabsf(dsg_s) > 8192.0f) atomicOr(clamp_flags + c, 16);
+        return fminf(fmaxf(dsg_s, -8192.0f), 8192.0f) * 10.0f;  // sigmas = raw * 10 (src/model.py:75)
+      };
+      if constexpr (KR == 0) {
+        draw = scale_dsigma(cur.dsg);
+        dr0 = cur.dr0 * gscale; dr1 = cur.dr1 * gscale; dr2 = cur.dr2 * gscale;
+      }
       const float* brow_l = reinterpret_cast<const float*>(smem + L8_BR) + (row - c * rows_per_class) * 128;
 
       auto pe_backward = [&](const f16v (&de)[3], int nblk, int band0, int nq) {
@@ -260,9 +308,20 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
 #pragma unroll
       for (int s = 0; s < 5; ++s) wq[s] = lds_frag(smem, KK_VD + s, lane);
       bq = acc_init(cf + CF_B_VD, h);
+      f16v y4keep;        // KR > 0: y4 (fp32) until the loss gradient exists
+      float raw = 0.0f;   // KR > 0: the sigma logit before the x10, fp32 VALU dot product as in fused_fwd.hip
+      if constexpr (KR == 0) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) DWS(i) = fmaf(draw, acc[i], DWS(i));  // d w_sigma += draw * y4
-      DBS += (h == 0) ? draw : 0.0f;
+        for (int i = 0; i < 16; ++i) DWS(i) = fmaf(draw, acc[i], DWS(i));  // d w_sigma += draw * y4
+        DBS += (h == 0) ? draw : 0.0f;
+      } else {
+        y4keep = acc;
+        const f16v ws = acc_init(cf + CF_W_SG, h);
+        float part = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) part = fmaf(ws[i], acc[i], part);
+        raw = part + __shfl_xor(part, 32, 64) + cf[CF_B_SG];
+      }
       const h8 Y4a = pack8(acc, 0, false), Y4b = pack8(acc, 1, false);
       acc = MFMA(wq[0], Y4a, bq);
       acc = MFMA(wq[1], Y4b, acc);
@@ -285,11 +344,133 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
       acc = MFMA(wq[0], A7a, bq);
       h8 Wn0 = lds_frag(bwf, KT_R0, lane), Wn1;
 
+      P8MARK(7);
+      // rgb = sigmoid(logits in rows 0..2 = registers 0..2 of lane half 0)
+      // (v_rcp_f32, 1 ulp, instead of an IEEE division: ten dependent instructions less per quotient, and this stretch of
+      //  the iteration runs as one dependent chain with the SIMD's other wave idle)
+      const float r0 = __builtin_amdgcn_rcpf(1.0f + __expf(-acc[0])), r1 = __builtin_amdgcn_rcpf(1.0f + __expf(-acc[1])),
+                  r2 = __builtin_amdgcn_rcpf(1.0f + __expf(-acc[2]));
+      if constexpr (KR > 0) {
+        // ================= composite + losses + their gradient + composite backward (a11-a15) ==========================
+        // lane half 0 = the tile's 32 samples (half 1 neutral); the ray's KR tiles sit in chain waves wv0 .. wv0 + KR - 1
+        // and exchange tile products / sums through LDS behind workgroup barriers (the dW waves take part in them).
+        // Same expressions as field_fwd_render_kernel (fused_fwd.hip), which holds the whole ray in one wave.
+        constexpr int wv_mask = KR - 1;
+        const int wv0 = wv & ~wv_mask, tin = wv & wv_mask;
+        const bool live = cur.live != 0;
+        const float occ = (h == 0 && live) ? __builtin_amdgcn_rcpf(1.0f + expf(-(raw * 10.0f))) : 0.0f;
+        const float zz = cur.z;
+        const float f = h == 0 ? (1.0f - occ + 1e-10f) : 1.0f;
+        const float incl = half_scan_mul(f);                         // inclusive product of the free probabilities
+        const float excl = lane_below(incl, 1.0f);                   // exclusive (lane 0: 1)
+        const float Pt = lane_value(incl, 31);                       // the tile's product
+        const float tl_ = occ * excl;                                // termination with the carry still to come
+        // the tile's own sums (lane 31 of the DPP scans holds the half-0 totals; half 1 is zero)
+        const float w_l = lane_value(half_scan_add(tl_), 31), d_l = lane_value(half_scan_add(tl_ * zz), 31);
+        const float r_l = lane_value(half_scan_add(tl_ * r0), 31), g_l = lane_value(half_scan_add(tl_ * r1), 31);
+        const float b_l = lane_value(half_scan_add(tl_ * r2), 31);
+        // var = sum term (z - depth)^2 needs the ray's depth first.  Tiles exchange ONCE: each publishes its weighted mean
+        // m_l and M2_l = sum tl (z - m_l)^2; with mean = depth / opacity over the ray,
+        //   var = sum_t c_t (M2_t + w_t (m_t - mean)^2) + opacity (mean - depth)^2      (exact; c_t = carried transmittance)
+        const float m_l = w_l > 0.0f ? d_l * __builtin_amdgcn_rcpf(w_l) : 0.0f;
+        const float dzl = zz - m_l;
+        const float M2_l = lane_value(half_scan_add(tl_ * dzl * dzl), 31);
+        float carry = 1.0f, sd = d_l, so = w_l, sr = r_l, sg = g_l, sb = b_l, sv;
+        f4 xa[KR > 1 ? KR : 1], xb[KR > 1 ? KR : 1];   // the ray's tiles: {P, w, d, r} {g, b, M2, m}
+        float cpre[KR > 1 ? KR : 1];                    // carried transmittance in front of tile t
+        if constexpr (KR > 1) {
+          if (lane == 0) {
+            f4* x = reinterpret_cast<f4*>(xch + wv * 8);
+            x[0] = f4{Pt, w_l, d_l, r_l}; x[1] = f4{g_l, b_l, M2_l, m_l};
+          }
+          P8SYNC();
+#pragma unroll
+          for (int t = 0; t < KR; ++t) {
+            const f4* x = reinterpret_cast<const f4*>(xch + (wv0 + t) * 8);
+            xa[t] = x[0]; xb[t] = x[1];
+          }
+          sd = so = sr = sg = sb = 0.0f;
+          float run = 1.0f;
+#pragma unroll
+          for (int t = 0; t < KR; ++t) {
+            cpre[t] = run;
+            so += run * xa[t][1]; sd += run * xa[t][2]; sr += run * xa[t][3]; sg += run * xb[t][0]; sb += run * xb[t][1];
+            run *= xa[t][0];
+          }
+#pragma unroll
+          for (int t = 0; t < KR; ++t) carry = t == tin ? cpre[t] : carry;
+        }
+        P8MARK(0);
+        const float mean = so > 0.0f ? sd * __builtin_amdgcn_rcpf(so) : 0.0f;
+        if constexpr (KR > 1) {
+          float M2 = 0.0f;
+#pragma unroll
+          for (int t = 0; t < KR; ++t) {
+            const float dm = xb[t][3] - mean;
+            M2 += cpre[t] * (xb[t][2] + xa[t][1] * dm * dm);
+          }
+          sv = M2 + so * (mean - sd) * (mean - sd);
+        } else {
+          const float dm = m_l - mean;   // (= 0 up to rounding: one tile is the whole ray)
+          sv = (M2_l + w_l * dm * dm) + so * (mean - sd) * (mean - sd);
+        }
+        P8MARK(1);
+        const float T = carry * excl;
+        const float term = occ * T;
+        auto sgn = [](float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); };
+        const bool mo = cur.lab != 0, ms = cur.lab != 2, md = (cur.dm != 0) && mo;
+        const float fd = md ? 1.f : 0.f, fo = mo ? 1.f : 0.f, fs = ms ? 1.f : 0.f;
+        const float rd = sd - cur.gtd;
+        const float info = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(sv) + 1e-4f);
+        const float rc0 = sr - cur.g0, rc1 = sg - cur.g1, rc2 = sb - cur.g2;
+        const float ro = so - fo;
+        if (tin == 0 && live) {   // the ray's first tile accounts for it (wave-uniform)
+          ld_acc += fabsf(rd) * fd * info;
+          lc_acc += (fabsf(rc0) + fabsf(rc1) + fabsf(rc2)) * fo;
+          lo_acc += fabsf(ro) * fs;
+          if (lane == 0) {
+            const int ray = c * R + (tile / KR);     // (C R < 2^31: checked by the host)
+            if (ta.depth_out) ta.depth_out[ray] = sd;
+            if (ta.var_out) ta.var_out[ray] = sv;
+            if (ta.opacity_out) ta.opacity_out[ray] = so;
+            if (ta.rgb_out) { ta.rgb_out[ray * 3 + 0] = sr; ta.rgb_out[ray * 3 + 1] = sg; ta.rgb_out[ray * 3 + 2] = sb; }
+          }
+        }
+        const float dD = ta.loss_scale * sgn(rd) * fd * info * wd_c;
+        const float dR = ta.loss_scale * ta.color_scaling * sgn(rc0) * fo * wc_c;
+        const float dG = ta.loss_scale * ta.color_scaling * sgn(rc1) * fo * wc_c;
+        const float dBl = ta.loss_scale * ta.color_scaling * sgn(rc2) * fo * wc_c;
+        const float dO = ta.loss_scale * ta.opacity_scaling * sgn(ro) * fs * wo_c;
+        P8MARK(2);
+        // composite backward: d occ_i = T_i g_i - (sum_{j > i} term_j g_j) / f_i.  The sum over LATER tiles needs no second
+        // exchange: a tile's total of term g is linear in the five ray-level factors, c_t (dD d_t + dR r_t + .. + dO w_t)
+        float suf_carry = 0.0f;
+        if constexpr (KR > 1) {
+#pragma unroll
+          for (int t = 0; t < KR; ++t) {
+            const float tot = cpre[t] * (dD * xa[t][2] + dR * xa[t][3] + dG * xb[t][0] + dBl * xb[t][1] + dO * xa[t][1]);
+            suf_carry += t > tin ? tot : 0.0f;
+          }
+        }
+        P8MARK(3);
+        const float g = dD * zz + dR * r0 + dG * r1 + dBl * r2 + dO;
+        const float tg = h == 0 ? term * g : 0.0f;
+        const float isuf = half0_suffix_add(tg, lane);
+        const float suf = (isuf - tg) + suf_carry;
+        const float docc = T * g - suf * __builtin_amdgcn_rcpf(f);
+        float dsg = (h == 0 && live) ? docc * occ * (1.0f - occ) : 0.0f;
+        P8MARK(4);
+        dsg = low_half_to_both(dsg);                // both lane halves of a sample column need it (d y4 rows 4..7 mod 8)
+        draw = scale_dsigma(dsg);
+        dr0 = term * dR * gscale; dr1 = term * dG * gscale; dr2 = term * dBl * gscale;   // used in lane half 0 only
+#pragma unroll
+        for (int i = 0; i < 16; ++i) DWS(i) = fmaf(draw, y4keep[i], DWS(i));  // d w_sigma += draw * y4
+        DBS += (h == 0) ? draw : 0.0f;
+      }
+      P8MARK(5);
       // ---- step R2: dPre9 = drgb * rgb (1 - rgb) in rows 0..2 (registers 0..2 of half 0)
       h8 D0 = zero8(), D1 = zero8();
       {
-        const float r0 = 1.0f / (1.0f + __expf(-acc[0])), r1 = 1.0f / (1.0f + __expf(-acc[1])),
-                    r2 = 1.0f / (1.0f + __expf(-acc[2]));
         if (h == 0) {
           D0[0] = (_Float16)(dr0 * r0 * (1.0f - r0));
           D0[1] = (_Float16)(dr1 * r1 * (1.0f - r1));
@@ -304,6 +485,7 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
         stage_hs(Ximg, A7a, one, col, h);
       }
       acc = MFMA(wq[1], D0, zero16());  // d a7 (rows 0..15)
+      P8MARK(6);
       P8SYNC();                   // A(R2)
       D0 = pack8_masked(acc, 0, A7a); D1 = zero8();
       u4v Mn0 = relu_mask(A6a), Mn1 = relu_mask(A6b);
@@ -419,6 +601,8 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
         const float v = half_sum_dpp(DBS);  // zero in lane half 1
         if (lane == 31) small[32] = v;
       }
+      if (KR > 0 && lane == 0) { small[40] = ld_acc; small[41] = lc_acc; small[42] = lo_acc; small[43] = __int_as_float(tab_flags);
+                                 small[44] = wd_c; small[45] = wc_c; small[46] = wo_c; }
 #pragma unroll
       for (int i = 0; i < 33; ++i) {
         const float v = half_sum_dpp(DBACC(i));
@@ -535,6 +719,7 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
           }
         }
       };
+      if constexpr (KR > 1) { P8SYNC(); }   // the chain waves' composite exchange
 #define STEP8(NX, K0, K1, K2, K3, GRP)                                                                        \
   P8SYNC();                                                                                             \
   if (dwid == 0) consume(IC<0>{}, IC<NX>{}, IC<K0>{}, IC<K1>{}, IC<K2>{}, IC<K3>{}, IC<GRP>{});               \
@@ -613,6 +798,15 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
     for (int i = threadIdx.x; i < 63; i += NTHR) { rec[TRUNK + i] = sum_chain(64 + i) * inv_gs; rec[TRUNK + 63 + i] = 0.0f; }
     for (int i = threadIdx.x; i < 32; i += NTHR) rec[OFF_SG_W + i] = sum_chain(i) * inv_gs;
     if (threadIdx.x == 0) rec[OFF_SG_B] = sum_chain(32) * inv_gs;
+    if constexpr (KR > 0) {   // per-block loss partials + the class header, the format of cnr_field_fwd_render
+      const int nb = gridDim.x, Cn = gridDim.y;
+      if (threadIdx.x < 3) ta.partials[((size_t)c * nb + blockIdx.x) * 3 + threadIdx.x] = sum_chain(40 + threadIdx.x);
+      if (blockIdx.x == 0 && threadIdx.x < 4) {
+        const float* s0 = reinterpret_cast<const float*>(chain_base + K_SMALL);
+        float* hdr = ta.partials + (size_t)Cn * nb * 3 + (size_t)c * 4;
+        hdr[threadIdx.x] = threadIdx.x < 3 ? s0[44 + threadIdx.x] : (float)__float_as_int(s0[43]);
+      }
+    }
   }
   P8PHASE(3); P8PHASE(4);
   P8PHASE(5);
@@ -620,35 +814,88 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
 }  // namespace
 
 // launched by cnr_field_bwd_pipe (fused_bwd_pipe.hip) for chain_waves = 4: same argument checks, same records
+template <bool WIDE, int KR>
+static int launch_p8(const float* pts, const float* B, const void* packed, const float* biasrows, const int* ray_row,
+                     float scale, const float* d_sigma, const float* d_rgb, float grad_scale, int C, int R, int S,
+                     int rows_per_class, int blocks, void* workspace, int64_t B_stride, long long* rows_fix,
+                     int* clamp_flags, const TrainArgs& ta, void* stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t er = hipFuncSetAttribute((const void*)field_bwd_pipe8_kernel<4, 4, WIDE, KR>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, l8_total(4));
+    if (er != hipSuccess) return (int)er;
+    attr_set = true;
+  }
+  const int64_t N = (int64_t)R * S;
+  hipLaunchKernelGGL((field_bwd_pipe8_kernel<4, 4, WIDE, KR>), dim3((unsigned)blocks, (unsigned)C), dim3(512), l8_total(4),
+                     (hipStream_t)stream, pts, B, (const unsigned char*)packed, biasrows, ray_row, 1.0f / scale, d_sigma,
+                     d_rgb, grad_scale, (float*)workspace, (int)N, S, R, rows_per_class,
+                     B_stride > 0 ? B_stride : (int64_t)63, rows_fix, clamp_flags, ta);
+  CNR_LAUNCH_CHECK();
+  return CNR_OK;
+}
+
 extern "C" int cnr_field_bwd_pipe8_launch(const float* pts, const float* B, const void* packed, const float* biasrows,
                                           const int* ray_row, float scale, const float* d_sigma, const float* d_rgb,
                                           float grad_scale, int C, int R, int S, int rows_per_class, int blocks,
                                           void* workspace, int64_t B_stride, long long* rows_fix, int* clamp_flags,
                                           void* stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t er = hipFuncSetAttribute((const void*)field_bwd_pipe8_kernel<4, 4, false>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, l8_total(4));
-    if (er != hipSuccess) return (int)er;
-    er = hipFuncSetAttribute((const void*)field_bwd_pipe8_kernel<4, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                             l8_total(4));
-    if (er != hipSuccess) return (int)er;
-    attr_set = true;
+  const TrainArgs none{};
+  if (rows_per_class > 4)
+    return launch_p8<true, 0>(pts, B, packed, biasrows, ray_row, scale, d_sigma, d_rgb, grad_scale, C, R, S, rows_per_class,
+                              blocks, workspace, B_stride, rows_fix, clamp_flags, none, stream);
+  return launch_p8<false, 0>(pts, B, packed, biasrows, ray_row, scale, d_sigma, d_rgb, grad_scale, C, R, S, rows_per_class,
+                             blocks, workspace, B_stride, rows_fix, clamp_flags, none, stream);
+}
+
+// ---- the ONE-launch step body: a8-a15 forward, losses, and the whole backward (see TrainArgs) ------------------------
+extern "C" int cnr_field_train_blocks(int R, int S, int max_blocks) {
+  if (R <= 0 || (S != 32 && S != 64 && S != 128)) return 0;
+  const int64_t ntiles = (int64_t)R * (S / 32);
+  int64_t blocks = (ntiles + 3) / 4;
+  const int64_t cap = max_blocks > 0 ? max_blocks : 256;
+  return (int)(blocks > cap ? cap : blocks);
+}
+extern "C" int64_t cnr_field_train_workspace_bytes(int C, int R, int S, int max_blocks) {
+  const int nb = cnr_field_train_blocks(R, S, max_blocks);
+  return nb ? ((int64_t)C * nb * 3 + (int64_t)C * 4) * (int64_t)sizeof(float) : 0;
+}
+extern "C" int cnr_field_train(const float* pts, const float* B, const void* packed, const float* biasrows,
+                               const int* ray_row, float scale, const float* z, const float* gt_depth,
+                               const float* gt_rgb, const uint8_t* labels, const uint8_t* depth_mask,
+                               const float* counts_tab, const int64_t* d_state, float color_scaling,
+                               float opacity_scaling, float loss_scale, float grad_scale, float* depth, float* var,
+                               float* rgb, float* opacity, int C, int R, int S, int rows_per_class, int max_blocks,
+                               void* records, int64_t records_bytes, void* loss_workspace, int64_t loss_workspace_bytes,
+                               int64_t B_stride, long long* rows_fix, int* clamp_flags, void* stream) {
+  if (!pts || !B || !packed || !biasrows || !ray_row || !z || !gt_depth || !gt_rgb || !labels || !depth_mask ||
+      !counts_tab || !records || !loss_workspace || C <= 0 || R <= 0 || !(scale > 0.f) || !(grad_scale > 0.f))
+    return CNR_E_ARG;
+  const int blocks = cnr_field_train_blocks(R, S, max_blocks);
+  if (!blocks || rows_per_class < 1 || rows_per_class > cnr_rec::ROWS_MAX) return CNR_E_SHAPE;
+  if ((int64_t)C * R * S >= ((int64_t)1 << 31)) return CNR_E_SHAPE;   // 32-bit sample indices inside the kernel
+  if (((uintptr_t)packed & 15) != 0 || ((uintptr_t)records & 15) != 0) return CNR_E_ALIGN;
+  if (records_bytes < (int64_t)C * blocks * REC_FLOATS * (int64_t)sizeof(float) ||
+      loss_workspace_bytes < cnr_field_train_workspace_bytes(C, R, S, max_blocks))
+    return CNR_E_ARG;
+  const TrainArgs ta{z, gt_depth, gt_rgb, labels, depth_mask, counts_tab, d_state, color_scaling, opacity_scaling,
+                     loss_scale, depth, var, rgb, opacity, (float*)loss_workspace};
+#define CNR_FT(WIDE, KR)                                                                                              \
+  return launch_p8<WIDE, KR>(pts, B, packed, biasrows, ray_row, scale, nullptr, nullptr, grad_scale, C, R, S,          \
+                             rows_per_class, blocks, records, B_stride, rows_fix, clamp_flags, ta, stream)
+  if (rows_per_class > 4) {
+    if (S == 32) CNR_FT(true, 1);
+    if (S == 64) CNR_FT(true, 2);
+    CNR_FT(true, 4);
   }
-  const int64_t N = (int64_t)R * S;
-#define CNR_LAUNCH_P8(WIDE)                                                                                        \
-  hipLaunchKernelGGL((field_bwd_pipe8_kernel<4, 4, WIDE>), dim3((unsigned)blocks, (unsigned)C), dim3(512),           \
-                     l8_total(4), (hipStream_t)stream, pts, B, (const unsigned char*)packed, biasrows, ray_row,      \
-                     1.0f / scale, d_sigma, d_rgb, grad_scale, (float*)workspace, (int)N, S, R, rows_per_class,       \
-                     B_stride > 0 ? B_stride : (int64_t)63, rows_fix, clamp_flags)
-  if (rows_per_class > 4) CNR_LAUNCH_P8(true); else CNR_LAUNCH_P8(false);
-#undef CNR_LAUNCH_P8
-  CNR_LAUNCH_CHECK();
-  return CNR_OK;
+  if (S == 32) CNR_FT(false, 1);
+  if (S == 64) CNR_FT(false, 2);
+  CNR_FT(false, 4);
+#undef CNR_FT
 }
 
 #ifdef CNR_PIPE_STAMPS
 extern "C" int cnr_pipe8_read_stamps(long long* host) {
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pipe8_stamps), sizeof(long long) * 8 * 48);
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pipe8_stamps), sizeof(long long) * 8 * 64);
 }
 #endif

@@ -92,7 +92,7 @@ class FusedCategoryTrainer:
     def __init__(self, cfg, n_cls, n_obj, pools, rays_per_step, device, seed=0, generator=None,
                  grad_scale=None, bwd_blocks=0, process_group=None, use_graph=True, split_graph=False,
                  fuse_render=True, split_weights=None, shard=None, n_cls_global=None, class_ids=None,
-                 check_every=0, world_frame=None, dp_rank=None, dp_world=None):
+                 check_every=0, world_frame=None, dp_rank=None, dp_world=None, one_launch=None):
         self.cfg, self.C, self.n_obj, self.R = cfg, n_cls, n_obj, rays_per_step
         self.device = torch.device(device)
         self.n1, self.n2 = cfg.n_bins_cam2surface, cfg.n_bins
@@ -190,6 +190,13 @@ class FusedCategoryTrainer:
             else bool(split_weights)
         # forward + render/loss in one launch where the shape allows (S a multiple of 32 up to 128), else two launches
         self._rl_blocks = int(_C.load().cnr_field_fwd_render_blocks(self.R, self.S)) if fuse_render else 0
+        # ... and forward + render / loss + the whole backward in ONE launch (cnr_field_train: S in {32, 64, 128}, the 8-wave
+        # kernel's record path): no second forward, no d sigma / d colour round trip.  CNR_ONE_LAUNCH=0 keeps the two calls.
+        one = bool(int(os.environ.get("CNR_ONE_LAUNCH", "1"))) if one_launch is None else bool(one_launch)
+        self._ft_blocks = int(_C.load().cnr_field_train_blocks(self.R, self.S, self.bwd_blocks)) \
+            if (one and fuse_render and self.use_records and ops.FIELD_BWD_VARIANT == "pipe4" and not self.split_weights) else 0
+        if self._ft_blocks:
+            self._nwg = self._ft_blocks
         self.use_graph = use_graph
         self.split_graph = bool(split_graph)     # the two-graph form of the distributed step, for single-GPU tests
         self.graphs = {}                         # parity -> captured graph (or (front, back) pair)
@@ -230,7 +237,8 @@ class FusedCategoryTrainer:
                                 ("dsig", (C, R, S)), ("drgb", (C, R, S, 3))):
                 o[name] = torch.empty(*shape, **kw)
             o["rl_ws"] = torch.zeros(max(_C.render_loss_workspace_bytes(C, R),
-                                         int(_C.load().cnr_field_fwd_render_workspace_bytes(C, R, S))),
+                                         int(_C.load().cnr_field_fwd_render_workspace_bytes(C, R, S)),
+                                         int(_C.load().cnr_field_train_workspace_bytes(C, R, S, self.bwd_blocks))),
                                      device=self.device, dtype=torch.uint8)
             o["bwd_ws"] = torch.empty(_C.field_bwd_workspace_bytes(C, self.bwd_blocks), device=self.device,
                                       dtype=torch.uint8)
@@ -263,7 +271,13 @@ class FusedCategoryTrainer:
         # the whole batch's gradient, nothing to rescale; the code regulariser is formed on every ray shard -> 1 / world
         inv_w = 1.0
         st = self.d_state2[self.parity]
-        if self._rl_blocks:
+        if self._ft_blocks:
+            # a8-a15 forward, losses, their gradient and the field backward in ONE launch
+            _C.call("cnr_field_train", b["pts"], Bc, packed, brows, ray_row, self.scale, b["z"], b["gt_depth"], b["gt_rgb"],
+                    b["labels"], b["depth_mask"], self.counts_tab, st, 5.0, 10.0, inv_w, self.grad_scale, o["depth"],
+                    o["var"], o["rgb"], o["opa"], C, R, S, n_obj, self.bwd_blocks, o["bwd_ws"], o["bwd_ws"].numel(),
+                    o["rl_ws"], o["rl_ws"].numel(), P, self.rows_fix, self.clamp)
+        elif self._rl_blocks:
             # a8-a15 in one launch (S = 32 k): field forward, composite, losses, their gradient, composite backward;
             # sigma / colour per sample never leave registers
             _C.call("cnr_field_fwd_render", b["pts"], Bc, packed, brows, ray_row, self.scale, b["z"], b["gt_depth"],
@@ -277,10 +291,11 @@ class FusedCategoryTrainer:
                     5.0, 10.0, inv_w, o["dsig"], o["drgb"], o["depth"], o["var"], o["rgb"], o["opa"], C, R, S,
                     o["rl_ws"], o["rl_ws"].numel(), self.counts_tab, st)
         # fused backward: dtrunk, dB, dbiasrows straight into the flat gradient buffer views
-        ops.field_bwd(b["pts"], Bc, packed, brows, ray_row, self.scale, o["dsig"], o["drgb"], self.grad_scale,
-                      g_trunk, g_B, self.dbias, C, R, S, n_obj, self.bwd_blocks, o["bwd_ws"],
-                      B_stride=P, dtrunk_stride=P, dB_stride=P, rows_fix=self.rows_fix, skip_reduce=self.use_records,
-                      clamp_flags=self.clamp)
+        if not self._ft_blocks:
+            ops.field_bwd(b["pts"], Bc, packed, brows, ray_row, self.scale, o["dsig"], o["drgb"], self.grad_scale,
+                          g_trunk, g_B, self.dbias, C, R, S, n_obj, self.bwd_blocks, o["bwd_ws"],
+                          B_stride=P, dtrunk_stride=P, dB_stride=P, rows_fix=self.rows_fix, skip_reduce=self.use_records,
+                          clamp_flags=self.clamp)
         self._reg = 0.0005 / self.ray_world      # code regulariser scale: loss.py:5-15, train.py:165-167
         if self.grad_exchange:                   # ray shards: the all-reduce needs the complete gradient first
             if self.use_records:                 # record reduction + latent backward in one launch, gradient only
@@ -304,7 +319,7 @@ class FusedCategoryTrainer:
                 self.d_state2[par], self.d_state2[1 - par], self.Rg, o["rl_ws"], self.losses, self.flags,
                 None, self.pool_rows, None, None, R,
                 o["bwd_ws"] if self.fused_tail else None, self._nwg if self.fused_tail else 0,
-                self.rows_fix if self.fused_tail else None, self._rl_blocks, self.clamp)
+                self.rows_fix if self.fused_tail else None, self._ft_blocks or self._rl_blocks, self.clamp)
 
     def step(self):
         """One train step.  Returns nothing; ``self.losses`` (3,C) / ``self.flags`` (C,) hold the device-side
@@ -386,6 +401,30 @@ class FusedCategoryTrainer:
         if self.grad_exchange and self.pg is not None:
             torch.distributed.all_reduce(out, group=self.pg)
         return out
+
+    def time_field_train(self, iters=50):
+        """Average duration (ms) of the one-launch step body (cnr_field_train) on the live buffers of the last step,
+        launched back to back between two HIP events on the launch stream (records / renders are overwritten with the same
+        values; the integer row table is scratch here)."""
+        assert self._ft_blocks
+        C, R, S, o, b, lay = self.C, self.R, self.S, self.bufs, self.bufs, self.lay
+        Bc = self.theta[0, lay.B[0]:lay.B[1]]
+        fix = torch.zeros_like(self.rows_fix)
+        clamp = torch.zeros_like(self.clamp)
+        st = self.d_state2[self.parity]
+        run = lambda: _C.call("cnr_field_train", b["pts"], Bc, o["packed"], o["brows"], b["ray_row"], self.scale, b["z"],
+                              b["gt_depth"], b["gt_rgb"], b["labels"], b["depth_mask"], self.counts_tab, st, 5.0, 10.0, 1.0,
+                              self.grad_scale, o["depth"], o["var"], o["rgb"], o["opa"], C, R, S, self.n_obj, self.bwd_blocks,
+                              o["bwd_ws"], o["bwd_ws"].numel(), o["rl_ws"], o["rl_ws"].numel(), lay.total, fix, clamp)
+        for _ in range(3):
+            run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
 
     def time_field_bwd(self, iters=50):
         """Average duration (ms) of the dominant call -- the fused field backward on the live buffers of the last step

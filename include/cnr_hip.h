@@ -383,6 +383,28 @@ int cnr_field_bwd_pipe(const float* pts, const float* B, const void* packed, con
                        int64_t dtrunk_stride, int64_t dB_stride, long long* rows_fix, int skip_reduce,
                        int* clamp_flags, void* stream);
 
+/* ---- the step body in ONE launch: cnr_field_fwd_render + cnr_field_bwd_pipe (chain_waves = 4) fused ---------------------
+ * a8-a15 forward, the loss gradient and the whole field backward (train.py:154-182 for the object branch) with ONE field
+ * forward per sample (cnr_field_bwd_pipe recomputes it), no d sigma / d colour round trip through HBM and one launch less.
+ * S in {32, 64, 128}: the S / 32 tiles of a ray sit in neighbouring chain waves of a workgroup iteration and exchange the
+ * tile products / partial renders / suffix sums of the composite through LDS.  Arguments as the two calls it replaces;
+ * counts_tab (cnr_slice_maskcounts) is REQUIRED -- the kernel never counts masks --, d_state selects its entry (NULL: 0);
+ * loss_scale multiplies the loss gradient (what cnr_field_fwd_render calls grad_scale), grad_scale is the power-of-two
+ * scale of the f16 data-gradient chain.  Outputs: the renders (each optional), the per-workgroup gradient records in
+ * `records` (>= C * cnr_field_train_blocks() * record size = cnr_field_bwd_workspace_bytes(C, blocks); reduce with
+ * cnr_step_tail / cnr_step_grad, nwg = cnr_field_train_blocks()), rows_fix as cnr_field_bwd_pipe, and per-block loss
+ * partials in loss_workspace (>= cnr_field_train_workspace_bytes()) for cnr_step_tail with rl_blocks =
+ * cnr_field_train_blocks().  Returns CNR_E_SHAPE for any other S or more than 7 rows per class (use the two calls). */
+int cnr_field_train_blocks(int R, int S, int max_blocks);
+int64_t cnr_field_train_workspace_bytes(int C, int R, int S, int max_blocks);
+int cnr_field_train(const float* pts, const float* B, const void* packed, const float* biasrows, const int* ray_row,
+                    float scale, const float* z, const float* gt_depth, const float* gt_rgb, const uint8_t* labels,
+                    const uint8_t* depth_mask, const float* counts_tab, const int64_t* d_state, float color_scaling,
+                    float opacity_scaling, float loss_scale, float grad_scale, float* depth, float* var, float* rgb,
+                    float* opacity, int C, int R, int S, int rows_per_class, int max_blocks, void* records,
+                    int64_t records_bytes, void* loss_workspace, int64_t loss_workspace_bytes, int64_t B_stride,
+                    long long* rows_fix, int* clamp_flags, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -119,7 +119,8 @@ def test_two_processes_match_the_single_process_run(cnr, dev, tmp_path, mode, em
     if mode == "ray":
         assert all(r["in_sync"] for r in res)
         assert torch.equal(res[0]["theta"], res[1]["theta"])
-        assert rel_l2(res[0]["theta"], one.theta) < 1e-4 and rel_l2(res[0]["hist"], hist) < 1e-3
+        # nine steps apart from the summation order of one all-reduce per step (AdamW's sign-like first steps amplify it)
+        assert rel_l2(res[0]["theta"], one.theta) < 1e-3 and rel_l2(res[0]["hist"], hist) < 2e-3
     else:
         for r in res:
             assert torch.equal(r["theta"], one.theta.cpu()[r["ids"]]) and torch.equal(r["hist"], hist[:, :, r["ids"]])

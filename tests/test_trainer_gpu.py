@@ -350,3 +350,41 @@ def test_many_epochs_graph_equals_eager(cnr, dev, n_obj):
         res[name] = (torch.stack(hist), tr.theta.clone())
     assert torch.isfinite(res["graph"][0]).all()
     assert torch.equal(res["graph"][0], res["eager"][0]) and torch.equal(res["graph"][1], res["eager"][1])
+
+
+@pytest.mark.parametrize("C,R,n1,n2,n_obj,L", [(1, 2048, 8, 56, 4, 256), (2, 250, 4, 28, 4, 32), (2, 249, 8, 56, 6, 32),
+                                               (1, 1023, 16, 112, 4, 32), (3, 64, 4, 28, 7, 32), (1, 1, 8, 56, 1, 32)])
+def test_one_launch_step_equals_forward_render_plus_backward(cnr, dev, C, R, n1, n2, n_obj, L):
+    """cnr_field_train (a8-a15 forward, losses, loss gradient and the field backward in ONE launch, the ray's tiles
+    exchanging composite partials between waves) against cnr_field_fwd_render + cnr_field_bwd_pipe: same f16 pipeline,
+    same samples -> renders and loss values to fp32 summation order, the complete gradient (trunk, latent layers, B,
+    codes) to 1e-5, parameters after AdamW; ragged tile counts (dead tiles in the last workgroup iteration), 5-7
+    objects per class (the run-time row-sum stride) and S = 32 / 64 / 128 (1, 2, 4 tiles per ray)."""
+    res = {}
+    for name, one in (("two", False), ("one", True)):
+        cfg = cnr.cfg.synthetic_config(device=str(dev), latent_dim=L, n_bins_cam2surface=n1, n_bins=n2)
+        gen = torch.Generator().manual_seed(5)
+        pools = [cnr.scene_cateogries.synthetic_pool(max(4 * R, 8), n_obj, gen, "cpu") for _ in range(C)]
+        tr = cnr.fused.FusedCategoryTrainer(cfg, C, n_obj, pools, R, dev, seed=2, generator=gen, use_graph=False,
+                                            one_launch=one)
+        assert bool(tr._ft_blocks) == one
+        hist = []
+        for _ in range(3):
+            tr.step()
+            torch.cuda.synchronize()
+            hist.append(dict(grad=tr.grad.clone(), losses=tr.losses.clone(), flags=tr.flags.clone(), theta=tr.theta.clone(),
+                             **{k: tr.bufs[k].clone() for k in ("depth", "var", "rgb", "opa", "z")}))
+        res[name] = hist
+    a, b = res["one"][0], res["two"][0]
+    assert torch.equal(a["z"], b["z"])
+    for k in ("depth", "rgb", "opa"):
+        assert rel_l2(a[k], b[k]) < 1e-6, (k, rel_l2(a[k], b[k]))
+    assert rel_l2(a["var"], b["var"]) < 1e-5
+    assert rel_l2(a["losses"], b["losses"]) < 1e-5 and torch.equal(a["flags"], b["flags"])
+    # (the one-launch kernel forms its quotients with v_rcp_f32, 1 ulp: d sigma differs in the last bit, which the f16 pack of
+    #  the scaled gradients turns into an f16 ulp here and there)
+    assert rel_l2(a["grad"], b["grad"]) < 1e-4, rel_l2(a["grad"], b["grad"])
+    assert rel_l2(a["theta"], b["theta"]) < 1e-3     # first AdamW step: +-lr per entry, the sign of a ~0 gradient entry is noise
+    for s in range(3):   # still the same training run two steps later (AdamW's sign-like first steps amplify rounding)
+        assert torch.isfinite(res["one"][s]["grad"]).all()
+        assert rel_l2(res["one"][s]["losses"], res["two"][s]["losses"]) < 2e-2

@@ -30,18 +30,18 @@ for it in range(3):
             2048.0, dtrunk.data_ptr(), dB.data_ptr(), dbr.data_ptr(), C, R, S, n_obj, 0, NCH, wsp.data_ptr(), wsp.numel(), 0, 0, 0, None, 0, None)
     torch.cuda.synchronize()
     if NCH == 4:
-        buf = (ctypes.c_longlong * (8 * 48))()
+        buf = (ctypes.c_longlong * (8 * 64))()
         lib.cnr_pipe8_read_stamps(buf)
-        base = min(buf[w * 48] for w in range(8))
+        base = min(buf[w * 64] for w in range(8))
         for w in range(8):
-            st = list(buf)[w * 48: w * 48 + 37]
+            st = list(buf)[w * 64: w * 64 + 37]
             # stamps: 0 = iteration start, then (before barrier, after barrier) x 18 (A, B per layer step)
             work = [st[1] - st[0]] + [st[2 * k + 1] - st[2 * k] for k in range(1, 18)]
             wait = [st[2 * k + 2] - st[2 * k + 1] for k in range(18)]
             print(rc, "wave", w, "t0", st[0] - base, "total", st[36] - st[0], "sum work", sum(work), "sum wait", sum(wait))
             print("      work", work)
             print("      wait", wait)
-            ph = list(buf)[w * 48 + 40: w * 48 + 46]
+            ph = list(buf)[w * 64 + 56: w * 64 + 62]
             print("      phases: start->weights in LDS", ph[1] - ph[0], "loops", ph[2] - ph[1], "partial sums -> record", ph[3] - ph[2],
                   "blocks -> LDS image", ph[4] - ph[3], "image -> record", ph[5] - ph[4], "| total", ph[5] - ph[0])
         continue
