@@ -10,7 +10,7 @@ for path in sys.argv[1:]:
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(path)):
         k = r["Kernel_Name"]
-        if "field_" in k or "reduce_records" in k:
+        if "field_" in k or "reduce_records" in k or "tail_kernel" in k or "param_prep" in k:
             key = k.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
             acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in acc.items():

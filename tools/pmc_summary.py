@@ -18,7 +18,8 @@ fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "W
 R, S = int(sys.argv[4]), int(sys.argv[5])
 out = {"workload": f"tools/prof_one.py {R} {S} (1 class, {R} rays x {S} samples), rocprofv3 --pmc, one counter per "
                    "pass, KB per launch; FETCH_SIZE x2 (64 B counted per 128-B request on gfx950)", "kernels": {}}
-want = ("field_fwd_kernel", "field_bwd_pipe8_kernel", "field_bwd_pipe_kernel", "field_bwd_kernel", "reduce_records_kernel")
+want = ("field_fwd_kernel", "field_bwd_pipe8_kernel", "field_bwd_pipe_kernel", "field_bwd_kernel", "reduce_records_kernel",
+        "tail_kernel", "param_prep_kernel")
 call = 0.0
 for name in sorted(set(fetch) | set(write)):
     short = next((w for w in want if w in name), None)
@@ -28,8 +29,13 @@ for name in sorted(set(fetch) | set(write)):
     f, w = fetch.get(name, 0.0), write.get(name, 0.0)
     hbm = (2 * f + w) * 1024
     out["kernels"][key] = {"FETCH_SIZE_KB_raw": f, "WRITE_SIZE_KB": w, "hbm_bytes": hbm}
-    if short != "field_fwd_kernel":
+    if short not in ("field_fwd_kernel", "tail_kernel", "param_prep_kernel"):
         call += hbm
+    if short == "field_bwd_pipe8_kernel" and "true, 0>" not in key and "false, 0>" not in key:
+        out["cnr_field_train_call_hbm_bytes"] = hbm      # the one-launch step body (KR > 0 instantiation)
+        # 12 B pts + 4 B z per sample in; per ray 18 B targets in + 24 B renders out; one 62 KB operand image and one
+        # 58 KB record per workgroup are what the launch structure adds
+        out["cnr_field_train_algorithmic_bytes"] = R * S * 16 + R * 42
 out["cnr_field_bwd_pipe_call_hbm_bytes"] = call
 out["cnr_field_bwd_algorithmic_bytes"] = R * S * 28
 out["note"] = ("backward call = field kernel + reduce_records; the per-workgroup records (one 59 KB record per workgroup, "

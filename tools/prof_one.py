@@ -6,6 +6,17 @@ import torch
 import cnr_amd
 from cnr_amd import ops, _C
 dev = torch.device("cuda:0")
+if len(sys.argv) > 3 and sys.argv[3] == "train":
+    # the trainer's own step (param_prep | field forward + composite + backward in one launch | tail), eager, ten times
+    R, S = int(sys.argv[1]), int(sys.argv[2])
+    cfg = cnr_amd.cfg.synthetic_config(device=str(dev), latent_dim=256, n_bins_cam2surface=S // 8, n_bins=S - S // 8)
+    gen = torch.Generator().manual_seed(0)
+    pools = [cnr_amd.scene_cateogries.synthetic_pool(16 * R, 4, gen, "cpu")]
+    tr = cnr_amd.fused.FusedCategoryTrainer(cfg, 1, 4, pools, R, dev, seed=0, generator=gen, use_graph=False)
+    for _ in range(10):
+        tr.step()
+    torch.cuda.synchronize()
+    sys.exit(0)
 L, n_obj = 256, 4
 C, R, S = 1, int(sys.argv[1]), int(sys.argv[2])
 blocks = int(sys.argv[3]) if len(sys.argv) > 3 else 0
