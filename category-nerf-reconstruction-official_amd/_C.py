@@ -24,7 +24,7 @@ SIGNATURES = {
     "cnr_sample_rays": [_vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64, _vp, _i64, _vp, _i, _i, _i, _i, _i, _f, _f, _f,
                         _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp],
     "cnr_latent_fwd": [_vp, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _vp, _vp, _vp],
-    "cnr_latent_bwd": [_vp, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _vp, _vp, _f, _vp, _vp],
+    "cnr_latent_bwd": [_vp, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp],
     "cnr_pe_fwd": [_vp, _vp, _vp, _i, _i64, _f, _vp],
     "cnr_pe_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i64, _f, _vp],
     "cnr_mlp_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
@@ -56,8 +56,8 @@ SIGNATURES = {
     "cnr_adamw_epilogue": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64,
                            _vp, _vp, _i, _i, _vp],
     "cnr_step_tail": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _vp, _vp, _f, _i, _f, _f, _f,
-                      _f, _f, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp],
-    "cnr_step_grad": [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _vp, _vp, _f, _vp, _i, _vp, _vp],
+                      _f, _f, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp],
+    "cnr_step_grad": [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _vp, _vp, _f, _vp, _i, _vp, _vp, _vp],
     "cnr_field_fwd_render_blocks": [_i, _i],
     "cnr_field_fwd_render_workspace_bytes": [_i, _i, _i],
     "cnr_field_fwd_render": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp,

@@ -30,12 +30,14 @@ struct GradStoreSink {
 __global__ __launch_bounds__(256) void latent_bwd_kernel(const float* __restrict__ theta, FlatLayout lay,
                                                          const float* __restrict__ zl,
                                                          const float* __restrict__ dbiasrows, float reg_scale,
-                                                         float* __restrict__ grad) {
+                                                         float* __restrict__ grad, const int* __restrict__ n_obj_cls) {
   extern __shared__ float sm[];
   const int c = blockIdx.y;
   GradStoreSink sink{grad + (int64_t)c * lay.stride};
+  const int n_real = n_obj_cls ? n_obj_cls[c] : lay.n_obj;   // src/loss.py:5-15: the regulariser needs > 1 object
   latent_bwd_block(theta + (int64_t)c * lay.stride, lay, zl + (int64_t)c * lay.n_obj * 128,
-                   dbiasrows + (int64_t)c * lay.n_obj * 128, reg_scale, sm, sink, blockIdx.x, gridDim.x, true);
+                   dbiasrows + (int64_t)c * lay.n_obj * 128, n_real > 1 ? reg_scale : 0.0f, sm, sink, blockIdx.x,
+                   gridDim.x, true, n_real);
 }
 }  // namespace
 
@@ -51,7 +53,8 @@ extern "C" int cnr_latent_fwd(const float* theta, int64_t class_stride, int64_t 
 
 extern "C" int cnr_latent_bwd(const float* theta, int64_t class_stride, int64_t off_latW, int64_t off_latb,
                               int64_t off_shape, int64_t off_tex, int L, int n_obj, int C, const float* zl,
-                              const float* dbiasrows, float reg_scale, float* grad, void* stream) {
+                              const float* dbiasrows, float reg_scale, float* grad, const int* n_obj_cls,
+                              void* stream) {
   if (!theta || !zl || !dbiasrows || !grad || L <= 0 || n_obj <= 0 || C <= 0) return CNR_E_ARG;
   if (n_obj > 64) return CNR_E_SHAPE;
   FlatLayout lay{class_stride, off_latW, off_latb, off_shape, off_tex, L, n_obj};
@@ -61,7 +64,7 @@ extern "C" int cnr_latent_bwd(const float* theta, int64_t class_stride, int64_t 
   int nblk = (int)((n4 + 255) / 256);
   if (nblk > 256) nblk = 256;
   hipLaunchKernelGGL(latent_bwd_kernel, dim3(nblk, C), dim3(256), lds, (hipStream_t)stream, theta, lay, zl, dbiasrows,
-                     n_obj > 1 ? reg_scale : 0.0f, grad);
+                     reg_scale, grad, n_obj_cls);
   CNR_LAUNCH_CHECK();
   return CNR_OK;
 }

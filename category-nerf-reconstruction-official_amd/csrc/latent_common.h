@@ -89,7 +89,9 @@ template <class Sink>
 __device__ __forceinline__ void latent_bwd_block(const float* __restrict__ th, const FlatLayout& lay,
                                                  const float* __restrict__ z, const float* __restrict__ dbr,
                                                  float reg_scale, float* sm, const Sink& sink, int blk, int nblk,
-                                                 bool with_trunk) {
+                                                 bool with_trunk, int n_real = 1 << 30) {
+  // n_real: objects the class really has (rows >= n_real are padding of a class with fewer objects than the layout's
+  // n_obj: no regulariser there; their bias-row gradients are zero because no ray refers to them)
   const int n_obj = lay.n_obj, L = lay.L;
   float* dpre = sm;
   float* inv_s = sm + n_obj * 128;
@@ -115,7 +117,7 @@ __device__ __forceinline__ void latent_bwd_block(const float* __restrict__ th, c
       for (int j = 0; j < 4; ++j) s = fmaf(cv[j], cv[j], s);
       for (int l = lane + 256; l < L; l += 64) s = fmaf(code[l], code[l], s);
       s = wave_sum(s);
-      if (lane == 0) (t < n_obj ? inv_s : inv_t)[ob] = reg_scale / sqrtf(s);
+      if (lane == 0) (t < n_obj ? inv_s : inv_t)[ob] = ob < n_real ? reg_scale / sqrtf(s) : 0.0f;
     }
   }
   __syncthreads();
@@ -178,7 +180,8 @@ __device__ __forceinline__ void latent_bwd_block_1trip(const float* __restrict__
                                                        const float* __restrict__ z,
                                                        const long long* __restrict__ rows_fix_c, int64_t copy_stride,
                                                        int ncopies, double fix_inv_scale, float* __restrict__ rows_out,
-                                                       float reg_scale, float* sm, const Sink& sink, int blk) {
+                                                       float reg_scale, float* sm, const Sink& sink, int blk,
+                                                       int n_real = 1 << 30) {
   const int n_obj = lay.n_obj, L = lay.L, nrow = n_obj * 128;
   float* rows = sm;                 // [n_obj * 128] d biasrows
   float* dpre = rows + nrow;        // [n_obj * 128]
@@ -271,7 +274,7 @@ __device__ __forceinline__ void latent_bwd_block_1trip(const float* __restrict__
 #pragma unroll
       for (int j = 0; j < 4; ++j) s = fmaf(cvn[r][j], cvn[r][j], s);
       s = wave_sum(s);
-      if (lane == 0) (tt < n_obj ? inv_s : inv_t)[tt % n_obj] = reg_scale / sqrtf(s);
+      if (lane == 0) (tt < n_obj ? inv_s : inv_t)[tt % n_obj] = (tt % n_obj) < n_real ? reg_scale / sqrtf(s) : 0.0f;
     }
   }
   __syncthreads();

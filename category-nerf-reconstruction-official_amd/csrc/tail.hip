@@ -38,6 +38,7 @@ struct TailArgs {
   const float* records; int nwg; const long long* rows_fix; int NR;
   // grad_only: stop at the finished gradient (no AdamW, no epilogue blocks): the multi-GPU step all-reduces it first
   int grad_only;
+  const int* n_obj_cls;  // optional (C,): objects each class really has (<= lay.n_obj; the rest of its rows are padding)
   int* clamp_flags;  // optional (C,): bits the field backward raised this step (cnr_field_bwd_pipe); or-ed into flags, cleared
 };
 
@@ -114,6 +115,8 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
   }
   if (b < nlat) {  // ---- latent backward of class c + AdamW on what it produces
     const int c = b / a.NL, blk = b % a.NL;
+    const int n_real = a.n_obj_cls ? a.n_obj_cls[c] : a.lay.n_obj;
+    const float reg_c = n_real > 1 ? a.reg_scale : 0.0f;        // src/loss.py:5-15: classes with one object: no regulariser
     AdamSink sink{a, (int64_t)c * P, step_size, inv_bc2_sqrt};
     const float* dbr = a.dbiasrows + (int64_t)c * a.lay.n_obj * 128;
     float* scratch = sm;
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
       const int n = a.lay.n_obj * 128;
       latent_bwd_block_1trip(a.theta_in + (int64_t)c * P, a.lay, a.zl + (int64_t)c * n, a.rows_fix + (size_t)c * n,
                              (int64_t)a.C * n, cnr_rec::ROWS_FIX_COPIES, 1.0 / cnr_rec::ROWS_FIX_SCALE,
-                             blk == 0 ? a.dbiasrows + (int64_t)c * n : nullptr, a.reg_scale, sm, sink, blk);
+                             blk == 0 ? a.dbiasrows + (int64_t)c * n : nullptr, reg_c, sm, sink, blk, n_real);
       TAIL_T1(0);
       return;
     }
@@ -135,8 +138,8 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
       dbr = rows;
       scratch = sm + a.lay.n_obj * 128;
     }
-    latent_bwd_block(a.theta_in + (int64_t)c * P, a.lay, a.zl + (int64_t)c * a.lay.n_obj * 128, dbr, a.reg_scale,
-                     scratch, sink, blk, a.NL, false);
+    latent_bwd_block(a.theta_in + (int64_t)c * P, a.lay, a.zl + (int64_t)c * a.lay.n_obj * 128, dbr, reg_c,
+                     scratch, sink, blk, a.NL, false, n_real);
     return;
   }
   b -= nlat;
@@ -249,7 +252,8 @@ extern "C" int cnr_step_tail(const float* theta_in, float* theta_out, float* gra
                              float weight_decay, const int64_t* state_cur, int64_t* state_next, int64_t add_rows,
                              const void* rl_workspace, float* losses, int32_t* flags, const float* depth,
                              int64_t pool_rows, const int* perm, float* next_max_bound, int R, const void* records,
-                             int nwg, const long long* rows_fix, int rl_blocks, int* clamp_flags, void* stream) {
+                             int nwg, const long long* rows_fix, int rl_blocks, int* clamp_flags, const int* n_obj_cls,
+                             void* stream) {
   if (!theta_in || !theta_out || theta_in == theta_out || !grad || !exp_avg || !exp_avg_sq || class_stride <= 0 ||
       L <= 0 || n_obj <= 0 || C <= 0 || !state_cur || !state_next || state_cur == state_next || !rl_workspace ||
       !losses || !flags || R <= 0)
@@ -262,7 +266,7 @@ extern "C" int cnr_step_tail(const float* theta_in, float* theta_out, float* gra
   TailArgs a{};
   a.theta_in = theta_in; a.theta_out = theta_out; a.grad = grad; a.m = exp_avg; a.v = exp_avg_sq;
   a.lay = FlatLayout{class_stride, off_latW, off_latb, off_shape, off_tex, L, n_obj};
-  a.off_B = off_B; a.C = C; a.zl = zl; a.dbiasrows = dbiasrows; a.reg_scale = n_obj > 1 ? reg_scale : 0.0f;
+  a.off_B = off_B; a.C = C; a.zl = zl; a.dbiasrows = dbiasrows; a.reg_scale = reg_scale; a.n_obj_cls = n_obj_cls;
   a.lr = lr; a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.wd = weight_decay;
   a.state_cur = state_cur; a.state_next = state_next; a.add_rows = add_rows;
   const int rpb = cnr_rl::rl_rays_per_block(C, R);
@@ -293,7 +297,7 @@ extern "C" int cnr_step_tail(const float* theta_in, float* theta_out, float* gra
 extern "C" int cnr_step_grad(const float* theta, float* grad, int64_t class_stride, int64_t off_B, int64_t off_latW,
                              int64_t off_latb, int64_t off_shape, int64_t off_tex, int L, int n_obj, int C,
                              const float* zl, float* dbiasrows, float reg_scale, const void* records, int nwg,
-                             const long long* rows_fix, void* stream) {
+                             const long long* rows_fix, const int* n_obj_cls, void* stream) {
   if (!theta || !grad || class_stride <= 0 || L <= 0 || n_obj <= 0 || C <= 0 || !zl || !dbiasrows || !records ||
       nwg <= 0 || !rows_fix)
     return CNR_E_ARG;
@@ -301,7 +305,7 @@ extern "C" int cnr_step_grad(const float* theta, float* grad, int64_t class_stri
   TailArgs a{};
   a.theta_in = theta; a.grad = grad;
   a.lay = FlatLayout{class_stride, off_latW, off_latb, off_shape, off_tex, L, n_obj};
-  a.off_B = off_B; a.C = C; a.zl = zl; a.dbiasrows = dbiasrows; a.reg_scale = n_obj > 1 ? reg_scale : 0.0f;
+  a.off_B = off_B; a.C = C; a.zl = zl; a.dbiasrows = dbiasrows; a.reg_scale = reg_scale; a.n_obj_cls = n_obj_cls;
   a.do_latent = 1; a.grad_only = 1;
   const int64_t nlat_out = (int64_t)4 * 32 * L + 128 + (int64_t)2 * n_obj * L;
   a.NL = (int)((nlat_out + 255) / 256);

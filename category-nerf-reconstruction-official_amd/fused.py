@@ -93,8 +93,15 @@ class FusedCategoryTrainer:
                  grad_scale=None, bwd_blocks=0, process_group=None, use_graph=True, split_graph=False,
                  fuse_render=True, split_weights=None, shard=None, n_cls_global=None, class_ids=None,
                  check_every=0, world_frame=None, dp_rank=None, dp_world=None, one_launch=None):
+        # n_obj: one count for every class, or one per (local) class -- the reference's categories differ (train.py:92-96).  The
+        # flat layout uses the largest; a smaller class keeps unused rows (no ray refers to them, no regulariser on them)
+        n_obj_list = [int(n_obj)] * n_cls if isinstance(n_obj, int) else [int(v) for v in n_obj]
+        assert len(n_obj_list) == n_cls and min(n_obj_list) >= 1
+        n_obj = max(n_obj_list)
+        self.n_obj_list = n_obj_list
         self.cfg, self.C, self.n_obj, self.R = cfg, n_cls, n_obj, rays_per_step
         self.device = torch.device(device)
+        self.n_obj_cls = None if min(n_obj_list) == n_obj else torch.tensor(n_obj_list, device=self.device, dtype=torch.int32)
         self.n1, self.n2 = cfg.n_bins_cam2surface, cfg.n_bins
         self.S = self.n1 + self.n2
         self.L = cfg.net_hyperparams["latent_dim"]
@@ -148,7 +155,7 @@ class FusedCategoryTrainer:
         # reference does that for single-object categories: origin_dirs_W on T_wc, src/scene_cateogries.py:427-432) keeps
         # inv(T_wc) in the pose slot: the sampler's origin_dirs_O inverts it back (rigid, so exact to fp32 rounding)
         if world_frame is None:
-            world_frame = n_obj == 1 and all("T_wc" in p for p in pools)
+            world_frame = [k == 1 and "T_wc" in p for k, p in zip(n_obj_list, pools)]
         self.world_frame = [bool(world_frame)] * n_cls if isinstance(world_frame, (bool, int)) else [bool(w) for w in world_frame]
         st = lambda k: torch.stack([p[k] for p in pools]).to(self.device).contiguous()
         T = torch.stack([torch.linalg.inv(p["T_wc"]) if wf else p["T_co"] for p, wf in zip(pools, self.world_frame)])
@@ -301,9 +308,9 @@ class FusedCategoryTrainer:
             if self.use_records:                 # record reduction + latent backward in one launch, gradient only
                 _C.call("cnr_step_grad", self.theta, self.grad, lay.total, lay.B[0], lay.latW[0], lay.latb[0],
                         lay.shape[0], lay.tex[0], L, n_obj, C, zl, self.dbias, self._reg, o["bwd_ws"], self._nwg,
-                        self.rows_fix)
+                        self.rows_fix, self.n_obj_cls)
             else:
-                _C.call("cnr_latent_bwd", self.theta, *lat_args, zl, self.dbias, self._reg, self.grad)
+                _C.call("cnr_latent_bwd", self.theta, *lat_args, zl, self.dbias, self._reg, self.grad, self.n_obj_cls)
 
     def _step_back(self):
         """Last launch (cnr_step_tail): the fixed-order reduction of the field backward's records (single GPU, <= 7
@@ -319,7 +326,7 @@ class FusedCategoryTrainer:
                 self.d_state2[par], self.d_state2[1 - par], self.Rg, o["rl_ws"], self.losses, self.flags,
                 None, self.pool_rows, None, None, R,
                 o["bwd_ws"] if self.fused_tail else None, self._nwg if self.fused_tail else 0,
-                self.rows_fix if self.fused_tail else None, self._ft_blocks or self._rl_blocks, self.clamp)
+                self.rows_fix if self.fused_tail else None, self._ft_blocks or self._rl_blocks, self.clamp, self.n_obj_cls)
 
     def step(self):
         """One train step.  Returns nothing; ``self.losses`` (3,C) / ``self.flags`` (C,) hold the device-side
@@ -480,8 +487,8 @@ class FusedCategoryTrainer:
             fc[n + ".weight"] = v["latW"][c, k].clone()
             fc[n + ".bias"] = v["latb"][c, k].clone()
         return dict(FC_state_dict=fc, PE_state_dict={"B_layer.weight": v["B"][c].clone(), "scale": torch.tensor(self.scale)},
-                    shape_code_state_dict={"weight": v["shape"][c].clone()},
-                    texture_code_state_dict={"weight": v["tex"][c].clone()}, obj_scale=self.scale)
+                    shape_code_state_dict={"weight": v["shape"][c, :self.n_obj_list[c]].clone()},
+                    texture_code_state_dict={"weight": v["tex"][c, :self.n_obj_list[c]].clone()}, obj_scale=self.scale)
 
     def load_state_dicts(self, d, c=0):
         """Inverse of :meth:`state_dicts` for local class ``c``: a checkpoint dict in the reference's key schema
@@ -498,7 +505,7 @@ class FusedCategoryTrainer:
                 v["latW"][c, k].copy_(fc[n + ".weight"])
                 v["latb"][c, k].copy_(fc[n + ".bias"])
             v["B"][c].copy_(d["PE_state_dict"]["B_layer.weight"])
-            v["shape"][c].copy_(d["shape_code_state_dict"]["weight"])
-            v["tex"][c].copy_(d["texture_code_state_dict"]["weight"])
+            v["shape"][c, :self.n_obj_list[c]].copy_(d["shape_code_state_dict"]["weight"])
+            v["tex"][c, :self.n_obj_list[c]].copy_(d["texture_code_state_dict"]["weight"])
         self.exp_avg[c].zero_()
         self.exp_avg_sq[c].zero_()

@@ -151,7 +151,10 @@ int cnr_latent_fwd(const float* theta, int64_t class_stride, int64_t off_latW, i
                    void* stream);
 int cnr_latent_bwd(const float* theta, int64_t class_stride, int64_t off_latW, int64_t off_latb,
                    int64_t off_shape, int64_t off_tex, int L, int n_obj, int C, const float* zl,
-                   const float* dbiasrows, float reg_scale, float* grad, void* stream);
+                   const float* dbiasrows, float reg_scale, float* grad, const int* n_obj_cls, void* stream);
+/* n_obj_cls (optional, (C,) int32 on the device; also cnr_step_tail / cnr_step_grad): the number of objects each class really
+ * has when classes differ (train.py:92-96): rows n_obj_cls[c] .. n_obj - 1 of class c are padding (no ray refers to them); the
+ * regulariser applies to a class's real rows, and only when it has more than one object (src/loss.py:5-15).  NULL: n_obj. */
 
 /* ================= fused f16-MFMA field path (a8 + a9 in one launch) ================================
  * Packed operand image per class, produced on device from the fp32 trunk blob: forward A fragments,
@@ -348,7 +351,7 @@ int cnr_step_tail(const float* theta_in, float* theta_out, float* grad, float* e
                   const int64_t* state_cur, int64_t* state_next, int64_t add_rows, const void* rl_workspace,
                   float* losses, int32_t* flags, const float* depth, int64_t pool_rows, const int* perm,
                   float* next_max_bound, int R, const void* records, int nwg, const long long* rows_fix,
-                  int rl_blocks, int* clamp_flags, void* stream);
+                  int rl_blocks, int* clamp_flags, const int* n_obj_cls, void* stream);
 /* clamp_flags (optional, (C,) int32, zero before the first step): what cnr_field_bwd_pipe raised during this step -- bit 4
  * (16) = a scaled upstream gradient |d sigma| * grad_scale exceeded 8192 and was clipped for the f16 chain; the epilogue
  * or-s the word into flags[c] and clears it. */
@@ -360,7 +363,7 @@ int cnr_step_tail(const float* theta_in, float* theta_out, float* grad, float* e
 int cnr_step_grad(const float* theta, float* grad, int64_t class_stride, int64_t off_B, int64_t off_latW,
                   int64_t off_latb, int64_t off_shape, int64_t off_tex, int L, int n_obj, int C, const float* zl,
                   float* dbiasrows, float reg_scale, const void* records, int nwg, const long long* rows_fix,
-                  void* stream);
+                  const int* n_obj_cls, void* stream);
 
 /* Same contract and results as cnr_field_bwd, ONE field kernel + the record reduction: each workgroup is
  * `chain_waves` waves that run forward recompute + data-gradient chain + PE backward for one 32-sample tile each,

@@ -388,3 +388,58 @@ def test_one_launch_step_equals_forward_render_plus_backward(cnr, dev, C, R, n1,
     for s in range(3):   # still the same training run two steps later (AdamW's sign-like first steps amplify rounding)
         assert torch.isfinite(res["one"][s]["grad"]).all()
         assert rel_l2(res["one"][s]["losses"], res["two"][s]["losses"]) < 2e-2
+
+
+def test_classes_with_different_object_counts_and_a_single_object_class(cnr, dev):
+    """The reference's categories differ (train.py:92-96): here one class with three objects (object frame, code
+    regulariser) and one with a single object (WORLD frame: origin_dirs_W on T_wc, no regulariser, src/scene_cateogries.py:
+    427-432, src/loss.py:5-15) in one fused trainer -- padded code rows, per-class regulariser switch, per-class frame --
+    against the oracle on the sampled batch, and a state_dicts / load_state_dicts round trip."""
+    C, R, n1, n2, L = 2, 512, 4, 28, 32
+    n_objs = [3, 1]
+    cfg = cnr.cfg.synthetic_config(device=str(dev), latent_dim=L, n_bins_cam2surface=n1, n_bins=n2)
+    gen = torch.Generator().manual_seed(8)
+    pools = [cnr.scene_cateogries.synthetic_pool(4 * R, k, gen, "cpu") for k in n_objs]
+    tr = cnr.fused.FusedCategoryTrainer(cfg, C, n_objs, pools, R, dev, seed=4, generator=gen, use_graph=False)
+    assert tr.n_obj == 3 and tr.world_frame == [False, True] and tr.n_obj_cls.tolist() == n_objs
+    theta0 = tr.theta.clone()
+    rows = tr.perm[:, :R].long().cpu()
+    tr.step()
+    torch.cuda.synchronize()
+    b = {k: v.cpu() for k, v in tr.bufs.items() if torch.is_tensor(v)}
+    # class 1's rays are in the world frame: pts = t_wc + R_wc d z (origin_dirs_W), to the rounding of inverting inv(T_wc)
+    T = pools[1]["T_wc"][rows[1]]
+    o_w, d_w = O.origin_dirs_W(T, pools[1]["dirs"][rows[1]])
+    assert rel_l2(b["pts"][1], o_w[:, None, :] + d_w[:, None, :] * b["z"][1][..., None]) < 1e-5
+    mlp, B, shape, tex = _oracle_params(cnr, tr, theta0)
+    mlp = {k: v.requires_grad_() for k, v in mlp.items()}
+    B.requires_grad_()
+    sh = [shape[c, :n_objs[c]].clone().requires_grad_() for c in range(C)]
+    tx = [tex[c, :n_objs[c]].clone().requires_grad_() for c in range(C)]
+    idx = torch.stack([pools[c]["indices"][rows[c]] for c in range(C)])
+    batch = dict(pts=b["pts"], z=b["z"], gt_depth=b["gt_depth"], gt_rgb=b["gt_rgb"], labels=b["labels"],
+                 depth_mask=b["depth_mask"].bool(), indices=idx)
+    loss, aux = O.forward_loss(mlp, B, cfg.obj_scale, sh, tx, batch)
+    loss.backward()
+    for k, name in enumerate(("loss_depth", "loss_color", "loss_opacity")):
+        assert rel_l2(tr.losses[k].cpu(), aux[name]) < 2e-3, name
+    gk = tr.lay.views(tr.grad.cpu())
+    for c in range(C):
+        k = n_objs[c]
+        assert rel_l2(gk["shape"][c, :k], sh[c].grad) < 0.1 and rel_l2(gk["tex"][c, :k], tx[c].grad) < 0.1, c
+        assert float(gk["shape"][c, k:].abs().sum()) == 0.0 and float(gk["tex"][c, k:].abs().sum()) == 0.0   # padding rows
+    # the single-object class carries no regulariser: its code gradient is the data term alone -- with the three-object
+    # class's reg_scale code / |code| on top it would be off by ~50 % here
+    assert rel_l2(gk["latW"], torch.stack([mlp[n + ".weight"].grad for n in cnr.ops.LATENT_LAYERS], 1)) < 0.1
+    assert rel_l2(gk["B"], B.grad) < 0.1
+    # export / import of one class in the reference's checkpoint keys (codes: the class's real rows only)
+    sd = tr.state_dicts(1)
+    assert sd["shape_code_state_dict"]["weight"].shape == (1, L)
+    tr2 = cnr.fused.FusedCategoryTrainer(cfg, C, n_objs, pools, R, dev, seed=9, generator=torch.Generator().manual_seed(99),
+                                         use_graph=False)
+    assert not torch.equal(tr2.theta[1], tr.theta[1])
+    tr2.load_state_dicts(sd, 1)
+    v1, v2 = tr.lay.views(tr.theta), tr2.lay.views(tr2.theta)
+    for k in ("trunk", "latW", "latb", "B"):
+        assert torch.equal(v1[k][1], v2[k][1]), k
+    assert torch.equal(v1["shape"][1, :1], v2["shape"][1, :1]) and torch.equal(v1["tex"][1, :1], v2["tex"][1, :1])
