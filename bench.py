@@ -123,6 +123,80 @@ def cpu_baseline(cfg_shape, seconds=12.0):
                       f"torch fp32 oracle with {cores} threads (best of 8/16/32/64/default on 3-step medians)"}
 
 
+def fp8_leg(args):
+    """configs[4] (8192 rays x 128 samples, fp8 weights on the CDNA4 fp8 MFMA): the field forward with 1 / 2 / 3 fp8 planes
+    against the f16 kernel -- samples/s (HIP events, back to back) and rendered-occupancy error against the CPU oracle on a
+    bounded sample.  The train step has no fp8 path: one plane is 60x outside north_star's 1e-3, the split that reaches it
+    costs nine MFMAs where f16 needs one."""
+    import cnr_amd
+    from oracle import ref_cpu as O
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    dev = torch.device("cuda", 0)
+    R, S, L, n_obj = (8192, 128, args.latent, 4) if args.rays == 2048 else (args.rays, args.samples, args.latent, 4)
+    gen = torch.Generator().manual_seed(1234)
+    theta, lay = cnr_amd.fused.init_params(1, L, n_obj, gen, dev)
+    v = lay.views(theta)
+    trunk = v["trunk"].contiguous()
+    packed = cnr_amd.ops.pack_weights(trunk)
+    zl, brows = torch.empty(n_obj, 4, 32, device=dev), torch.empty(n_obj, 4, 32, device=dev)
+    cnr_amd._C.call("cnr_latent_fwd", theta, lay.total, lay.latW[0], lay.latb[0], lay.shape[0], lay.tex[0], L, n_obj, 1, zl, brows)
+    pts = (torch.rand(1, R, S, 3, generator=gen) * 2 - 1).to(dev)
+    idx = torch.randint(0, n_obj, (1, R), generator=gen)
+    ray_row = idx.to(torch.int32).to(dev)
+    B = v["B"].contiguous()
+
+    def timed(fn, iters=20):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+    legs = {}
+    ms = timed(lambda: cnr_amd.ops.field_fwd(pts, B, packed, brows, ray_row, 2.0))
+    outs = {"f16": cnr_amd.ops.field_fwd(pts, B, packed, brows, ray_row, 2.0)}
+    legs["f16"] = {"ms": ms, "samples_per_s": R * S / (ms * 1e-3), "mfma_per_fragment": 1}
+    for t in (1, 2, 3):
+        p8 = torch.empty(1, int(cnr_amd._C.load().cnr_pack_fp8_bytes(t)), device=dev, dtype=torch.uint8)
+        cnr_amd._C.call("cnr_pack_weights_fp8", trunk, p8, 1, t)
+        sig, rgb = torch.empty(1, R, S, device=dev), torch.empty(1, R, S, 3, device=dev)
+        run = lambda: cnr_amd._C.call("cnr_field_fwd_fp8", pts, B, packed, p8, brows, ray_row, 2.0, sig, rgb, 1, R, S, 0, t)
+        ms = timed(run)
+        outs[f"fp8x{t}"] = (sig.clone(), rgb.clone())
+        legs[f"fp8_{t}_plane"] = {"ms": ms, "samples_per_s": R * S / (ms * 1e-3), "mfma_per_fragment": t * t}
+    # error against the oracle on the first 256 rays
+    n = min(R, 256)
+    th = theta.cpu()
+    vv = lay.views(th)
+    mlp, off = {}, 0
+    for name, o, i in cnr_amd.ops.TRUNK_LAYERS:
+        mlp[name + ".weight"] = vv["trunk"][:, off:off + o * i].reshape(1, o, i); off += o * i
+        mlp[name + ".bias"] = vv["trunk"][:, off:off + o]; off += o
+    for k, name in enumerate(cnr_amd.ops.LATENT_LAYERS):
+        mlp[name + ".weight"], mlp[name + ".bias"] = vv["latW"][:, k], vv["latb"][:, k]
+    e = O.unidirs_embed(pts[:, :n].cpu(), vv["B"], 2.0)
+    cs, ct = vv["shape"][0][idx[0, :n]][None, :, None], vv["tex"][0][idx[0, :n]][None, :, None]
+    sig_ref, rgb_ref = O.codenerf_forward(mlp, e, cs, ct)
+    occ_ref = torch.sigmoid(sig_ref.squeeze(-1))
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    for k, (sg, rg) in outs.items():
+        key = "f16" if k == "f16" else f"fp8_{k[-1]}_plane"
+        legs[key]["occupancy_rel_l2_vs_oracle"] = rel(torch.sigmoid(sg[:, :n].cpu()), occ_ref)
+        legs[key]["rgb_rel_l2_vs_oracle"] = rel(rg[:, :n].cpu(), rgb_ref)
+    one = legs["fp8_1_plane"]
+    print(json.dumps({"metric": "samples/sec (field forward only, fp8 MFMA) -- BASELINE.json configs[4]; NOT the train-step metric",
+                      "value": one["samples_per_s"], "unit": "samples/s", "n_gpus": 1, "higher_is_better": True,
+                      "dtype": "fp8", "data": "synthetic", "vs_baseline": None,
+                      "config": {"workload": f"1 category x {n_obj} objects, {R} rays x {S} samples, latent {L}: PE + CodeNeRF forward, "
+                                             "OCP e4m3 weights and activations on v_mfma_f32_32x32x16_fp8_fp8"},
+                      "legs": legs,
+                      "note": "no fp8 train step: one fp8 plane misses the 1e-3 parity bar by ~60x; three planes meet it at nine MFMAs per "
+                              "fragment where the f16 kernel needs one of the same rate"}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -136,6 +210,9 @@ def main():
                     help="N > 1: 'class' = every GPU owns whole categories, no gradient collective (north_star's "
                          "per-category sharding); 'ray' = the rays of every category are split, one all-reduce per step")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--dtype", choices=("f16", "fp8"), default="f16",
+                    help="fp8: BASELINE.json configs[4] -- forward-only throughput and error of the fp8-MFMA field forward "
+                         "(there is no fp8 train step: see DESIGN.md section 3.4); prints its own JSON line")
     ap.add_argument("--bwd-blocks", type=int, default=0)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -143,6 +220,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
+    if args.dtype == "fp8":
+        return fp8_leg(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -62,6 +62,9 @@ SIGNATURES = {
     "cnr_field_fwd_render_workspace_bytes": [_i, _i, _i],
     "cnr_field_fwd_render": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp,
                              _vp, _i, _i, _i, _i64, _vp, _i64, _vp, _vp, _vp, _vp],
+    "cnr_pack_fp8_bytes": [_i],
+    "cnr_pack_weights_fp8": [_vp, _vp, _i, _i, _vp],
+    "cnr_field_fwd_fp8": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i64, _i, _vp],
     "cnr_field_train_blocks": [_i, _i, _i],
     "cnr_field_train_workspace_bytes": [_i, _i, _i, _i],
     "cnr_field_train": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _vp, _vp, _vp, _vp,
@@ -74,7 +77,7 @@ SIGNATURES = {
     "cnr_step_epilogue": [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i, _i, _vp],
 }
 _RESTYPE64 = {"cnr_pack_bytes", "cnr_pack_lo_bytes", "cnr_field_bwd_workspace_bytes", "cnr_render_loss_workspace_bytes",
-              "cnr_dense_bwd_workspace_bytes", "cnr_field_fwd_render_workspace_bytes", "cnr_field_train_workspace_bytes"}
+              "cnr_dense_bwd_workspace_bytes", "cnr_field_fwd_render_workspace_bytes", "cnr_field_train_workspace_bytes", "cnr_pack_fp8_bytes"}
 
 _lib = None
 _double = None

@@ -79,6 +79,27 @@ __host__ __device__ inline int slot_feature(int part, int h, int q) {
 __host__ __device__ inline int acc_feature(int s, int h, int j) { return 16 * s + 8 * (j >> 2) + 4 * h + (j & 3); }
 // accumulator row of (reg, h)
 __host__ __device__ inline int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+// element A[r][k] of forward weight fragment kk (k-step of 16, K permuted as above) for lane half h, element j ; 0 = padding
+__device__ __forceinline__ float fwd_elem(const float* __restrict__ Wt, int kk, int r, int h, int j) {
+    int s, w_off, ld, out, col = -1;
+  if (kk < KK_S1) { s = kk - KK_XYZ; w_off = OFF_XYZ_W; ld = E1; out = 32;
+    const int f = slot_feature(0, h, 8 * s + j); col = f; }
+  else if (kk < KK_CAT) { s = kk - KK_S1; w_off = OFF_S1_W; ld = 32; out = 32; col = acc_feature(s, h, j); }
+  else if (kk < KK_S2) { s = kk - KK_CAT; w_off = OFF_CAT_W; ld = 32 + E1; out = 32;
+    if (s < 2) col = acc_feature(s, h, j);
+    else { const int f = slot_feature(0, h, 8 * (s - 2) + j); col = f < 0 ? -1 : 32 + f; } }
+  else if (kk < KK_ES) { s = kk - KK_S2; w_off = OFF_S2_W; ld = 32; out = 32; col = acc_feature(s, h, j); }
+  else if (kk < KK_VD) { s = kk - KK_ES; w_off = OFF_ES_W; ld = 32; out = 32; col = acc_feature(s, h, j); }
+  else if (kk < KK_T1) { s = kk - KK_VD; w_off = OFF_VD_W; ld = 32 + E2; out = 32;
+    if (s < 2) col = acc_feature(s, h, j);
+    else { const int f = slot_feature(1, h, 8 * (s - 2) + j); col = f < 0 ? -1 : 32 + (f - E1); } }
+  else if (kk < KK_R0) { s = kk - KK_T1; w_off = OFF_T1_W; ld = 32; out = 32; col = acc_feature(s, h, j); }
+  else if (kk < KK_R2) { s = kk - KK_R0; w_off = OFF_R0_W; ld = 32; out = 16; col = acc_feature(s, h, j); }
+  else { s = 0; w_off = OFF_R2_W; ld = 16; out = 3; col = acc_feature(0, h, j); }
+  if (col < 0 || r >= out) return 0.0f;
+  return Wt[w_off + r * ld + col];
+}
+
 // ---------------------------------------------------------------------------------------------------
 // device helpers
 // ---------------------------------------------------------------------------------------------------

@@ -22,27 +22,6 @@ using namespace fz;
 // ---------------------------------------------------------------------------------------------------
 struct LayerRef { int w_off, ld, out; };
 
-__device__ __forceinline__ float fwd_elem(const float* __restrict__ Wt, int kk, int r, int h, int j) {
-  // A[r][k] of forward k-step kk ; returns 0 for padding
-  int s, w_off, ld, out, col = -1;
-  if (kk < KK_S1) { s = kk - KK_XYZ; w_off = OFF_XYZ_W; ld = E1; out = 32;
-    const int f = slot_feature(0, h, 8 * s + j); col = f; }
-  else if (kk < KK_CAT) { s = kk - KK_S1; w_off = OFF_S1_W; ld = 32; out = 32; col = acc_feature(s, h, j); }
-  else if (kk < KK_S2) { s = kk - KK_CAT; w_off = OFF_CAT_W; ld = 32 + E1; out = 32;
-    if (s < 2) col = acc_feature(s, h, j);
-    else { const int f = slot_feature(0, h, 8 * (s - 2) + j); col = f < 0 ? -1 : 32 + f; } }
-  else if (kk < KK_ES) { s = kk - KK_S2; w_off = OFF_S2_W; ld = 32; out = 32; col = acc_feature(s, h, j); }
-  else if (kk < KK_VD) { s = kk - KK_ES; w_off = OFF_ES_W; ld = 32; out = 32; col = acc_feature(s, h, j); }
-  else if (kk < KK_T1) { s = kk - KK_VD; w_off = OFF_VD_W; ld = 32 + E2; out = 32;
-    if (s < 2) col = acc_feature(s, h, j);
-    else { const int f = slot_feature(1, h, 8 * (s - 2) + j); col = f < 0 ? -1 : 32 + (f - E1); } }
-  else if (kk < KK_R0) { s = kk - KK_T1; w_off = OFF_T1_W; ld = 32; out = 32; col = acc_feature(s, h, j); }
-  else if (kk < KK_R2) { s = kk - KK_R0; w_off = OFF_R0_W; ld = 32; out = 16; col = acc_feature(s, h, j); }
-  else { s = 0; w_off = OFF_R2_W; ld = 16; out = 3; col = acc_feature(0, h, j); }
-  if (col < 0 || r >= out) return 0.0f;
-  return Wt[w_off + r * ld + col];
-}
-
 __device__ __forceinline__ float bwd_elem(const float* __restrict__ Wt, int kt, int r, int h, int j) {
   // A[r][k] of the transposed product: r = input feature (or E slot row), k = output feature
   int s, w_off, ld, out, in_col = -1;

@@ -405,6 +405,19 @@ def field_fwd(pts, B, packed, biasrows, ray_row, scale, packed_lo=None):
     return sig, rgb
 
 
+def field_fwd_fp8(pts, B, trunk, packed, biasrows, ray_row, scale, terms=1):
+    """BASELINE.json configs[4]: cnr_field_fwd on the fp8 matrix instruction (OCP e4m3 weights AND activations, `terms`
+    residual planes each); forward only.  trunk (C,13892) fp32, packed = pack_weights(trunk) (for its fp32 constants)."""
+    C, R, S, _ = pts.shape
+    p8 = torch.empty(C, int(_C.load().cnr_pack_fp8_bytes(int(terms))), device=pts.device, dtype=torch.uint8)
+    _C.call("cnr_pack_weights_fp8", trunk.contiguous(), p8, C, int(terms))
+    sig = torch.empty(C, R, S, device=pts.device, dtype=torch.float32)
+    rgb = torch.empty(C, R, S, 3, device=pts.device, dtype=torch.float32)
+    _C.call("cnr_field_fwd_fp8", pts.contiguous(), B.contiguous(), packed, p8, biasrows.contiguous(), ray_row,
+            float(scale), sig, rgb, C, R, S, 0, int(terms))
+    return sig, rgb
+
+
 class FusedFieldFn(Function):
     """pts (C,R,S,3), B (C,21,3), trunk (C,13892), biasrows (C*rows,4,32) -> sigmas (C,R,S), rgbs (C,R,S,3)
     on the f16-MFMA kernels; backward = cnr_field_bwd (recompute).  ray_row (C,R) int32 or None,

@@ -386,6 +386,19 @@ int cnr_field_bwd_pipe(const float* pts, const float* B, const void* packed, con
                        int64_t dtrunk_stride, int64_t dB_stride, long long* rows_fix, int skip_reduce,
                        int* clamp_flags, void* stream);
 
+/* ---- BASELINE.json configs[4]: the field forward on the gfx950 fp8 matrix instruction (v_mfma_f32_32x32x16_fp8_fp8) ----
+ * Same contract as cnr_field_fwd with OCP e4m3 operands: weights as `terms` fp8 planes of 64 W (plane p = fp8 of what planes
+ * 0..p-1 left over), activations / PE features as `terms` planes of 16 x formed on the fly, terms^2 MFMAs per fragment into
+ * one fp32 accumulator, fp32 sigma head.  terms in {1, 2, 3}.  `packed` is the f16 image (its fp32 constants are used),
+ * `packed8` = (C, cnr_pack_fp8_bytes(terms)) from cnr_pack_weights_fp8.  Forward only: measured against the oracle, terms = 1
+ * is 6e-2 on occupancy (60x outside the 1e-3 bar), 2 -> 1.8e-3, 3 -> 1.5e-4, while the f16 kernel's ONE MFMA of the same
+ * rate gives 7e-4 -- which is why the train step stays on f16. */
+int64_t cnr_pack_fp8_bytes(int terms);
+int cnr_pack_weights_fp8(const float* trunk, void* packed8, int C, int terms, void* stream);
+int cnr_field_fwd_fp8(const float* pts, const float* B, const void* packed, const void* packed8, const float* biasrows,
+                      const int* ray_row, float scale, float* sigmas, float* rgbs, int C, int R, int S, int64_t B_stride,
+                      int terms, void* stream);
+
 /* ---- the step body in ONE launch: cnr_field_fwd_render + cnr_field_bwd_pipe (chain_waves = 4) fused ---------------------
  * a8-a15 forward, the loss gradient and the whole field backward (train.py:154-182 for the object branch) with ONE field
  * forward per sample (cnr_field_bwd_pipe recomputes it), no d sigma / d colour round trip through HBM and one launch less.
