@@ -427,3 +427,31 @@ def test_field_bwd_is_linear_in_the_upstream_gradients(cnr, dev, C, R, S):
     ga, gb = run(a_s, a_c), run(b_s, b_c)
     assert rel_l2(run(2 * a_s, 2 * a_c), 2 * ga) < 1e-4
     assert rel_l2(run(a_s + b_s, a_c + b_c), ga + gb) < 2e-3
+
+
+def test_loss_scale_clamp_is_reported(cnr, dev):
+    """The f16 data-gradient chain needs |d sigma| * grad_scale <= 8192; beyond that the value is clipped (a ray whose
+    termination collapsed to one sample: var -> 0, info -> 1e4) and the clip is REPORTED in bit 4 of the class's flag word
+    (cnr_field_bwd_pipe's clamp_flags, or-ed into the step's flags by cnr_step_tail).  No hit: the word stays zero."""
+    ops, _C = cnr.ops, cnr._C
+    C, R, S, n_obj, L = 2, 64, 32, 4, 32
+    gen = torch.Generator().manual_seed(1)
+    theta, lay = cnr.fused.init_params(C, L, n_obj, gen, dev)
+    v = lay.views(theta)
+    packed = ops.pack_weights(v["trunk"].contiguous())
+    B = v["B"].contiguous()
+    pts = torch.rand(C, R, S, 3, device=dev) * 2 - 1
+    brows = torch.randn(C * n_obj, 4, 32, device=dev) * 0.1
+    ray_row = (torch.randint(0, n_obj, (C, R), device=dev) + torch.arange(C, device=dev)[:, None] * n_obj).to(torch.int32)
+    wsp = torch.empty(_C.field_bwd_workspace_bytes(C, 0), device=dev, dtype=torch.uint8)
+    z = lambda *s_: torch.zeros(*s_, device=dev)
+    for big_class in (None, 1):
+        dsig = torch.randn(C, R, S, device=dev) * 1e-3
+        if big_class is not None:
+            dsig[big_class, 5, 7] = 9.0                       # x 2048 = 18432 > 8192
+        clamp = torch.zeros(C, device=dev, dtype=torch.int32)
+        ops.field_bwd(pts, B, packed, brows, ray_row, 2.0, dsig, z(C, R, S, 3), 2048.0, z(C, 13892), z(C, 21, 3),
+                      z(C * n_obj, 4, 32), C, R, S, n_obj, 0, wsp, variant="pipe4", clamp_flags=clamp)
+        torch.cuda.synchronize()
+        want = [0, 0] if big_class is None else [0, 16]
+        assert clamp.tolist() == want, clamp.tolist()

@@ -63,6 +63,24 @@ def test_ray_shards_add_up_to_the_single_gpu_step(cnr, dev, world):
         assert int(ranks[1].d_state[0]) == int(one.d_state[0]) + R
 
 
+def test_sixteen_classes_on_two_ranks(cnr, dev):
+    """BASELINE.json configs[2] ("all categories": 16 classes x 4 objects, the survey's stand-in) split 8 + 8 over two class
+    shards: same bits as the single-GPU run of all sixteen."""
+    C, R, n_obj, L, world = 16, 128, 4, 32, 2
+    one = build(cnr, dev, "class", 0, 1, None, C, R, n_obj, L, False)
+    ranks = [build(cnr, dev, "class", r, world, None, C, R, n_obj, L, False) for r in range(world)]
+    flags = torch.stack([tr.counts_tab[:, tr.C, :3] for tr in ranks]).amax(0)
+    for tr in ranks:
+        tr.counts_tab[:, tr.C, :3] = flags
+    for _ in range(3):
+        one.step()
+        for tr in ranks:
+            tr.step()
+    torch.cuda.synchronize()
+    for tr in ranks:
+        assert tr.C == 8 and torch.equal(tr.theta, one.theta[tr.class_ids]) and torch.equal(tr.losses, one.losses[:, tr.class_ids])
+
+
 @pytest.mark.parametrize("empty_class", [None, 2])
 def test_class_shards_equal_the_single_gpu_step_bitwise(cnr, dev, empty_class):
     """Classes share nothing but the any-class-empty rule: rank r trains classes r, r + 2 with NO gradient exchange and
