@@ -11,6 +11,10 @@ constexpr int ROWS_LDS = 4;  // rows_per_class <= 4: what the 4-wave and block-s
 constexpr int ROWS_MAX = 7;
 constexpr int REC_FLOATS = ((TRUNK + 126 + ROWS_MAX * 128 + 255) / 256) * 256;  // one workgroup's record
 constexpr double ROWS_FIX_SCALE = 1099511627776.0;  // 2^40: bias-row sums as int64 fixed point (order-free atomics)
+#ifndef CNR_TAIL_EPB
+#define CNR_TAIL_EPB 64
+#endif
+constexpr int TAIL_EPB = CNR_TAIL_EPB;  // record entries per reducing block of the tail launch (256 / TAIL_EPB sub-ranges each)
 constexpr int ROWS_FIX_COPIES = 8;  // the table is replicated: a workgroup adds into copy (its index & 7), which
                                     // cuts the same-address atomic queue 8-fold; consumers add the copies (exact)
 

@@ -13,7 +13,7 @@
 //     per-object bias-row sums, from a fixed-point table the field backward filled with integer atomics (order-free,
 //     hence still bitwise reproducible) instead of waiting for that reduction.
 // grid: [ do_latent ? NL latent blocks per class : 0 ] [ NA AdamW blocks over the flat (C, P) buffer, or with records
-//        NR = REC_FLOATS / 64 reduce-and-update blocks per class ] [ C epilogue ].
+//        NR = REC_FLOATS / TAIL_EPB reduce-and-update blocks per class ] [ C epilogue ].
 // With do_latent = 0 (the gradient was completed by cnr_latent_bwd, e.g. before a multi-GPU all-reduce) the AdamW
 // blocks cover every parameter and nothing else changes.
 #include "adamw_common.h"
@@ -146,15 +146,19 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
   if (a.records) {  // ---- reduce 64 record entries of class c over all workgroups, finish the gradient, AdamW
     if (b < a.NR * C) {
       const int c = b / a.NR, blk = b % a.NR;
-      float* rows = sm;                    // [n_obj * 128] bias-row gradient of the class
-      float* part = sm + a.lay.n_obj * 128;  // [4][64] (+ [4][64] for the second dB addend)
+      // EPB record entries per block, NQ = 256 / EPB sub-ranges of the workgroup range per entry: every thread sums
+      // nwg / NQ records.  Measured at configs[1] (256 records): EPB = 64 (two rounds of 32 loads per thread, 256-byte
+      // segments per wave load) 30.75 M rays/s; EPB = 32 29.9 M; EPB = 16 (one round, 64-byte segments, 4 x the blocks) 24.2 M
+      constexpr int EPB = cnr_rec::TAIL_EPB, NQ = 256 / EPB;
+      float* rows = sm;                      // [n_obj * 128] bias-row gradient of the class
+      float* part = sm + a.lay.n_obj * 128;  // [NQ][EPB] (+ [NQ][EPB] for the second dB addend)
       // only blocks that hold a latent-conditioned layer's weights or biases need the rows (block-uniform test)
-      const int lo = blk * 64, hi = lo + 64;
+      const int lo = blk * EPB, hi = lo + EPB;
       auto hits = [&](int off, int len) { return lo < off + len && hi > off; };
       if (hits(OFF_S1_W, 1056) || hits(OFF_CAT_W, 32 * (32 + E1) + 32) || hits(OFF_S2_W, 1056) || hits(OFF_T1_W, 1056))
         load_rows_fix(a, c, rows);
-      const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
-      const int i = blk * 64 + e;
+      const int e = threadIdx.x % EPB, q = threadIdx.x / EPB;
+      const int i = blk * EPB + e;
       // trunk entries and the first dB half own an output; the second dB half is the other addend of the first
       const bool owner = i < TRUNK + 63;
       float s0 = 0.0f, s1 = 0.0f;
@@ -162,16 +166,27 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
       float p0 = 0.f, m0 = 0.f, v0 = 0.f;
       if (q == 0 && owner && !a.grad_only) { p0 = a.theta_in[idx]; m0 = a.m[idx]; v0 = a.v[idx]; }   // in flight under the record sum
       if (owner) {
-        const int per = (a.nwg + 3) / 4, w0 = q * per, w1 = min(a.nwg, w0 + per);
+        const int per = (a.nwg + NQ - 1) / NQ, w0 = q * per, w1 = min(a.nwg, w0 + per);
         const float* r = a.records + (size_t)c * a.nwg * cnr_rec::REC_FLOATS + i;
         if (cnr_rec::rec_entry_written(i, a.lay.n_obj)) s0 = cnr_rec::record_range_sum(r, w0, w1);
         if (i >= TRUNK) s1 = cnr_rec::record_range_sum(r + 63, w0, w1);
       }
-      part[q * 64 + e] = s0; part[256 + q * 64 + e] = s1;
+      part[q * EPB + e] = s0; part[256 + q * EPB + e] = s1;
       __syncthreads();
       if (q == 0 && owner) {
-        float g = (part[e] + part[64 + e]) + (part[128 + e] + part[192 + e]);
-        if (i >= TRUNK) g += (part[256 + e] + part[320 + e]) + (part[384 + e] + part[448 + e]);
+        auto tree = [&](const float* pp) {       // fixed-order pairwise sum of the NQ partials of entry e
+          float t[NQ];
+#pragma unroll
+          for (int k = 0; k < NQ; ++k) t[k] = pp[k * EPB + e];
+#pragma unroll
+          for (int st = NQ / 2; st >= 1; st >>= 1) {
+#pragma unroll
+            for (int k = 0; k < st; ++k) t[k] += t[k + st];
+          }
+          return t[0];
+        };
+        float g = tree(part);
+        if (i >= TRUNK) g += tree(part + 256);
         if (i < TRUNK) g += latent_trunk_term(i, a.zl + (int64_t)c * a.lay.n_obj * 128, rows, a.lay.n_obj);
         a.grad[idx] = g;
         if (!a.grad_only) {
@@ -281,7 +296,7 @@ extern "C" int cnr_step_tail(const float* theta_in, float* theta_out, float* gra
   int64_t na = (n + 255) / 256;
   if (na > 2048) na = 2048;
   a.NA = (int)na;
-  a.records = (const float*)records; a.nwg = nwg; a.rows_fix = rows_fix; a.NR = cnr_rec::REC_FLOATS / 64;
+  a.records = (const float*)records; a.nwg = nwg; a.rows_fix = rows_fix; a.NR = cnr_rec::REC_FLOATS / cnr_rec::TAIL_EPB;
   a.clamp_flags = clamp_flags;
   const unsigned grid = (unsigned)((a.do_latent ? a.NL * C : 0) + (records ? a.NR * C : a.NA) + C);
   const size_t lds = (size_t)(2 * n_obj * 128 + 2 * n_obj + 520) * sizeof(float);
@@ -310,7 +325,7 @@ extern "C" int cnr_step_grad(const float* theta, float* grad, int64_t class_stri
   const int64_t nlat_out = (int64_t)4 * 32 * L + 128 + (int64_t)2 * n_obj * L;
   a.NL = (int)((nlat_out + 255) / 256);
   if (a.NL > 256) a.NL = 256;
-  a.records = (const float*)records; a.nwg = nwg; a.rows_fix = rows_fix; a.NR = cnr_rec::REC_FLOATS / 64;
+  a.records = (const float*)records; a.nwg = nwg; a.rows_fix = rows_fix; a.NR = cnr_rec::REC_FLOATS / cnr_rec::TAIL_EPB;
   const unsigned grid = (unsigned)(a.NL * C + a.NR * C);
   const size_t lds = (size_t)(2 * n_obj * 128 + 2 * n_obj + 520) * sizeof(float);
   hipLaunchKernelGGL(tail_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
