@@ -443,3 +443,29 @@ def test_classes_with_different_object_counts_and_a_single_object_class(cnr, dev
     for k in ("trunk", "latW", "latb", "B"):
         assert torch.equal(v1[k][1], v2[k][1]), k
     assert torch.equal(v1["shape"][1, :1], v2["shape"][1, :1]) and torch.equal(v1["tex"][1, :1], v2["tex"][1, :1])
+
+
+@pytest.mark.parametrize("C,R,slices,perm_on", [(1, 2048, 7, True), (3, 100, 5, False), (9, 33, 4, True)])
+def test_slice_mask_count_table_against_torch(cnr, dev, C, R, slices, perm_on):
+    """cnr_slice_maskcounts: per slice and class #(valid depth & label != 0), #(label != 0), #(label != 2) and the
+    any-class-empty flags (src/render_rays.py:66-72, src/loss.py:24-26) -- bit-exact against torch and against
+    parallel.mask_count_table, including a slice in which one class has no ray on its object."""
+    _C = cnr._C
+    gen = torch.Generator().manual_seed(C * R)
+    pool_rows = slices * R + 17
+    pools = [cnr.scene_cateogries.synthetic_pool(pool_rows, 4, gen, "cpu") for _ in range(C)]
+    pools[C - 1]["rgbs"][:, 3] = torch.where(torch.arange(pool_rows) < 2 * R, torch.zeros(pool_rows, dtype=torch.uint8),
+                                             pools[C - 1]["rgbs"][:, 3])           # without perm: slices 0, 1 of the last class are empty
+    st = lambda k: torch.stack([p[k] for p in pools]).to(dev).contiguous()
+    rgbs, depth = st("rgbs"), st("depth")
+    perm = torch.stack([torch.randperm(pool_rows, generator=gen) for _ in range(C)]).to(torch.int32).to(dev) if perm_on else None
+    tab = torch.empty(slices, C + 1, 4, device=dev)
+    _C.call("cnr_slice_maskcounts", rgbs, depth, perm, pool_rows, C, R, slices, 0.0, tab)
+    for s_ in range(slices):
+        rows = [(perm[c, s_ * R:(s_ + 1) * R].long() if perm_on else torch.arange(s_ * R, (s_ + 1) * R, device=dev)) for c in range(C)]
+        labels = torch.stack([rgbs[c][rows[c], 3] for c in range(C)]).cpu()
+        dmask = torch.stack([depth[c][rows[c]] > 0.0 for c in range(C)]).cpu()
+        want = cnr.parallel.mask_count_table(labels, dmask)
+        assert torch.equal(tab[s_].cpu(), want), s_
+    if not perm_on:
+        assert tab[0, C, 0] == 1 and tab[0, C, 1] == 1 and tab[slices - 1, C, 1] == 0
