@@ -314,8 +314,8 @@ def main():
 
     # ---- roofline leg: the dominant kernel (fused backward) timed with HIP events on its launch stream ----
     bwd_name = "cnr_field_bwd" if cnr_amd.ops.FIELD_BWD_VARIANT == "split" else "cnr_field_bwd_pipe"
-    names = [bwd_name, "cnr_field_train", "cnr_field_fwd", "cnr_field_fwd_render", "cnr_step_prologue", "cnr_param_prep",
-             "cnr_render_loss", "cnr_step_tail", "cnr_step_grad"]
+    names = [bwd_name, "cnr_field_train", "cnr_field_fwd", "cnr_field_fwd_render", "cnr_step_prologue", "cnr_render_loss",
+             "cnr_step_tail", "cnr_step_grad"]
     tr.use_graph = False                                           # eager so that events bracket single launches
     cnr_amd._C.enable_kernel_timing(names)
     for _ in range(min(args.steps, 50)):

@@ -22,7 +22,7 @@ SIGNATURES = {
     "cnr_sample_maxdepth": [_vp, _vp, _vp, _i64, _vp, _i, _i, _vp],
     "cnr_step_advance": [_vp, _i64, _vp],
     "cnr_sample_rays": [_vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64, _vp, _i64, _vp, _i, _i, _i, _i, _i, _f, _f, _f,
-                        _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+                        _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp],
     "cnr_latent_fwd": [_vp, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _vp, _vp, _vp],
     "cnr_latent_bwd": [_vp, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp],
     "cnr_pe_fwd": [_vp, _vp, _vp, _i, _i64, _f, _vp],
@@ -56,7 +56,7 @@ SIGNATURES = {
     "cnr_adamw_epilogue": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64,
                            _vp, _vp, _i, _i, _vp],
     "cnr_step_tail": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _vp, _vp, _f, _i, _f, _f, _f,
-                      _f, _f, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp],
+                      _f, _f, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp],
     "cnr_step_grad": [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _vp, _vp, _f, _vp, _i, _vp, _vp, _vp],
     "cnr_field_fwd_render_blocks": [_i, _i],
     "cnr_field_fwd_render_workspace_bytes": [_i, _i, _i],
@@ -78,25 +78,6 @@ SIGNATURES = {
 }
 _RESTYPE64 = {"cnr_pack_bytes", "cnr_pack_lo_bytes", "cnr_field_bwd_workspace_bytes", "cnr_render_loss_workspace_bytes",
               "cnr_dense_bwd_workspace_bytes", "cnr_field_fwd_render_workspace_bytes", "cnr_field_train_workspace_bytes", "cnr_pack_fp8_bytes"}
-
-class SampleDesc(ctypes.Structure):
-    """cnr_sample_desc of include/cnr_hip.h (field for field)."""
-    _fields_ = [("rgbs", _vp), ("depth", _vp), ("dirs_c", _vp), ("T", _vp), ("seed", _u64), ("offset", _u64),
-                ("pool_rows", _i64), ("max_bound", _vp), ("max_bound_slices", _i), ("world_frame", _i), ("R", _i),
-                ("n1", _i), ("n2", _i), ("eps", _f), ("stop_eps", _f), ("min_bound", _f), ("z", _vp), ("pts", _vp),
-                ("gt_rgb", _vp), ("gt_depth", _vp), ("depth_mask", _vp), ("labels", _vp), ("pool_indices", _vp),
-                ("n_obj", _i), ("ray_row", _vp), ("perm", _vp), ("rng_c0", _i), ("rng_cstride", _i), ("rng_R", _i),
-                ("rng_r0", _i)]
-
-
-def sample_desc(**kw):
-    """Build a cnr_sample_desc from tensors (device pointers) and scalars; keeps the tensors alive on the object."""
-    d = SampleDesc()
-    d._keep = kw
-    for k, v in kw.items():
-        setattr(d, k, v.data_ptr() if torch.is_tensor(v) else v)
-    return d
-
 
 _lib = None
 _double = None
@@ -158,8 +139,6 @@ def call(name, *args):
     for a in args:
         if torch.is_tensor(a):
             conv.append(_ptr(a))
-        elif isinstance(a, ctypes.Structure):
-            conv.append(ctypes.addressof(a))       # a host-side descriptor, read during the call
         else:
             conv.append(a)
     # trailing arguments a caller leaves out are the optional ones the C-ABI grew over time: NULL / 0

@@ -677,8 +677,7 @@ extern "C" int cnr_step_prologue(
   const int nsample = (R + 3) / 4;
   cnr_sample::SampleArgs sa{rgbs, depth, dirs_c, T, u, g, seed, offset, d_state, pool_rows, max_bound, world_frame,
                             C, R, n1, n2, eps, stop_eps, min_bound, z, pts, origins, dirs_o, gt_rgb, gt_depth,
-                            depth_mask, labels, pool_indices, n_obj, ray_row, perm, max_bound_slices, rng_c0, rng_cstride, rng_R, rng_r0,
-                            0, 0};
+                            depth_mask, labels, pool_indices, n_obj, ray_row, perm, max_bound_slices, rng_c0, rng_cstride, rng_R, rng_r0};
   dim3 grid(fz::NKK_FWD + fz::NKK_BWD + 1 + 4 * n_obj + nzero + nsample, (unsigned)C);
   hipLaunchKernelGGL(param_prep_kernel, grid, dim3(256), 0, (hipStream_t)stream, theta, lay, off_trunk,
                      (unsigned char*)packed, zl, biasrows, zero_buf, zero_count, nzero, sa, nsample);

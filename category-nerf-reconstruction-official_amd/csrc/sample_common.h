@@ -19,9 +19,6 @@ struct SampleArgs {
   // (rng_R = global rays per class, rng_r0 = this rank's first ray) are sharded over GPUs, so that N ranks draw
   // exactly what one rank would.  All zero: the local index c * R + r.
   int rng_c0, rng_cstride, rng_R, rng_r0;
-  // sampling AHEAD (cnr_step_tail samples the NEXT step's rays): the cursor / rng step used are d_state[0] + cursor_add /
-  // d_state[1] + rng_add; a slice that would run past the pool (the host reshuffles before that step) is skipped
-  int64_t cursor_add; int rng_add;
 };
 
 
@@ -96,12 +93,10 @@ __device__ __forceinline__ void sample_ray(const SampleArgs& a, int64_t ray, int
   // pool row of this ray: either the slice itself (pool_rows == 0) or row cursor + r of a device-resident
   // (C, pool_rows, ...) pool whose cursor lives on the device (hipGraph replay advances it, no host work)
   int64_t prow = ray;
-  const int64_t cursor = pool_rows > 0 ? d_state[0] + a.cursor_add : 0;
   if (pool_rows > 0) {
-    if (cursor + R > pool_rows) return;                      // (wave-uniform) only when sampling ahead of an epoch end
-    prow = (int64_t)c * pool_rows + cursor + (ray - (int64_t)c * R);
+    prow = (int64_t)c * pool_rows + d_state[0] + (ray - (int64_t)c * R);
     if (perm) prow = (int64_t)c * pool_rows + perm[prow];   // epoch shuffle = a new permutation, the pool stays put
-    offset += (uint64_t)(d_state[1] + a.rng_add) * 4;
+    offset += (uint64_t)d_state[1] * 4;
   }
 
   // ---- a2: origin / direction in object (or world) frame -----------------------------------
@@ -170,10 +165,10 @@ __device__ __forceinline__ void sample_ray(const SampleArgs& a, int64_t ray, int
 
   // ---- a3/a5: per-column z -------------------------------------------------------------------
   float mb;
-  if (max_bound) mb = a.mb_slices > 1 ? max_bound[(int64_t)c * a.mb_slices + (int)(cursor / R)] : max_bound[c];
+  if (max_bound) mb = a.mb_slices > 1 ? max_bound[(int64_t)c * a.mb_slices + (int)(d_state[0] / R)] : max_bound[c];
   else {  // max depth of this step's slice of class c, by this wave (same value as cnr_sample_maxdepth: max is exact)
     float m = -INFINITY;
-    const int64_t base = pool_rows > 0 ? (int64_t)c * pool_rows + cursor : (int64_t)c * R;
+    const int64_t base = pool_rows > 0 ? (int64_t)c * pool_rows + d_state[0] : (int64_t)c * R;
     for (int r = lane; r < R; r += 64)
       m = fmaxf(m, depth[perm ? (int64_t)c * pool_rows + perm[base + r] : base + r]);
     mb = cnr::wave_max(m);

@@ -20,7 +20,6 @@
 #include "latent_common.h"
 #include "records_common.h"
 #include "render_common.h"
-#include "sample_common.h"
 
 namespace {
 using namespace cnr;
@@ -40,9 +39,6 @@ struct TailArgs {
   // grad_only: stop at the finished gradient (no AdamW, no epilogue blocks): the multi-GPU step all-reduces it first
   int grad_only;
   const int* n_obj_cls;  // optional (C,): objects each class really has (<= lay.n_obj; the rest of its rows are padding)
-  // optional: a2-a6 of the NEXT step side by side with everything else (its rays depend on the pool and the cursor only):
-  // nsample blocks of four rays per class behind the epilogue blocks; cursor / rng step = state_cur + (add_rows, 1)
-  cnr_sample::SampleArgs sa; int nsample;
   int* clamp_flags;  // optional (C,): bits the field backward raised this step (cnr_field_bwd_pipe); or-ed into flags, cleared
 };
 
@@ -226,11 +222,6 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
   } else {
     b -= a.NA;
   }
-  if (b >= C) {  // ---- sampling for the next step: four rays of class cs per block
-    const int sb = b - C, cs = sb / a.nsample, r = (sb % a.nsample) * 4 + (threadIdx.x >> 6);
-    if (r < a.sa.R) cnr_sample::sample_ray(a.sa, (int64_t)cs * a.sa.R + r, threadIdx.x & 63);
-    return;
-  }
   // ---- epilogue of class b: loss values + flags, next slice's max depth, next step state (class 0)
   const int c = b, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   float* red = sm;
@@ -277,7 +268,7 @@ extern "C" int cnr_step_tail(const float* theta_in, float* theta_out, float* gra
                              const void* rl_workspace, float* losses, int32_t* flags, const float* depth,
                              int64_t pool_rows, const int* perm, float* next_max_bound, int R, const void* records,
                              int nwg, const long long* rows_fix, int rl_blocks, int* clamp_flags, const int* n_obj_cls,
-                             const cnr_sample_desc* next_sample, void* stream) {
+                             void* stream) {
   if (!theta_in || !theta_out || theta_in == theta_out || !grad || !exp_avg || !exp_avg_sq || class_stride <= 0 ||
       L <= 0 || n_obj <= 0 || C <= 0 || !state_cur || !state_next || state_cur == state_next || !rl_workspace ||
       !losses || !flags || R <= 0)
@@ -307,21 +298,7 @@ extern "C" int cnr_step_tail(const float* theta_in, float* theta_out, float* gra
   a.NA = (int)na;
   a.records = (const float*)records; a.nwg = nwg; a.rows_fix = rows_fix; a.NR = cnr_rec::REC_FLOATS / cnr_rec::TAIL_EPB;
   a.clamp_flags = clamp_flags;
-  a.nsample = 0;
-  if (next_sample) {
-    const cnr_sample_desc& d = *next_sample;
-    if (!d.rgbs || !d.depth || !d.dirs_c || !d.T || !d.max_bound || !d.z || !d.pts || !d.gt_rgb || !d.depth_mask || !d.labels ||
-        d.pool_rows < d.R || d.R <= 0 || d.n1 < 0 || d.n2 <= 0 || d.n2 > 128 || d.max_bound_slices < 0 ||
-        (d.ray_row && !d.pool_indices) || (d.rng_R > 0 && d.rng_r0 + d.R > d.rng_R))
-      return CNR_E_ARG;
-    a.sa = cnr_sample::SampleArgs{d.rgbs, d.depth, d.dirs_c, d.T, nullptr, nullptr, d.seed, d.offset, state_cur, d.pool_rows,
-                                  d.max_bound, d.world_frame, C, d.R, d.n1, d.n2, d.eps, d.stop_eps, d.min_bound, d.z, d.pts,
-                                  nullptr, nullptr, d.gt_rgb, d.gt_depth, d.depth_mask, d.labels, d.pool_indices, d.n_obj,
-                                  d.ray_row, d.perm, d.max_bound_slices, d.rng_c0, d.rng_cstride, d.rng_R, d.rng_r0,
-                                  add_rows, 1};
-    a.nsample = (d.R + 3) / 4;
-  }
-  const unsigned grid = (unsigned)((a.do_latent ? a.NL * C : 0) + (records ? a.NR * C : a.NA) + C + a.nsample * C);
+  const unsigned grid = (unsigned)((a.do_latent ? a.NL * C : 0) + (records ? a.NR * C : a.NA) + C);
   const size_t lds = (size_t)(2 * n_obj * 128 + 2 * n_obj + 520) * sizeof(float);
   hipLaunchKernelGGL(tail_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
   CNR_LAUNCH_CHECK();

@@ -92,7 +92,7 @@ class FusedCategoryTrainer:
     def __init__(self, cfg, n_cls, n_obj, pools, rays_per_step, device, seed=0, generator=None,
                  grad_scale=None, bwd_blocks=0, process_group=None, use_graph=True, split_graph=False,
                  fuse_render=True, split_weights=None, shard=None, n_cls_global=None, class_ids=None,
-                 check_every=0, world_frame=None, dp_rank=None, dp_world=None, one_launch=None, sample_ahead=None):
+                 check_every=0, world_frame=None, dp_rank=None, dp_world=None, one_launch=None):
         # n_obj: one count for every class, or one per (local) class -- the reference's categories differ (train.py:92-96).  The
         # flat layout uses the largest; a smaller class keeps unused rows (no ray refers to them, no regulariser on them)
         n_obj_list = [int(n_obj)] * n_cls if isinstance(n_obj, int) else [int(v) for v in n_obj]
@@ -183,20 +183,7 @@ class FusedCategoryTrainer:
         self.seed = int(seed) + 1
         self.grad_scale = float(grad_scale) if grad_scale else float(2 ** round(math.log2(max(self.Rg, 2))))
         self.bwd_blocks = int(bwd_blocks)
-        # step outputs / scratch (self._ob) and the sampled batch in TWO copies (self._sb): step k reads copy k & 1, and its
-        # last launch (cnr_step_tail) samples step k + 1's rays into copy (k + 1) & 1 beside its other jobs -- a2-a6 depend on
-        # the pool, the permutation and the cursor only -- so the step's first launch is left with the parameter-only work.
-        # CNR_SAMPLE_AHEAD=0: sample in the first launch instead (cnr_step_prologue), one copy
-        self.sample_ahead = bool(int(os.environ.get("CNR_SAMPLE_AHEAD", "1"))) if sample_ahead is None else bool(sample_ahead)
-        self._ob = {}
-        kwf = dict(device=self.device, dtype=torch.float32)
-        mk = lambda: dict(z=torch.empty(n_cls, self.R, self.S, **kwf), pts=torch.empty(n_cls, self.R, self.S, 3, **kwf),
-                          gt_rgb=torch.empty(n_cls, self.R, 3, **kwf), gt_depth=torch.empty(n_cls, self.R, **kwf),
-                          depth_mask=torch.empty(n_cls, self.R, device=self.device, dtype=torch.uint8),
-                          labels=torch.empty(n_cls, self.R, device=self.device, dtype=torch.uint8),
-                          ray_row=torch.empty(n_cls, self.R, device=self.device, dtype=torch.int32))
-        self._sb = [mk(), mk()] if self.sample_ahead else [mk()] * 2
-        self._next_desc = [None, None]
+        self.bufs = {}
         self.losses = torch.zeros(3, n_cls, device=self.device)
         self.flags = torch.zeros(n_cls, device=self.device, dtype=torch.int32)
         self.clamp = torch.zeros(n_cls, device=self.device, dtype=torch.int32)
@@ -230,12 +217,6 @@ class FusedCategoryTrainer:
         return self.theta2[self.parity]
 
     @property
-    def bufs(self):
-        """buffers of the step that ran last (or, before the first step, of the one about to run): renders, gradients of the
-        samples, scratch, and THAT step's sampled batch (z, pts, gt_rgb, gt_depth, labels, depth_mask, ray_row)"""
-        return {**self._ob, **self._sb[(self.parity ^ 1) if self.steps_done else self.parity]}
-
-    @property
     def d_state(self):
         """the state the NEXT step will read (int64[3] view)"""
         return self.d_state2[self.parity]
@@ -251,7 +232,7 @@ class FusedCategoryTrainer:
         C, R, S, n_obj, L = self.C, self.R, self.S, self.n_obj, self.L
         cfg, v, lay = self.cfg, self.lay.views(self.theta), self.lay
         gv = self.lay.views(self.grad)
-        o = self._ob
+        o = self.bufs
         if "zl" not in o:
             kw = dict(device=self.device, dtype=torch.float32)
             o["zl"] = torch.empty(C * n_obj, 4, 32, **kw)
@@ -281,15 +262,9 @@ class FusedCategoryTrainer:
         # latent layers (per-object bias rows) | f16 operand image of the trunk | a2-a6: slice the device pool at
         # the device cursor, transform, sample (the slice's max depth comes out of self.slice_max, which _reshuffle
         # filled for the whole epoch)
-        b = self._sb[self.parity]
-        if self.sample_ahead:
-            # this step's rays were sampled by the previous step's last launch (or by _sample_now after a reshuffle)
-            _C.call("cnr_param_prep", self.theta, lay.total, lay.trunk[0], lay.latW[0], lay.latb[0], lay.shape[0], lay.tex[0],
-                    L, n_obj, C, packed, zl, brows, self._gbuf, self._gbuf.numel())
-        else:
-            ops.step_prologue(self.theta, lay, L, n_obj, packed, zl, brows, self._gbuf, self.pool["rgbs"],
+        b = ops.step_prologue(self.theta, lay, L, n_obj, packed, zl, brows, self._gbuf, self.pool["rgbs"],
                               self.pool["depth"], self.pool["dirs"], self.pool["T"], self.n1, self.n2, cfg.surface_eps,
-                              cfg.stop_eps, cfg.min_depth, self.seed, self.d_state2[self.parity], R, b,
+                              cfg.stop_eps, cfg.min_depth, self.seed, self.d_state2[self.parity], R, self.bufs,
                               self.slice_max, self.pool["indices"], self.perm, max_bound_slices=self.n_slices,
                               rng=self._rng_map())
         ray_row = b["ray_row"]
@@ -344,15 +319,14 @@ class FusedCategoryTrainer:
         epilogue (loss values +
         flags from the render kernel's partials, the next slice's max depth, next step state into the other state
         copy) -- side by side in one grid."""
-        C, R, o, par, lay = self.C, self.R, self._ob, self.parity, self.lay
-        nxt = self._sample_desc(1 - par) if self.sample_ahead else None
+        C, R, o, par, lay = self.C, self.R, self.bufs, self.parity, self.lay
         _C.call("cnr_step_tail", self.theta2[par], self.theta2[1 - par], self.grad, self.exp_avg, self.exp_avg_sq,
                 lay.total, lay.B[0], lay.latW[0], lay.latb[0], lay.shape[0], lay.tex[0], self.L, self.n_obj, C,
                 o["zl"], self.dbias, self._reg, 0 if self.grad_exchange else 1, self.lr, 0.9, 0.999, 1e-8, self.wd,
                 self.d_state2[par], self.d_state2[1 - par], self.Rg, o["rl_ws"], self.losses, self.flags,
                 None, self.pool_rows, None, None, R,
                 o["bwd_ws"] if self.fused_tail else None, self._nwg if self.fused_tail else 0,
-                self.rows_fix if self.fused_tail else None, self._ft_blocks or self._rl_blocks, self.clamp, self.n_obj_cls, nxt)
+                self.rows_fix if self.fused_tail else None, self._ft_blocks or self._rl_blocks, self.clamp, self.n_obj_cls)
 
     def step(self):
         """One train step.  Returns nothing; ``self.losses`` (3,C) / ``self.flags`` (C,) hold the device-side
@@ -403,28 +377,6 @@ class FusedCategoryTrainer:
         self.steps_done += 1
         if self.check_every and self.steps_done % self.check_every == 0:
             self.check_flags()
-
-    def _sample_desc(self, which):
-        """cnr_sample_desc that fills sample-buffer copy `which` (built once per copy: the pointers never change)"""
-        if self._next_desc[which] is None:
-            cfg, sb, rng = self.cfg, self._sb[which], self._rng_map()
-            self._next_desc[which] = _C.sample_desc(
-                rgbs=self.pool["rgbs"], depth=self.pool["depth"], dirs_c=self.pool["dirs"], T=self.pool["T"], seed=self.seed, offset=0,
-                pool_rows=self.pool_rows, max_bound=self.slice_max, max_bound_slices=self.n_slices, world_frame=0, R=self.R,
-                n1=self.n1, n2=self.n2, eps=float(cfg.surface_eps), stop_eps=float(cfg.stop_eps), min_bound=float(cfg.min_depth),
-                z=sb["z"], pts=sb["pts"], gt_rgb=sb["gt_rgb"], gt_depth=sb["gt_depth"], depth_mask=sb["depth_mask"],
-                labels=sb["labels"], pool_indices=self.pool["indices"], n_obj=self.n_obj, ray_row=sb["ray_row"], perm=self.perm,
-                rng_c0=rng[0], rng_cstride=rng[1], rng_R=rng[2], rng_r0=rng[3])
-        return self._next_desc[which]
-
-    def _sample_now(self):
-        """a2-a6 for the step about to run (first step, first step of an epoch): stand-alone launch into its sample copy"""
-        cfg, sb, rng = self.cfg, self._sb[self.parity], self._rng_map()
-        _C.call("cnr_sample_rays", self.pool["rgbs"], self.pool["depth"], self.pool["dirs"], self.pool["T"], None, None,
-                self.seed, 0, self.d_state2[self.parity], self.pool_rows, self.slice_max, 0, self.C, self.R, self.n1, self.n2,
-                float(cfg.surface_eps), float(cfg.stop_eps), float(cfg.min_depth), sb["z"], sb["pts"], None, None,
-                sb["gt_rgb"], sb["gt_depth"], sb["depth_mask"], sb["labels"], self.pool["indices"], self.n_obj,
-                sb["ray_row"], self.perm, self.n_slices, rng[0], rng[1], rng[2], rng[3])
 
     def _rng_map(self):
         """(first global class, class stride, global rays per class, first ray of this rank): the Philox counter of a ray
@@ -523,8 +475,6 @@ class FusedCategoryTrainer:
             parallel.allreduce_any_(tab[:, C, :3], self.pg)
         self.slice_max.copy_(smax.repeat_interleave(w, dim=1))
         self.counts_tab.copy_(tab.repeat_interleave(w, dim=0))
-        if self.sample_ahead:
-            self._sample_now()
 
     # ---- reference-named export ------------------------------------------------------------------------
     def state_dicts(self, c=0):

@@ -74,10 +74,7 @@ int cnr_sample_rays(const uint8_t* rgbs, const float* depth, const float* dirs_c
                     float eps, float stop_eps, float min_bound,
                     float* z, float* pts, float* origins, float* dirs_o,
                     float* gt_rgb, float* gt_depth, uint8_t* depth_mask, uint8_t* labels,
-                    const int64_t* pool_indices, int n_obj, int* ray_row, const int* perm, int max_bound_slices,
-                    int rng_c0, int rng_cstride, int rng_R, int rng_r0, void* stream);
-/* max_bound_slices / rng_*: as cnr_step_prologue (a (C, slices) max-depth table indexed by cursor / R; the global-batch ray
- * index of the Philox counter).  All zero: one max_bound per class, local ray indices. */
+                    const int64_t* pool_indices, int n_obj, int* ray_row, const int* perm, void* stream);
 /* Device-resident step state int64[3] = {pool cursor (rows), rng step, optimiser step}.  With pool_rows > 0
  * the four pool pointers above are the BASES of (C, pool_rows, ...) pools and the slice starts at row
  * d_state[0] (src/scene_cateogries.py:422-431's i_batch); the Philox offset advances by d_state[1].
@@ -332,21 +329,6 @@ int cnr_adamw_epilogue(float* param, const float* grad, float* exp_avg, float* e
                        float* losses, int32_t* flags, const float* depth, int64_t pool_rows, const int* perm,
                        float* next_max_bound, int C, int R, void* stream);
 
-/* a2-a6 of one pool slice as a descriptor (the arguments of cnr_sample_rays in its device-pool form, minus the step state):
- * cnr_step_tail takes one to sample the NEXT step's rays beside its other jobs -- they depend on the pool, the permutation and
- * the cursor only -- so that the step's first launch is left with the parameter-only work.  The slice starts at row
- * state_cur[0] + add_rows, the Philox step is state_cur[1] + 1; a slice that would run past pool_rows is skipped (the host
- * reshuffles before that step and samples it with cnr_sample_rays). */
-typedef struct cnr_sample_desc {
-  const uint8_t* rgbs; const float* depth; const float* dirs_c; const float* T;      /* (C, pool_rows, ...) pools          */
-  uint64_t seed, offset; int64_t pool_rows;
-  const float* max_bound; int max_bound_slices;                                       /* as cnr_step_prologue              */
-  int world_frame, R, n1, n2; float eps, stop_eps, min_bound;
-  float* z; float* pts; float* gt_rgb; float* gt_depth; uint8_t* depth_mask; uint8_t* labels;   /* outputs, (C, R, ...)    */
-  const int64_t* pool_indices; int n_obj; int* ray_row; const int* perm;
-  int rng_c0, rng_cstride, rng_R, rng_r0;
-} cnr_sample_desc;
-
 /* The tail of the fused trainer's step in ONE launch: cnr_latent_bwd (do_latent != 0), AdamW on the flat parameter
  * buffer and cnr_step_epilogue, for PING-PONG parameters and step state: every kernel of step k reads theta_in /
  * state_cur, this launch writes theta_out / state_next (AdamW out of place), the caller swaps them for step k + 1.
@@ -369,7 +351,7 @@ int cnr_step_tail(const float* theta_in, float* theta_out, float* grad, float* e
                   const int64_t* state_cur, int64_t* state_next, int64_t add_rows, const void* rl_workspace,
                   float* losses, int32_t* flags, const float* depth, int64_t pool_rows, const int* perm,
                   float* next_max_bound, int R, const void* records, int nwg, const long long* rows_fix,
-                  int rl_blocks, int* clamp_flags, const int* n_obj_cls, const cnr_sample_desc* next_sample, void* stream);
+                  int rl_blocks, int* clamp_flags, const int* n_obj_cls, void* stream);
 /* clamp_flags (optional, (C,) int32, zero before the first step): what cnr_field_bwd_pipe raised during this step -- bit 4
  * (16) = a scaled upstream gradient |d sigma| * grad_scale exceeded 8192 and was clipped for the f16 chain; the epilogue
  * or-s the word into flags[c] and clears it. */
