@@ -322,6 +322,22 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
         for (int i = 0; i < 16; ++i) part = fmaf(ws[i], acc[i], part);
         raw = part + __shfl_xor(part, 32, 64) + cf[CF_B_SG];
       }
+      // the sigma-only half of the composite starts HERE, ahead of the colour branch: its scans are a dependent VALU chain
+      // that the scheduler can run under the ten MFMAs (and their result latencies) of the colour layers
+      float c_occ = 0.f, c_f = 1.f, c_excl = 1.f, c_Pt = 1.f, c_tl = 0.f, c_wl = 0.f, c_dl = 0.f, c_ml = 0.f, c_M2 = 0.f;
+      if constexpr (KR > 0) {
+        c_occ = (h == 0 && cur.live != 0) ? __builtin_amdgcn_rcpf(1.0f + expf(-(raw * 10.0f))) : 0.0f;
+        c_f = h == 0 ? (1.0f - c_occ + 1e-10f) : 1.0f;
+        const float incl = half_scan_mul(c_f);                       // inclusive product of the free probabilities
+        c_excl = lane_below(incl, 1.0f);                             // exclusive (lane 0: 1)
+        c_Pt = lane_value(incl, 31);                                 // the tile's product
+        c_tl = c_occ * c_excl;                                       // termination with the carry still to come
+        c_wl = lane_value(half_scan_add(c_tl), 31);
+        c_dl = lane_value(half_scan_add(c_tl * cur.z), 31);
+        c_ml = c_wl > 0.0f ? c_dl * __builtin_amdgcn_rcpf(c_wl) : 0.0f;
+        const float dzl = cur.z - c_ml;
+        c_M2 = lane_value(half_scan_add(c_tl * dzl * dzl), 31);
+      }
       const h8 Y4a = pack8(acc, 0, false), Y4b = pack8(acc, 1, false);
       acc = MFMA(wq[0], Y4a, bq);
       acc = MFMA(wq[1], Y4b, acc);
@@ -358,23 +374,15 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
         constexpr int wv_mask = KR - 1;
         const int wv0 = wv & ~wv_mask, tin = wv & wv_mask;
         const bool live = cur.live != 0;
-        const float occ = (h == 0 && live) ? __builtin_amdgcn_rcpf(1.0f + expf(-(raw * 10.0f))) : 0.0f;
-        const float zz = cur.z;
-        const float f = h == 0 ? (1.0f - occ + 1e-10f) : 1.0f;
-        const float incl = half_scan_mul(f);                         // inclusive product of the free probabilities
-        const float excl = lane_below(incl, 1.0f);                   // exclusive (lane 0: 1)
-        const float Pt = lane_value(incl, 31);                       // the tile's product
-        const float tl_ = occ * excl;                                // termination with the carry still to come
-        // the tile's own sums (lane 31 of the DPP scans holds the half-0 totals; half 1 is zero)
-        const float w_l = lane_value(half_scan_add(tl_), 31), d_l = lane_value(half_scan_add(tl_ * zz), 31);
+        const float occ = c_occ, zz = cur.z, f = c_f, excl = c_excl, Pt = c_Pt, tl_ = c_tl;
+        // the tile's own sums (lane 31 of the DPP scans holds the half-0 totals; half 1 is zero); the sigma-only ones
+        // (w_l, d_l and the pieces of the variance) were formed ahead of the colour branch
+        const float w_l = c_wl, d_l = c_dl, m_l = c_ml, M2_l = c_M2;
         const float r_l = lane_value(half_scan_add(tl_ * r0), 31), g_l = lane_value(half_scan_add(tl_ * r1), 31);
         const float b_l = lane_value(half_scan_add(tl_ * r2), 31);
         // var = sum term (z - depth)^2 needs the ray's depth first.  Tiles exchange ONCE: each publishes its weighted mean
         // m_l and M2_l = sum tl (z - m_l)^2; with mean = depth / opacity over the ray,
         //   var = sum_t c_t (M2_t + w_t (m_t - mean)^2) + opacity (mean - depth)^2      (exact; c_t = carried transmittance)
-        const float m_l = w_l > 0.0f ? d_l * __builtin_amdgcn_rcpf(w_l) : 0.0f;
-        const float dzl = zz - m_l;
-        const float M2_l = lane_value(half_scan_add(tl_ * dzl * dzl), 31);
         float carry = 1.0f, sd = d_l, so = w_l, sr = r_l, sg = g_l, sb = b_l, sv;
         f4 xa[KR > 1 ? KR : 1], xb[KR > 1 ? KR : 1];   // the ray's tiles: {P, w, d, r} {g, b, M2, m}
         float cpre[KR > 1 ? KR : 1];                    // carried transmittance in front of tile t
