@@ -378,7 +378,7 @@ def main():
             out["config"]["params_in_sync"] = f"check failed: {e}"
     if world == 1 and not args.no_extra_legs:
         # the reference's REAL batch shape (configs/Replica/config_replica_room0.json:25-28: 120 rays per object, 1 + 9
-        # samples): S = 10 is not a multiple of 32, so this runs the two-launch forward / render path
+        # samples): rays padded to 16 sample slots, two per tile, on the same one-launch step body
         try:
             cfg2 = cnr_amd.cfg.synthetic_config(device=str(dev), latent_dim=L, n_bins_cam2surface=1, n_bins=9)
             R2 = 120 * n_obj
@@ -394,7 +394,7 @@ def main():
             torch.cuda.synchronize()
             d2 = time.perf_counter() - t0
             out["extra_legs"] = {"real_config_480x10": {"workload": "1 category x 4 objects, 120 rays per object x 10 samples "
-                                                                    "(the reference's own batch shape), two-launch forward/render",
+                                                                    "(the reference's own batch shape), two 16-slot rays per 32-sample tile",
                                                         "steps": 2000, "ms_per_step": d2 / 2000 * 1e3, "rays_per_s": R2 * 2000 / d2}}
         except Exception as e:
             out["extra_legs"] = {"real_config_480x10": f"failed: {e}"}

@@ -194,6 +194,45 @@ __device__ __forceinline__ float half0_suffix_add(float v, int lane) {
 __device__ __forceinline__ float lane_value(float v, int l) {  // wave-uniform copy of lane l (l a constant)
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
+// ---- the same scans over SEGMENTS: ROW16 = false: one segment = the 32 lanes of lane half 0 (as above); ROW16 = true: two
+// segments of 16 lanes (DPP rows 0 and 1 of half 0) -- two short rays side by side in one tile.  seg_total: the segment's
+// total of an inclusive prefix scan, in every lane of the segment.
+template <bool ROW16> __device__ __forceinline__ float seg_scan_add(float v) {
+  if constexpr (!ROW16) return half_sum_dpp(v);
+  int x = __builtin_bit_cast(int, v);
+#define CNR_DPP_ADDR(CTRL)                                                                             \
+  x = __builtin_bit_cast(int, __builtin_bit_cast(float, x) +                                           \
+                                  __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, true)))
+  CNR_DPP_ADDR(0x111); CNR_DPP_ADDR(0x112); CNR_DPP_ADDR(0x114); CNR_DPP_ADDR(0x118);
+#undef CNR_DPP_ADDR
+  return __builtin_bit_cast(float, x);
+}
+template <bool ROW16> __device__ __forceinline__ float seg_scan_mul(float v) {
+  if constexpr (!ROW16) return half_scan_mul(v);
+  int x = __builtin_bit_cast(int, v);
+  const int one = 0x3f800000;
+#define CNR_DPP_MULR(CTRL)                                                                             \
+  x = __builtin_bit_cast(int, __builtin_bit_cast(float, x) *                                           \
+                                  __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(one, x, CTRL, 0xf, 0xf, false)))
+  CNR_DPP_MULR(0x111); CNR_DPP_MULR(0x112); CNR_DPP_MULR(0x114); CNR_DPP_MULR(0x118);
+#undef CNR_DPP_MULR
+  return __builtin_bit_cast(float, x);
+}
+template <bool ROW16> __device__ __forceinline__ float seg_total(float scan, int lane) {
+  if constexpr (!ROW16) return lane_value(scan, 31);
+  const float a = lane_value(scan, 15), b = lane_value(scan, 31);
+  return (lane & 16) ? b : a;
+}
+template <bool ROW16> __device__ __forceinline__ float seg_suffix_add(float v, int lane) {
+  if constexpr (!ROW16) return half0_suffix_add(v, lane);
+  int x = __builtin_bit_cast(int, v);
+#define CNR_DPP_ADDS(CTRL)                                                                             \
+  x = __builtin_bit_cast(int, __builtin_bit_cast(float, x) +                                           \
+                                  __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, true)))
+  CNR_DPP_ADDS(0x101); CNR_DPP_ADDS(0x102); CNR_DPP_ADDS(0x104); CNR_DPP_ADDS(0x108);
+#undef CNR_DPP_ADDS
+  return __builtin_bit_cast(float, x);
+}
 // lanes 32..63 := lanes 0..31 (v_permlane32_swap, gfx950)
 __device__ __forceinline__ float low_half_to_both(float v) {
   const unsigned x = __builtin_bit_cast(unsigned, v);

@@ -48,7 +48,9 @@ __host__ __device__ constexpr int l8_total(int nch) {
 }
 // KR > 0 (cnr_field_train): the render / loss side of the step, so that ONE launch runs field forward -> composite ->
 // losses -> their gradient -> composite backward -> field backward with no second forward and no d sigma / d colour
-// round trip through HBM.  S = 32 KR: the KR chain waves wv, wv ^ 1, .. of a workgroup iteration hold one ray.
+// round trip through HBM.  A ray occupies SP = 32 KR padded sample slots (S <= SP; slots >= S are dead lanes): the KR chain
+// waves wv, wv ^ 1, .. of a workgroup iteration hold one ray.  TWO (KR = 1 only): SP = 16, two short rays side by side in a
+// tile, one per DPP row -- the reference's real batch shape is 10 samples per ray (config_replica_room0.json:25-28).
 struct TrainArgs {
   const float* z; const float* gt_depth; const float* gt_rgb; const uint8_t* labels; const uint8_t* depth_mask;
   const float* counts_tab; const int64_t* d_state; float color_scaling, opacity_scaling, loss_scale;
@@ -76,7 +78,7 @@ template <> __host__ __device__ constexpr int local8<4>(int kind) {
 
 // WIDE: more than four object rows per class (up to ROWS_MAX): the row stride of the row-sum block is then a run-time
 // value; with <= 4 rows it is the constant 4 and the index arithmetic folds (1 us of the kernel at 2048 x 64).
-template <int NCH, int NDW, bool WIDE, int KR>
+template <int NCH, int NDW, bool WIDE, int KR, bool TWO>
 __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
     const float* __restrict__ pts, const float* __restrict__ Bdir, const unsigned char* __restrict__ packed,
     const float* __restrict__ biasrows, const int* __restrict__ ray_row, float inv_scale,
@@ -84,6 +86,8 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
     int N, int S, int R, int rows_per_class, int64_t B_stride, long long* __restrict__ rows_fix,
     int* __restrict__ clamp_flags, TrainArgs ta) {
   static_assert(KR == 0 || KR == 1 || KR == 2 || KR == 4, "tiles per ray");
+  static_assert(!TWO || KR == 1, "two rays per tile only with one tile per ray");
+  constexpr int SP = TWO ? 16 : (KR > 0 ? 32 * KR : 32);   // padded sample slots per ray (one-launch form)
   constexpr int NCHW = NCH, NTHR = (NCH + NDW) * 64, NACC = 5, LI_RS = local8<NDW>(BK_RS);
   // per chain wave: E1 image, E2 image, dPre / input slot, row one-hot table (the flush reuses it for the wave's
   // partial sums)
@@ -117,7 +121,7 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
   unsigned char* chain_base = smem + L8_CHAIN;
   const float inv_gs = 1.0f / gscale;
   const int slot_inv = (65536 + S - 1) / S;
-  const int ntiles = (N + 31) / 32;
+  const int ntiles = KR > 0 ? (int)(((int64_t)R * SP + 31) / 32) : (N + 31) / 32;
   const int tile_step = gridDim.x * NCHW;
 
   // dW waves: up to 5 accumulator blocks each.  Chain waves never touch them; their own persistent per-lane partial
@@ -149,22 +153,25 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
     const float* Bl_h = reinterpret_cast<const float*>(smem + L8_BL) + 33 * h;
 
     // one lane's inputs of a tile; past the end: a dead tile (all-zero gradients, any valid row)
-    struct TileIn { float px, py, pz, dsg, dr0, dr1, dr2; int row; float z, gtd, g0, g1, g2; int lab, dm, live; };
+    struct TileIn { float px, py, pz, dsg, dr0, dr1, dr2; int row; float z, gtd, g0, g1, g2; int lab, dm, live, rlive; };
     auto fetch = [&](int tile) {
       const bool tile_ok = tile < ntiles;
       const int tl = tile_ok ? tile : ntiles - 1;
       const int n0 = tl * 32;
       TileIn t;
       if constexpr (KR > 0) {
-        // S = 32 KR: tile tl is samples [32 (tl % KR), + 32) of ray tl / KR, never partial
-        const int64_t ray = (int64_t)c * R + tl / KR;
-        const int64_t gs = (int64_t)c * N + n0 + col;
+        // padded slots: lane col of tile tl is slot 32 tl + col = sample slot % SP of ray slot / SP; samples >= S and rays
+        // >= R are dead lanes (they run the forward on a clamped address and contribute nothing)
+        const int slot = n0 + col, ray_l = slot / SP, sidx = slot % SP;
+        const bool ray_ok = tile_ok && ray_l < R, lane_ok = ray_ok && sidx < S;
+        const int64_t ray = (int64_t)c * R + (ray_l < R ? ray_l : R - 1);
+        const int64_t gs = ray * S + (sidx < S ? sidx : S - 1);
         const float* pp = pts + gs * 3;
         t.px = pp[0]; t.py = pp[1]; t.pz = pp[2];
         t.row = ray_row ? ray_row[ray] : (int)ray;
         t.z = ta.z[gs]; t.gtd = ta.gt_depth[ray];
         t.g0 = ta.gt_rgb[ray * 3 + 0]; t.g1 = ta.gt_rgb[ray * 3 + 1]; t.g2 = ta.gt_rgb[ray * 3 + 2];
-        t.lab = ta.labels[ray]; t.dm = ta.depth_mask[ray]; t.live = tile_ok ? 1 : 0;
+        t.lab = ta.labels[ray]; t.dm = ta.depth_mask[ray]; t.live = lane_ok ? 1 : 0; t.rlive = ray_ok ? 1 : 0;
         t.dsg = t.dr0 = t.dr1 = t.dr2 = 0.0f;
         return t;
       }
@@ -183,7 +190,7 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
       t.dr0 = live ? d_rgb[gs * 3 + 0] : 0.0f;
       t.dr1 = live ? d_rgb[gs * 3 + 1] : 0.0f;
       t.dr2 = live ? d_rgb[gs * 3 + 2] : 0.0f;
-      t.z = t.gtd = t.g0 = t.g1 = t.g2 = 0.0f; t.lab = t.dm = 0; t.live = live ? 1 : 0;
+      t.z = t.gtd = t.g0 = t.g1 = t.g2 = 0.0f; t.lab = t.dm = 0; t.live = live ? 1 : 0; t.rlive = t.live;
       return t;
     };
     // ---- one-launch step: this class's loss weights from the epoch's mask-count table, loss partial sums ------------
@@ -328,15 +335,16 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
       if constexpr (KR > 0) {
         c_occ = (h == 0 && cur.live != 0) ? __builtin_amdgcn_rcpf(1.0f + expf(-(raw * 10.0f))) : 0.0f;
         c_f = h == 0 ? (1.0f - c_occ + 1e-10f) : 1.0f;
-        const float incl = half_scan_mul(c_f);                       // inclusive product of the free probabilities
-        c_excl = lane_below(incl, 1.0f);                             // exclusive (lane 0: 1)
-        c_Pt = lane_value(incl, 31);                                 // the tile's product
+        const float incl = seg_scan_mul<TWO>(c_f);                   // inclusive product of the free probabilities
+        c_excl = lane_below(incl, 1.0f);                             // exclusive (first lane of a ray: 1)
+        if (TWO && col == 16) c_excl = 1.0f;
+        c_Pt = lane_value(incl, 31);                                 // the tile's product (rays spanning tiles)
         c_tl = c_occ * c_excl;                                       // termination with the carry still to come
-        c_wl = lane_value(half_scan_add(c_tl), 31);
-        c_dl = lane_value(half_scan_add(c_tl * cur.z), 31);
+        c_wl = seg_total<TWO>(seg_scan_add<TWO>(c_tl), lane);
+        c_dl = seg_total<TWO>(seg_scan_add<TWO>(c_tl * cur.z), lane);
         c_ml = c_wl > 0.0f ? c_dl * __builtin_amdgcn_rcpf(c_wl) : 0.0f;
         const float dzl = cur.z - c_ml;
-        c_M2 = lane_value(half_scan_add(c_tl * dzl * dzl), 31);
+        c_M2 = seg_total<TWO>(seg_scan_add<TWO>(c_tl * dzl * dzl), lane);
       }
       const h8 Y4a = pack8(acc, 0, false), Y4b = pack8(acc, 1, false);
       acc = MFMA(wq[0], Y4a, bq);
@@ -378,8 +386,8 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
         // the tile's own sums (lane 31 of the DPP scans holds the half-0 totals; half 1 is zero); the sigma-only ones
         // (w_l, d_l and the pieces of the variance) were formed ahead of the colour branch
         const float w_l = c_wl, d_l = c_dl, m_l = c_ml, M2_l = c_M2;
-        const float r_l = lane_value(half_scan_add(tl_ * r0), 31), g_l = lane_value(half_scan_add(tl_ * r1), 31);
-        const float b_l = lane_value(half_scan_add(tl_ * r2), 31);
+        const float r_l = seg_total<TWO>(seg_scan_add<TWO>(tl_ * r0), lane), g_l = seg_total<TWO>(seg_scan_add<TWO>(tl_ * r1), lane);
+        const float b_l = seg_total<TWO>(seg_scan_add<TWO>(tl_ * r2), lane);
         // var = sum term (z - depth)^2 needs the ray's depth first.  Tiles exchange ONCE: each publishes its weighted mean
         // m_l and M2_l = sum tl (z - m_l)^2; with mean = depth / opacity over the ray,
         //   var = sum_t c_t (M2_t + w_t (m_t - mean)^2) + opacity (mean - depth)^2      (exact; c_t = carried transmittance)
@@ -432,12 +440,12 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
         const float info = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(sv) + 1e-4f);
         const float rc0 = sr - cur.g0, rc1 = sg - cur.g1, rc2 = sb - cur.g2;
         const float ro = so - fo;
-        if (tin == 0 && live) {   // the ray's first tile accounts for it (wave-uniform)
+        if (tin == 0 && cur.rlive) {   // the ray's first tile accounts for it (uniform over the ray's lanes)
           ld_acc += fabsf(rd) * fd * info;
           lc_acc += (fabsf(rc0) + fabsf(rc1) + fabsf(rc2)) * fo;
           lo_acc += fabsf(ro) * fs;
-          if (lane == 0) {
-            const int ray = c * R + (tile / KR);     // (C R < 2^31: checked by the host)
+          if (lane == 0 || (TWO && lane == 16)) {
+            const int ray = c * R + (tile * 32 + col) / SP;     // (C R < 2^31: checked by the host)
             if (ta.depth_out) ta.depth_out[ray] = sd;
             if (ta.var_out) ta.var_out[ray] = sv;
             if (ta.opacity_out) ta.opacity_out[ray] = so;
@@ -463,7 +471,7 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
         P8MARK(3);
         const float g = dD * zz + dR * r0 + dG * r1 + dBl * r2 + dO;
         const float tg = h == 0 ? term * g : 0.0f;
-        const float isuf = half0_suffix_add(tg, lane);
+        const float isuf = seg_suffix_add<TWO>(tg, lane);
         const float suf = (isuf - tg) + suf_carry;
         const float docc = T * g - suf * __builtin_amdgcn_rcpf(f);
         float dsg = (h == 0 && live) ? docc * occ * (1.0f - occ) : 0.0f;
@@ -608,6 +616,9 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
       {
         const float v = half_sum_dpp(DBS);  // zero in lane half 1
         if (lane == 31) small[32] = v;
+      }
+      if constexpr (TWO) {   // two rays per tile: lanes 0 and 16 hold the two rays' shares
+        ld_acc += lane_value(ld_acc, 16); lc_acc += lane_value(lc_acc, 16); lo_acc += lane_value(lo_acc, 16);
       }
       if (KR > 0 && lane == 0) { small[40] = ld_acc; small[41] = lc_acc; small[42] = lo_acc; small[43] = __int_as_float(tab_flags);
                                  small[44] = wd_c; small[45] = wc_c; small[46] = wo_c; }
@@ -822,20 +833,20 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
 }  // namespace
 
 // launched by cnr_field_bwd_pipe (fused_bwd_pipe.hip) for chain_waves = 4: same argument checks, same records
-template <bool WIDE, int KR>
+template <bool WIDE, int KR, bool TWO = false>
 static int launch_p8(const float* pts, const float* B, const void* packed, const float* biasrows, const int* ray_row,
                      float scale, const float* d_sigma, const float* d_rgb, float grad_scale, int C, int R, int S,
                      int rows_per_class, int blocks, void* workspace, int64_t B_stride, long long* rows_fix,
                      int* clamp_flags, const TrainArgs& ta, void* stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t er = hipFuncSetAttribute((const void*)field_bwd_pipe8_kernel<4, 4, WIDE, KR>,
+    hipError_t er = hipFuncSetAttribute((const void*)field_bwd_pipe8_kernel<4, 4, WIDE, KR, TWO>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, l8_total(4));
     if (er != hipSuccess) return (int)er;
     attr_set = true;
   }
   const int64_t N = (int64_t)R * S;
-  hipLaunchKernelGGL((field_bwd_pipe8_kernel<4, 4, WIDE, KR>), dim3((unsigned)blocks, (unsigned)C), dim3(512), l8_total(4),
+  hipLaunchKernelGGL((field_bwd_pipe8_kernel<4, 4, WIDE, KR, TWO>), dim3((unsigned)blocks, (unsigned)C), dim3(512), l8_total(4),
                      (hipStream_t)stream, pts, B, (const unsigned char*)packed, biasrows, ray_row, 1.0f / scale, d_sigma,
                      d_rgb, grad_scale, (float*)workspace, (int)N, S, R, rows_per_class,
                      B_stride > 0 ? B_stride : (int64_t)63, rows_fix, clamp_flags, ta);
@@ -850,16 +861,19 @@ extern "C" int cnr_field_bwd_pipe8_launch(const float* pts, const float* B, cons
                                           void* stream) {
   const TrainArgs none{};
   if (rows_per_class > 4)
-    return launch_p8<true, 0>(pts, B, packed, biasrows, ray_row, scale, d_sigma, d_rgb, grad_scale, C, R, S, rows_per_class,
+    return launch_p8<true, 0, false>(pts, B, packed, biasrows, ray_row, scale, d_sigma, d_rgb, grad_scale, C, R, S, rows_per_class,
                               blocks, workspace, B_stride, rows_fix, clamp_flags, none, stream);
-  return launch_p8<false, 0>(pts, B, packed, biasrows, ray_row, scale, d_sigma, d_rgb, grad_scale, C, R, S, rows_per_class,
+  return launch_p8<false, 0, false>(pts, B, packed, biasrows, ray_row, scale, d_sigma, d_rgb, grad_scale, C, R, S, rows_per_class,
                              blocks, workspace, B_stride, rows_fix, clamp_flags, none, stream);
 }
 
 // ---- the ONE-launch step body: a8-a15 forward, losses, and the whole backward (see TrainArgs) ------------------------
+// padded sample slots per ray of the one-launch form: 16 (two rays per tile), 32, 64 or 128; 0 = not supported
+static int train_slots(int S) { return S <= 0 ? 0 : S <= 16 ? 16 : S <= 32 ? 32 : S <= 64 ? 64 : S <= 128 ? 128 : 0; }
 extern "C" int cnr_field_train_blocks(int R, int S, int max_blocks) {
-  if (R <= 0 || (S != 32 && S != 64 && S != 128)) return 0;
-  const int64_t ntiles = (int64_t)R * (S / 32);
+  const int sp = train_slots(S);
+  if (R <= 0 || !sp) return 0;
+  const int64_t ntiles = ((int64_t)R * sp + 31) / 32;
   int64_t blocks = (ntiles + 3) / 4;
   const int64_t cap = max_blocks > 0 ? max_blocks : 256;
   return (int)(blocks > cap ? cap : blocks);
@@ -881,24 +895,27 @@ extern "C" int cnr_field_train(const float* pts, const float* B, const void* pac
     return CNR_E_ARG;
   const int blocks = cnr_field_train_blocks(R, S, max_blocks);
   if (!blocks || rows_per_class < 1 || rows_per_class > cnr_rec::ROWS_MAX) return CNR_E_SHAPE;
-  if ((int64_t)C * R * S >= ((int64_t)1 << 31)) return CNR_E_SHAPE;   // 32-bit sample indices inside the kernel
+  const int sp = train_slots(S);
+  if ((int64_t)C * R * sp >= ((int64_t)1 << 31)) return CNR_E_SHAPE;   // 32-bit slot indices inside the kernel
   if (((uintptr_t)packed & 15) != 0 || ((uintptr_t)records & 15) != 0) return CNR_E_ALIGN;
   if (records_bytes < (int64_t)C * blocks * REC_FLOATS * (int64_t)sizeof(float) ||
       loss_workspace_bytes < cnr_field_train_workspace_bytes(C, R, S, max_blocks))
     return CNR_E_ARG;
   const TrainArgs ta{z, gt_depth, gt_rgb, labels, depth_mask, counts_tab, d_state, color_scaling, opacity_scaling,
                      loss_scale, depth, var, rgb, opacity, (float*)loss_workspace};
-#define CNR_FT(WIDE, KR)                                                                                              \
-  return launch_p8<WIDE, KR>(pts, B, packed, biasrows, ray_row, scale, nullptr, nullptr, grad_scale, C, R, S,          \
-                             rows_per_class, blocks, records, B_stride, rows_fix, clamp_flags, ta, stream)
+#define CNR_FT(WIDE, KR, TWO)                                                                                         \
+  return launch_p8<WIDE, KR, TWO>(pts, B, packed, biasrows, ray_row, scale, nullptr, nullptr, grad_scale, C, R, S,     \
+                                  rows_per_class, blocks, records, B_stride, rows_fix, clamp_flags, ta, stream)
   if (rows_per_class > 4) {
-    if (S == 32) CNR_FT(true, 1);
-    if (S == 64) CNR_FT(true, 2);
-    CNR_FT(true, 4);
+    if (sp == 16) CNR_FT(true, 1, true);
+    if (sp == 32) CNR_FT(true, 1, false);
+    if (sp == 64) CNR_FT(true, 2, false);
+    CNR_FT(true, 4, false);
   }
-  if (S == 32) CNR_FT(false, 1);
-  if (S == 64) CNR_FT(false, 2);
-  CNR_FT(false, 4);
+  if (sp == 16) CNR_FT(false, 1, true);
+  if (sp == 32) CNR_FT(false, 1, false);
+  if (sp == 64) CNR_FT(false, 2, false);
+  CNR_FT(false, 4, false);
 #undef CNR_FT
 }
 

@@ -197,9 +197,13 @@ class FusedCategoryTrainer:
             else bool(split_weights)
         # forward + render/loss in one launch where the shape allows (S a multiple of 32 up to 128), else two launches
         self._rl_blocks = int(_C.load().cnr_field_fwd_render_blocks(self.R, self.S)) if fuse_render else 0
-        # ... and forward + render / loss + the whole backward in ONE launch (cnr_field_train: S in {32, 64, 128}, the 8-wave
-        # kernel's record path): no second forward, no d sigma / d colour round trip.  CNR_ONE_LAUNCH=0 keeps the two calls.
+        # ... and forward + render / loss + the whole backward in ONE launch (cnr_field_train, the 8-wave kernel's record
+        # path): no second forward, no d sigma / d colour round trip.  A ray takes 16 / 32 / 64 / 128 padded sample slots;
+        # taken when at least 60 % of them are real samples (S = 10, 16, 20-32, 39-64, 77-128), else the two calls, whose
+        # extra forward costs less than the dead lanes would.  CNR_ONE_LAUNCH=0 keeps the two calls.
         one = bool(int(os.environ.get("CNR_ONE_LAUNCH", "1"))) if one_launch is None else bool(one_launch)
+        slots = 16 if self.S <= 16 else 32 if self.S <= 32 else 64 if self.S <= 64 else 128
+        one = one and self.S <= 128 and self.S >= 0.6 * slots
         self._ft_blocks = int(_C.load().cnr_field_train_blocks(self.R, self.S, self.bwd_blocks)) \
             if (one and fuse_render and self.use_records and ops.FIELD_BWD_VARIANT == "pipe4" and not self.split_weights) else 0
         if self._ft_blocks:

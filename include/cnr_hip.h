@@ -402,15 +402,17 @@ int cnr_field_fwd_fp8(const float* pts, const float* B, const void* packed, cons
 /* ---- the step body in ONE launch: cnr_field_fwd_render + cnr_field_bwd_pipe (chain_waves = 4) fused ---------------------
  * a8-a15 forward, the loss gradient and the whole field backward (train.py:154-182 for the object branch) with ONE field
  * forward per sample (cnr_field_bwd_pipe recomputes it), no d sigma / d colour round trip through HBM and one launch less.
- * S in {32, 64, 128}: the S / 32 tiles of a ray sit in neighbouring chain waves of a workgroup iteration and exchange the
- * tile products / partial renders / suffix sums of the composite through LDS.  Arguments as the two calls it replaces;
+ * Any S <= 128: a ray occupies 16, 32, 64 or 128 padded sample slots (the smallest that holds S; slots beyond S are dead
+ * lanes).  With 16 slots two rays share a 32-sample tile, one per DPP row (the reference's real batch is 10 samples per
+ * ray); with 64 / 128 the ray's 2 / 4 tiles sit in neighbouring chain waves of a workgroup iteration and exchange the tile
+ * products / partial renders / suffix sums of the composite through LDS.  Arguments as the two calls it replaces;
  * counts_tab (cnr_slice_maskcounts) is REQUIRED -- the kernel never counts masks --, d_state selects its entry (NULL: 0);
  * loss_scale multiplies the loss gradient (what cnr_field_fwd_render calls grad_scale), grad_scale is the power-of-two
  * scale of the f16 data-gradient chain.  Outputs: the renders (each optional), the per-workgroup gradient records in
  * `records` (>= C * cnr_field_train_blocks() * record size = cnr_field_bwd_workspace_bytes(C, blocks); reduce with
  * cnr_step_tail / cnr_step_grad, nwg = cnr_field_train_blocks()), rows_fix as cnr_field_bwd_pipe, and per-block loss
  * partials in loss_workspace (>= cnr_field_train_workspace_bytes()) for cnr_step_tail with rl_blocks =
- * cnr_field_train_blocks().  Returns CNR_E_SHAPE for any other S or more than 7 rows per class (use the two calls). */
+ * cnr_field_train_blocks().  Returns CNR_E_SHAPE for S > 128 or more than 7 rows per class (use the two calls). */
 int cnr_field_train_blocks(int R, int S, int max_blocks);
 int64_t cnr_field_train_workspace_bytes(int C, int R, int S, int max_blocks);
 int cnr_field_train(const float* pts, const float* B, const void* packed, const float* biasrows, const int* ray_row,

@@ -353,13 +353,19 @@ def test_many_epochs_graph_equals_eager(cnr, dev, n_obj):
 
 
 @pytest.mark.parametrize("C,R,n1,n2,n_obj,L", [(1, 2048, 8, 56, 4, 256), (2, 250, 4, 28, 4, 32), (2, 249, 8, 56, 6, 32),
-                                               (1, 1023, 16, 112, 4, 32), (3, 64, 4, 28, 7, 32), (1, 1, 8, 56, 1, 32)])
+                                               (1, 1023, 16, 112, 4, 32), (3, 64, 4, 28, 7, 32), (1, 1, 8, 56, 1, 32),
+                                               # padded rays: the reference's real shape (120 rays per object x (1 + 9)
+                                               # samples: two rays per tile), an odd ray count, 16 of 16, 24 of 32, 40 of
+                                               # 64, 100 of 128 slots
+                                               (1, 480, 1, 9, 4, 256), (2, 249, 1, 9, 5, 32), (1, 77, 2, 14, 4, 32),
+                                               (1, 130, 4, 20, 4, 32), (2, 100, 8, 32, 4, 32), (1, 50, 12, 88, 4, 32)])
 def test_one_launch_step_equals_forward_render_plus_backward(cnr, dev, C, R, n1, n2, n_obj, L):
     """cnr_field_train (a8-a15 forward, losses, loss gradient and the field backward in ONE launch, the ray's tiles
     exchanging composite partials between waves) against cnr_field_fwd_render + cnr_field_bwd_pipe: same f16 pipeline,
     same samples -> renders and loss values to fp32 summation order, the complete gradient (trunk, latent layers, B,
-    codes) to 1e-5, parameters after AdamW; ragged tile counts (dead tiles in the last workgroup iteration), 5-7
-    objects per class (the run-time row-sum stride) and S = 32 / 64 / 128 (1, 2, 4 tiles per ray)."""
+    codes) to 1e-4, parameters after AdamW; ragged tile counts (dead tiles in the last workgroup iteration), 5-7
+    objects per class (the run-time row-sum stride), S = 32 / 64 / 128 (1, 2, 4 tiles per ray) and rays padded to
+    16 / 32 / 64 / 128 sample slots (dead lanes; two 16-slot rays per tile for S <= 16)."""
     res = {}
     for name, one in (("two", False), ("one", True)):
         cfg = cnr.cfg.synthetic_config(device=str(dev), latent_dim=L, n_bins_cam2surface=n1, n_bins=n2)
@@ -380,7 +386,7 @@ def test_one_launch_step_equals_forward_render_plus_backward(cnr, dev, C, R, n1,
     for k in ("depth", "rgb", "opa"):
         assert rel_l2(a[k], b[k]) < 1e-6, (k, rel_l2(a[k], b[k]))
     assert rel_l2(a["var"], b["var"]) < 1e-5
-    assert rel_l2(a["losses"], b["losses"]) < 1e-5 and torch.equal(a["flags"], b["flags"])
+    assert rel_l2(a["losses"], b["losses"]) < 5e-5 and torch.equal(a["flags"], b["flags"])   # (v_rcp / v_sqrt in the depth weight)
     # (the one-launch kernel forms its quotients with v_rcp_f32, 1 ulp: d sigma differs in the last bit, which the f16 pack of
     #  the scaled gradients turns into an f16 ulp here and there)
     assert rel_l2(a["grad"], b["grad"]) < 1e-4, rel_l2(a["grad"], b["grad"])
