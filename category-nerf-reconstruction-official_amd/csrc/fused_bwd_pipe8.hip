@@ -78,7 +78,7 @@ template <> __host__ __device__ constexpr int local8<4>(int kind) {
 
 // WIDE: more than four object rows per class (up to ROWS_MAX): the row stride of the row-sum block is then a run-time
 // value; with <= 4 rows it is the constant 4 and the index arithmetic folds (1 us of the kernel at 2048 x 64).
-template <int NCH, int NDW, bool WIDE, int KR, bool TWO>
+template <int NCH, int NDW, bool WIDE, int KR, bool TWO, bool PAD>
 __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
     const float* __restrict__ pts, const float* __restrict__ Bdir, const unsigned char* __restrict__ packed,
     const float* __restrict__ biasrows, const int* __restrict__ ray_row, float inv_scale,
@@ -87,6 +87,7 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
     int* __restrict__ clamp_flags, TrainArgs ta) {
   static_assert(KR == 0 || KR == 1 || KR == 2 || KR == 4, "tiles per ray");
   static_assert(!TWO || KR == 1, "two rays per tile only with one tile per ray");
+  static_assert(!TWO || PAD, "16-slot rays are the padded form");   // PAD = false: S == SP exactly (the plain index arithmetic)
   constexpr int SP = TWO ? 16 : (KR > 0 ? 32 * KR : 32);   // padded sample slots per ray (one-launch form)
   constexpr int NCHW = NCH, NTHR = (NCH + NDW) * 64, NACC = 5, LI_RS = local8<NDW>(BK_RS);
   // per chain wave: E1 image, E2 image, dPre / input slot, row one-hot table (the flush reuses it for the wave's
@@ -160,18 +161,27 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
       const int n0 = tl * 32;
       TileIn t;
       if constexpr (KR > 0) {
-        // padded slots: lane col of tile tl is slot 32 tl + col = sample slot % SP of ray slot / SP; samples >= S and rays
-        // >= R are dead lanes (they run the forward on a clamped address and contribute nothing)
-        const int slot = n0 + col, ray_l = slot / SP, sidx = slot % SP;
-        const bool ray_ok = tile_ok && ray_l < R, lane_ok = ray_ok && sidx < S;
-        const int64_t ray = (int64_t)c * R + (ray_l < R ? ray_l : R - 1);
-        const int64_t gs = ray * S + (sidx < S ? sidx : S - 1);
+        int64_t ray, gs;
+        bool ray_ok = tile_ok, lane_ok = tile_ok;
+        if constexpr (PAD) {
+          // padded slots: lane col of tile tl is slot 32 tl + col = sample slot % SP of ray slot / SP; samples >= S and rays
+          // >= R are dead lanes (they run the forward on a clamped address and contribute nothing)
+          const int slot = n0 + col, ray_l = slot / SP, sidx = slot % SP;
+          ray_ok = tile_ok && ray_l < R; lane_ok = ray_ok && sidx < S;
+          ray = (int64_t)c * R + (ray_l < R ? ray_l : R - 1);
+          gs = ray * S + (sidx < S ? sidx : S - 1);
+        } else {  // S = 32 KR: tile tl is samples [32 (tl % KR), + 32) of ray tl / KR, never partial
+          ray = (int64_t)c * R + tl / KR;
+          gs = (int64_t)c * N + n0 + col;
+        }
         const float* pp = pts + gs * 3;
         t.px = pp[0]; t.py = pp[1]; t.pz = pp[2];
         t.row = ray_row ? ray_row[ray] : (int)ray;
-        t.z = ta.z[gs]; t.gtd = ta.gt_depth[ray];
-        t.g0 = ta.gt_rgb[ray * 3 + 0]; t.g1 = ta.gt_rgb[ray * 3 + 1]; t.g2 = ta.gt_rgb[ray * 3 + 2];
-        t.lab = ta.labels[ray]; t.dm = ta.depth_mask[ray]; t.live = lane_ok ? 1 : 0; t.rlive = ray_ok ? 1 : 0;
+        t.live = lane_ok ? 1 : 0; t.rlive = PAD ? (ray_ok ? 1 : 0) : 0;
+        // the render-side inputs (z, targets, label) are first used ~4 k cycles into the iteration, by the composite: they
+        // are requested at the START of their own iteration (render_inputs), not with the prefetch three steps before the
+        // previous one ends -- seven registers less while the d e1 accumulators (48) are live, which is where the kernel spilled
+        t.z = t.gtd = t.g0 = t.g1 = t.g2 = 0.0f; t.lab = t.dm = 0;
         t.dsg = t.dr0 = t.dr1 = t.dr2 = 0.0f;
         return t;
       }
@@ -193,6 +203,22 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
       t.z = t.gtd = t.g0 = t.g1 = t.g2 = 0.0f; t.lab = t.dm = 0; t.live = live ? 1 : 0; t.rlive = t.live;
       return t;
     };
+    auto render_inputs = [&](TileIn& t, int tile) {   // KR > 0: same index arithmetic as fetch
+      const int tl = tile < ntiles ? tile : ntiles - 1;
+      const int n0 = tl * 32;
+      int64_t ray, gs;
+      if constexpr (PAD) {
+        const int slot = n0 + col, ray_l = slot / SP, sidx = slot % SP;
+        ray = (int64_t)c * R + (ray_l < R ? ray_l : R - 1);
+        gs = ray * S + (sidx < S ? sidx : S - 1);
+      } else {
+        ray = (int64_t)c * R + tl / (KR > 0 ? KR : 1);
+        gs = (int64_t)c * N + n0 + col;
+      }
+      t.z = ta.z[gs]; t.gtd = ta.gt_depth[ray];
+      t.g0 = ta.gt_rgb[ray * 3 + 0]; t.g1 = ta.gt_rgb[ray * 3 + 1]; t.g2 = ta.gt_rgb[ray * 3 + 2];
+      t.lab = ta.labels[ray]; t.dm = ta.depth_mask[ray];
+    };
     // ---- one-launch step: this class's loss weights from the epoch's mask-count table, loss partial sums ------------
     float wd_c = 0.f, wc_c = 0.f, wo_c = 0.f, ld_acc = 0.f, lc_acc = 0.f, lo_acc = 0.f;
     int tab_flags = 0;
@@ -212,6 +238,7 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
       P8STAMP_RESET();
       P8STAMP();
       // ---- this lane's sample (fetched during the previous iteration's shape_layer_2 step) -------------------
+      if constexpr (KR > 0) render_inputs(cur, tile);
       const float t0x = cur.px * inv_scale, t1x = cur.py * inv_scale, t2x = cur.pz * inv_scale;
       const int row = cur.row;
       // upstream gradients: given (KR == 0) or formed after this tile's forward by the composite / loss block below
@@ -392,26 +419,34 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
         // m_l and M2_l = sum tl (z - m_l)^2; with mean = depth / opacity over the ray,
         //   var = sum_t c_t (M2_t + w_t (m_t - mean)^2) + opacity (mean - depth)^2      (exact; c_t = carried transmittance)
         float carry = 1.0f, sd = d_l, so = w_l, sr = r_l, sg = g_l, sb = b_l, sv;
-        f4 xa[KR > 1 ? KR : 1], xb[KR > 1 ? KR : 1];   // the ray's tiles: {P, w, d, r} {g, b, M2, m}
+        // the ray's tiles: {P, w, d, r} {g, b, M2, m} per tile, kept in registers for the three passes below (re-reading the
+        // four tiles of a 128-slot ray from LDS in every pass instead was measured 2 % slower at 8192 x 128)
+        constexpr bool XREG = KR >= 2;
+        f4 xa[XREG ? KR : 1], xb[XREG ? KR : 1];
         float cpre[KR > 1 ? KR : 1];                    // carried transmittance in front of tile t
+        auto XA = [&](int t) { return XREG ? xa[XREG ? t : 0] : reinterpret_cast<const f4*>(xch + (wv0 + t) * 8)[0]; };
+        auto XB = [&](int t) { return XREG ? xb[XREG ? t : 0] : reinterpret_cast<const f4*>(xch + (wv0 + t) * 8)[1]; };
         if constexpr (KR > 1) {
           if (lane == 0) {
             f4* x = reinterpret_cast<f4*>(xch + wv * 8);
             x[0] = f4{Pt, w_l, d_l, r_l}; x[1] = f4{g_l, b_l, M2_l, m_l};
           }
           P8SYNC();
+          if constexpr (XREG) {
 #pragma unroll
-          for (int t = 0; t < KR; ++t) {
-            const f4* x = reinterpret_cast<const f4*>(xch + (wv0 + t) * 8);
-            xa[t] = x[0]; xb[t] = x[1];
+            for (int t = 0; t < KR; ++t) {
+              const f4* x = reinterpret_cast<const f4*>(xch + (wv0 + t) * 8);
+              xa[t] = x[0]; xb[t] = x[1];
+            }
           }
           sd = so = sr = sg = sb = 0.0f;
           float run = 1.0f;
 #pragma unroll
           for (int t = 0; t < KR; ++t) {
+            const f4 a4 = XA(t), b4 = XB(t);
             cpre[t] = run;
-            so += run * xa[t][1]; sd += run * xa[t][2]; sr += run * xa[t][3]; sg += run * xb[t][0]; sb += run * xb[t][1];
-            run *= xa[t][0];
+            so += run * a4[1]; sd += run * a4[2]; sr += run * a4[3]; sg += run * b4[0]; sb += run * b4[1];
+            run *= a4[0];
           }
 #pragma unroll
           for (int t = 0; t < KR; ++t) carry = t == tin ? cpre[t] : carry;
@@ -422,8 +457,9 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
           float M2 = 0.0f;
 #pragma unroll
           for (int t = 0; t < KR; ++t) {
-            const float dm = xb[t][3] - mean;
-            M2 += cpre[t] * (xb[t][2] + xa[t][1] * dm * dm);
+            const f4 a4 = XA(t), b4 = XB(t);
+            const float dm = b4[3] - mean;
+            M2 += cpre[t] * (b4[2] + a4[1] * dm * dm);
           }
           sv = M2 + so * (mean - sd) * (mean - sd);
         } else {
@@ -440,12 +476,12 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
         const float info = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(sv) + 1e-4f);
         const float rc0 = sr - cur.g0, rc1 = sg - cur.g1, rc2 = sb - cur.g2;
         const float ro = so - fo;
-        if (tin == 0 && cur.rlive) {   // the ray's first tile accounts for it (uniform over the ray's lanes)
+        if (tin == 0 && (PAD ? cur.rlive : cur.live)) {   // the ray's first tile accounts for it (uniform over its lanes)
           ld_acc += fabsf(rd) * fd * info;
           lc_acc += (fabsf(rc0) + fabsf(rc1) + fabsf(rc2)) * fo;
           lo_acc += fabsf(ro) * fs;
           if (lane == 0 || (TWO && lane == 16)) {
-            const int ray = c * R + (tile * 32 + col) / SP;     // (C R < 2^31: checked by the host)
+            const int ray = c * R + (PAD ? (tile * 32 + col) / SP : tile / KR);     // (C R < 2^31: checked by the host)
             if (ta.depth_out) ta.depth_out[ray] = sd;
             if (ta.var_out) ta.var_out[ray] = sv;
             if (ta.opacity_out) ta.opacity_out[ray] = so;
@@ -464,7 +500,8 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
         if constexpr (KR > 1) {
 #pragma unroll
           for (int t = 0; t < KR; ++t) {
-            const float tot = cpre[t] * (dD * xa[t][2] + dR * xa[t][3] + dG * xb[t][0] + dBl * xb[t][1] + dO * xa[t][1]);
+            const f4 a4 = XA(t), b4 = XB(t);
+            const float tot = cpre[t] * (dD * a4[2] + dR * a4[3] + dG * b4[0] + dBl * b4[1] + dO * a4[1]);
             suf_carry += t > tin ? tot : 0.0f;
           }
         }
@@ -833,20 +870,20 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
 }  // namespace
 
 // launched by cnr_field_bwd_pipe (fused_bwd_pipe.hip) for chain_waves = 4: same argument checks, same records
-template <bool WIDE, int KR, bool TWO = false>
+template <bool WIDE, int KR, bool TWO = false, bool PAD = false>
 static int launch_p8(const float* pts, const float* B, const void* packed, const float* biasrows, const int* ray_row,
                      float scale, const float* d_sigma, const float* d_rgb, float grad_scale, int C, int R, int S,
                      int rows_per_class, int blocks, void* workspace, int64_t B_stride, long long* rows_fix,
                      int* clamp_flags, const TrainArgs& ta, void* stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t er = hipFuncSetAttribute((const void*)field_bwd_pipe8_kernel<4, 4, WIDE, KR, TWO>,
+    hipError_t er = hipFuncSetAttribute((const void*)field_bwd_pipe8_kernel<4, 4, WIDE, KR, TWO, PAD>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, l8_total(4));
     if (er != hipSuccess) return (int)er;
     attr_set = true;
   }
   const int64_t N = (int64_t)R * S;
-  hipLaunchKernelGGL((field_bwd_pipe8_kernel<4, 4, WIDE, KR, TWO>), dim3((unsigned)blocks, (unsigned)C), dim3(512), l8_total(4),
+  hipLaunchKernelGGL((field_bwd_pipe8_kernel<4, 4, WIDE, KR, TWO, PAD>), dim3((unsigned)blocks, (unsigned)C), dim3(512), l8_total(4),
                      (hipStream_t)stream, pts, B, (const unsigned char*)packed, biasrows, ray_row, 1.0f / scale, d_sigma,
                      d_rgb, grad_scale, (float*)workspace, (int)N, S, R, rows_per_class,
                      B_stride > 0 ? B_stride : (int64_t)63, rows_fix, clamp_flags, ta);
@@ -861,9 +898,9 @@ extern "C" int cnr_field_bwd_pipe8_launch(const float* pts, const float* B, cons
                                           void* stream) {
   const TrainArgs none{};
   if (rows_per_class > 4)
-    return launch_p8<true, 0, false>(pts, B, packed, biasrows, ray_row, scale, d_sigma, d_rgb, grad_scale, C, R, S, rows_per_class,
+    return launch_p8<true, 0, false, false>(pts, B, packed, biasrows, ray_row, scale, d_sigma, d_rgb, grad_scale, C, R, S, rows_per_class,
                               blocks, workspace, B_stride, rows_fix, clamp_flags, none, stream);
-  return launch_p8<false, 0, false>(pts, B, packed, biasrows, ray_row, scale, d_sigma, d_rgb, grad_scale, C, R, S, rows_per_class,
+  return launch_p8<false, 0, false, false>(pts, B, packed, biasrows, ray_row, scale, d_sigma, d_rgb, grad_scale, C, R, S, rows_per_class,
                              blocks, workspace, B_stride, rows_fix, clamp_flags, none, stream);
 }
 
@@ -903,19 +940,22 @@ extern "C" int cnr_field_train(const float* pts, const float* B, const void* pac
     return CNR_E_ARG;
   const TrainArgs ta{z, gt_depth, gt_rgb, labels, depth_mask, counts_tab, d_state, color_scaling, opacity_scaling,
                      loss_scale, depth, var, rgb, opacity, (float*)loss_workspace};
-#define CNR_FT(WIDE, KR, TWO)                                                                                         \
-  return launch_p8<WIDE, KR, TWO>(pts, B, packed, biasrows, ray_row, scale, nullptr, nullptr, grad_scale, C, R, S,     \
-                                  rows_per_class, blocks, records, B_stride, rows_fix, clamp_flags, ta, stream)
+#define CNR_FT(WIDE, KR, TWO, PAD)                                                                                    \
+  return launch_p8<WIDE, KR, TWO, PAD>(pts, B, packed, biasrows, ray_row, scale, nullptr, nullptr, grad_scale, C, R, S, \
+                                       rows_per_class, blocks, records, B_stride, rows_fix, clamp_flags, ta, stream)
+  const bool pad = S != sp;   // exact fit: the plain index arithmetic (2 % faster at configs[1] than the padded form)
   if (rows_per_class > 4) {
-    if (sp == 16) CNR_FT(true, 1, true);
-    if (sp == 32) CNR_FT(true, 1, false);
-    if (sp == 64) CNR_FT(true, 2, false);
-    CNR_FT(true, 4, false);
+    if (sp == 16) CNR_FT(true, 1, true, true);
+    if (sp == 32) { if (pad) CNR_FT(true, 1, false, true); CNR_FT(true, 1, false, false); }
+    if (sp == 64) { if (pad) CNR_FT(true, 2, false, true); CNR_FT(true, 2, false, false); }
+    if (pad) CNR_FT(true, 4, false, true);
+    CNR_FT(true, 4, false, false);
   }
-  if (sp == 16) CNR_FT(false, 1, true);
-  if (sp == 32) CNR_FT(false, 1, false);
-  if (sp == 64) CNR_FT(false, 2, false);
-  CNR_FT(false, 4, false);
+  if (sp == 16) CNR_FT(false, 1, true, true);
+  if (sp == 32) { if (pad) CNR_FT(false, 1, false, true); CNR_FT(false, 1, false, false); }
+  if (sp == 64) { if (pad) CNR_FT(false, 2, false, true); CNR_FT(false, 2, false, false); }
+  if (pad) CNR_FT(false, 4, false, true);
+  CNR_FT(false, 4, false, false);
 #undef CNR_FT
 }
 
