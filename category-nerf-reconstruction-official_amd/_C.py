@@ -45,8 +45,8 @@ SIGNATURES = {
     "cnr_field_bwd_workspace_bytes": [_i, _i],
     "cnr_field_bwd_pipe_blocks": [_i, _i, _i, _i],
     "cnr_gather_pool": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "cnr_dense_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
-    "cnr_dense_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i64, _vp],
+    "cnr_dense_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "cnr_dense_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i64, _i, _f, _vp],
     "cnr_dense_bwd_workspace_bytes": [_i, _i, _i],
     "cnr_step_prologue": [_vp, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _i64,
                           _vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64, _vp, _i64, _vp, _i, _i, _i, _i, _f, _f, _f,

@@ -15,7 +15,7 @@ from . import _C, loss as loss_mod, ops, trainer as trainer_mod
 
 
 class BackgroundStep:
-    def __init__(self, cfg, pool, rays_per_step=None, device=None, seed=0):
+    def __init__(self, cfg, pool, rays_per_step=None, device=None, seed=0, precision="fp32"):
         import copy
         self.cfg = cfg
         self.device = torch.device(device or cfg.training_device)
@@ -24,6 +24,10 @@ class BackgroundStep:
         tcfg = copy.copy(cfg)
         tcfg.hidden_feature_size, tcfg.obj_scale, tcfg.training_device = cfg.hidden_feature_size_bg, cfg.bg_scale, str(self.device)
         self.trainer = trainer_mod.Trainer(tcfg, 0, [0])                     # .pe, .fc_occ_map (src/trainer.py:23-25)
+        assert precision in ("fp32", "f16")
+        # "f16": the hidden layers' products on f16 MFMA operands with fp32 accumulation (ops.DenseFn half=True; the x10
+        # occupancy head stays fp32, like the sigma head of the category kernel); "fp32": the exact tier (default)
+        self.trainer.fc_occ_map.half = precision == "f16"
         dev = self.device
         self.pool = dict(rgbs=pool["rgbs"].to(dev)[None].contiguous(), depth=pool["depth"].to(dev)[None].contiguous(),
                          dirs=pool["dirs"].to(dev)[None].contiguous(), T=pool["T_wc"].to(dev)[None].contiguous())

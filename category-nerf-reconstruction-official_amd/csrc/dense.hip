@@ -13,11 +13,18 @@
 // wave a 32 x 32 quadrant; 32-deep slabs of A and B go through LDS as [i][r] / [j][r] (row stride 33: the per-lane
 // operand reads hit 32 different banks) whatever their orientation in memory -- global reads always run along the
 // contiguous dimension.
+//
+// HALF = true (f16_operands != 0 in the C-ABI): the same kernel with both operands rounded to f16 when they are staged in
+// LDS and v_mfma_f32_32x32x16_f16 (fp32 accumulation): 2 instead of 16 matrix instructions and 2 x 16-byte instead of
+// 32 x 4-byte LDS reads per lane and 32-deep slab.  Gradient operands are multiplied by `a_scale` (a power of two, the loss
+// scale of the f16 chain) on the way in and the result by 1 / a_scale on the way out.  This is the f16 tier of the
+// background model (the exact-fp32 form stays the parity tier).
 #include "cnr_common.h"
 
 namespace {
 typedef float f16acc __attribute__((ext_vector_type(16)));
-constexpr int TM = 64, TN = 64, TK = 32, LDT = TK + 1;
+typedef _Float16 hv8 __attribute__((ext_vector_type(8)));
+constexpr int TM = 64, TN = 64, TK = 32, LDT = TK + 1, LDH = TK + 8;   // LDH: f16 row stride (80 B: 16-byte aligned rows)
 
 struct DenseArgs {
   const float* A; int64_t lda; int a_trans;   // a_trans: A(i, r) = A[r * lda + i], else A[i * lda + r]
@@ -28,11 +35,15 @@ struct DenseArgs {
   float* extra_col; int extra_j;              // column j == extra_j (>= 0) goes to extra_col[i]; B(extra_j, r) = 1
   int I, J, Rn;
   int r_chunk; int64_t c_zstride;             // split over r: block z takes r in [z r_chunk, (z+1) r_chunk) and
-};                                            // writes its partial product to C + z c_zstride
+  float a_scale;                              // writes its partial product to C + z c_zstride ; HALF: A x a_scale, C / a_scale
+};
 
+template <bool HALF>
 __global__ __launch_bounds__(256) void dense_kernel(DenseArgs p) {
-  __shared__ float As[TM * LDT];
-  __shared__ float Bs[TN * LDT];
+  __shared__ __attribute__((aligned(16))) float As[TM * LDT];   // HALF: reinterpreted as _Float16 [TM][LDH]
+  __shared__ __attribute__((aligned(16))) float Bs[TN * LDT];
+  _Float16* Ah = reinterpret_cast<_Float16*>(As);
+  _Float16* Bh = reinterpret_cast<_Float16*>(Bs);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int i0 = blockIdx.y * TM, j0 = blockIdx.x * TN;
   const int wi = (wv >> 1) * 32, wj = (wv & 1) * 32;
@@ -41,8 +52,11 @@ __global__ __launch_bounds__(256) void dense_kernel(DenseArgs p) {
   for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
   const int r_lo = blockIdx.z * p.r_chunk, r_hi = r_lo + p.r_chunk < p.Rn ? r_lo + p.r_chunk : p.Rn;
   float* Cz = p.C + (int64_t)blockIdx.z * p.c_zstride;
-  for (int r0 = r_lo; r0 < r_hi; r0 += TK) {
-    // ---- slab loads: 64 x 32 elements each, 8 per thread, consecutive threads along the contiguous dimension ----
+  // ---- slab loads: 64 x 32 elements each, 8 per thread, consecutive threads along the contiguous dimension.  The loads of
+  // slab k + 1 are issued before the products of slab k (registers -> LDS after them): a block used to walk load -> barrier
+  // -> products -> barrier per slab, one memory round trip per 32 of K with nothing to overlap it
+  float an[8], bn[8];
+  auto load_slab = [&](int r0) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int idx = e * 256 + threadIdx.x;
@@ -55,7 +69,7 @@ __global__ __launch_bounds__(256) void dense_kernel(DenseArgs p) {
         v = p.A[off];
         if (p.mask && !(p.mask[off] > 0.0f)) v = 0.0f;
       }
-      As[ii * LDT + rr] = v;
+      an[e] = v;
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -68,15 +82,42 @@ __global__ __launch_bounds__(256) void dense_kernel(DenseArgs p) {
         if (gj == p.extra_j) v = 1.0f;
         else if (gj < p.J) v = p.B[p.b_trans ? (int64_t)gr * p.ldb + gj : (int64_t)gj * p.ldb + gr];
       }
-      Bs[jj * LDT + rr] = v;
+      bn[e] = v;
+    }
+  };
+  load_slab(r_lo);
+  for (int r0 = r_lo; r0 < r_hi; r0 += TK) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int idx = e * 256 + threadIdx.x;
+      int ii, rr, jj, rb;
+      if (p.a_trans) { ii = idx & 63; rr = idx >> 6; } else { rr = idx & 31; ii = idx >> 5; }
+      if (p.b_trans) { jj = idx & 63; rb = idx >> 6; } else { rb = idx & 31; jj = idx >> 5; }
+      if (HALF) {
+        Ah[ii * LDH + rr] = (_Float16)fminf(fmaxf(an[e] * p.a_scale, -60000.0f), 60000.0f);
+        Bh[jj * LDH + rb] = (_Float16)bn[e];
+      } else {
+        As[ii * LDT + rr] = an[e];
+        Bs[jj * LDT + rb] = bn[e];
+      }
     }
     __syncthreads();
+    if (r0 + TK < r_hi) load_slab(r0 + TK);
     // ---- 16 MFMAs of depth 2: lane (lane & 31) = row of its operand, (lane >> 5) = which of the two r ----
+    if constexpr (HALF) {  // lane (lane & 31) = row of its operand, (lane >> 5) = which 8 of the k-step's 16 r
 #pragma unroll
-    for (int kk = 0; kk < TK; kk += 2) {
-      const float a = As[(wi + (lane & 31)) * LDT + kk + (lane >> 5)];
-      const float b = Bs[(wj + (lane & 31)) * LDT + kk + (lane >> 5)];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      for (int ks = 0; ks < TK; ks += 16) {
+        const hv8 a = *reinterpret_cast<const hv8*>(Ah + (wi + (lane & 31)) * LDH + ks + 8 * (lane >> 5));
+        const hv8 b = *reinterpret_cast<const hv8*>(Bh + (wj + (lane & 31)) * LDH + ks + 8 * (lane >> 5));
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < TK; kk += 2) {
+        const float a = As[(wi + (lane & 31)) * LDT + kk + (lane >> 5)];
+        const float b = Bs[(wj + (lane & 31)) * LDT + kk + (lane >> 5)];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      }
     }
     __syncthreads();
   }
@@ -87,7 +128,7 @@ __global__ __launch_bounds__(256) void dense_kernel(DenseArgs p) {
   for (int q = 0; q < 16; ++q) {
     const int i = i0 + wi + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
     if (i >= p.I) continue;
-    float v = acc[q] + bj;
+    float v = (HALF ? acc[q] * (1.0f / p.a_scale) : acc[q]) + bj;
     if (p.relu) v = fmaxf(v, 0.0f);
     if (j < p.J) Cz[(int64_t)i * p.ldc + j] = v;
     else if (j == p.extra_j) {
@@ -112,20 +153,21 @@ __global__ __launch_bounds__(256) void dense_reduce_kernel(const float* __restri
   }
 }
 
-int launch(const DenseArgs& p, void* stream, int nz = 1) {
+int launch(const DenseArgs& p, void* stream, int nz = 1, bool half = false) {
   const int jn = p.extra_j >= 0 ? p.J + 1 : p.J;
   dim3 grid((jn + TN - 1) / TN, (p.I + TM - 1) / TM, nz);
-  hipLaunchKernelGGL(dense_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+  if (half) hipLaunchKernelGGL(dense_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(dense_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, p);
   CNR_LAUNCH_CHECK();
   return CNR_OK;
 }
 }  // namespace
 
 extern "C" int cnr_dense_fwd(const float* x, const float* W, const float* b, float* y, int M, int K, int N, int relu,
-                             void* stream) {
+                             int f16_operands, void* stream) {
   if (!x || !W || !y || M <= 0 || K <= 0 || N <= 0) return CNR_E_ARG;
-  DenseArgs p{x, K, 0, W, K, 0, nullptr, 0, b, relu, y, N, nullptr, -1, M, N, K, K, 0};
-  return launch(p, stream);
+  DenseArgs p{x, K, 0, W, K, 0, nullptr, 0, b, relu, y, N, nullptr, -1, M, N, K, K, 0, 1.0f};
+  return launch(p, stream, 1, f16_operands != 0);
 }
 
 // number of sample chunks of the dW product: enough blocks to fill the chip, at least 256 samples each
@@ -143,12 +185,14 @@ extern "C" int64_t cnr_dense_bwd_workspace_bytes(int M, int K, int N) {
 
 extern "C" int cnr_dense_bwd(const float* x, const float* W, const float* y, const float* dy, float* dx, float* dW,
                              float* db, int M, int K, int N, int relu, void* workspace, int64_t workspace_bytes,
-                             void* stream) {
+                             int f16_operands, float grad_scale, void* stream) {
   if (!x || !W || !dy || !dW || M <= 0 || K <= 0 || N <= 0 || (relu && !y)) return CNR_E_ARG;
+  const bool half = f16_operands != 0;
+  const float gs = half ? (grad_scale > 0.0f ? grad_scale : 1.0f) : 1.0f;
   const float* mask = relu ? y : nullptr;
   if (dx) {  // dx (M x K) = dpre (M x N) W (N x K): r = N, B(j = k, r = n) = W[n * K + k]
-    DenseArgs p{dy, N, 0, W, K, 1, mask, 1, nullptr, 0, dx, K, nullptr, -1, M, K, N, N, 0};
-    const int rc = launch(p, stream);
+    DenseArgs p{dy, N, 0, W, K, 1, mask, 1, nullptr, 0, dx, K, nullptr, -1, M, K, N, N, 0, gs};
+    const int rc = launch(p, stream, 1, half);
     if (rc) return rc;
   }
   // dW (N x K) = dpre^T x: r = M, A(i = n, r = m) = dy[m * N + n], B(j = k, r = m) = x[m * K + k]; column K = db.
@@ -156,15 +200,15 @@ extern "C" int cnr_dense_bwd(const float* x, const float* W, const float* y, con
   // chunk of samples, partial products to the workspace) and add the partials in a fixed order.
   const int nz = dense_split(M);
   if (nz == 1) {
-    DenseArgs p{dy, N, 1, x, K, 1, mask, 1, nullptr, 0, dW, K, db, db ? K : -1, N, K, M, M, 0};
-    return launch(p, stream);
+    DenseArgs p{dy, N, 1, x, K, 1, mask, 1, nullptr, 0, dW, K, db, db ? K : -1, N, K, M, M, 0, gs};
+    return launch(p, stream, 1, half);
   }
   const int ld = K + (db ? 1 : 0);
   if (!workspace || workspace_bytes < (int64_t)nz * N * ld * (int64_t)sizeof(float)) return CNR_E_ARG;
   const int chunk = ((M + nz - 1) / nz + TK - 1) / TK * TK;
   DenseArgs p{dy, N, 1, x, K, 1, mask, 1, nullptr, 0, (float*)workspace, ld, nullptr, db ? K : -1, N, K, M, chunk,
-              (int64_t)N * ld};
-  const int rc = launch(p, stream, (M + chunk - 1) / chunk);
+              (int64_t)N * ld, gs};
+  const int rc = launch(p, stream, (M + chunk - 1) / chunk, half);
   if (rc) return rc;
   const int64_t n = (int64_t)N * ld;
   hipLaunchKernelGGL(dense_reduce_kernel, dim3((unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024)), dim3(256), 0,

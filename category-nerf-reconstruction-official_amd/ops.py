@@ -335,18 +335,23 @@ def pack_weights(trunk):
 # ------------------------------------------------------------------------------------------------
 # SURVEY 8(f).1  dense layers of the background OccupancyMap (src/model.py:86-155)
 # ------------------------------------------------------------------------------------------------
+DENSE_GRAD_SCALE = 1024.0   # loss scale of the f16 dense tier's gradient operands (a power of two)
+
+
 class DenseFn(Function):
-    """y = act(x W^T + b) on the exact-fp32 MFMA kernel (cnr_dense_fwd / cnr_dense_bwd); x (..., K), W (N, K)."""
+    """y = act(x W^T + b) on the MFMA dense kernel (cnr_dense_fwd / cnr_dense_bwd); x (..., K), W (N, K).
+    half = False: exact fp32 (v_mfma_f32_32x32x2_f32), the parity tier; half = True: operands rounded to f16 in LDS,
+    v_mfma_f32_32x32x16_f16, fp32 accumulation -- the f16 tier of the background model."""
 
     @staticmethod
-    def forward(ctx, x, W, b, relu):
+    def forward(ctx, x, W, b, relu, half=False):
         K, N = W.shape[1], W.shape[0]
         x2 = x.reshape(-1, K).contiguous()
         y = torch.empty(x2.shape[0], N, device=x.device, dtype=torch.float32)
         _C.call("cnr_dense_fwd", x2, W.contiguous(), b.contiguous() if b is not None else None, y, x2.shape[0], K, N,
-                int(bool(relu)))
+                int(bool(relu)), int(bool(half)))
         ctx.save_for_backward(x2, W, y)
-        ctx.relu, ctx.xshape, ctx.has_b = bool(relu), x.shape, b is not None
+        ctx.relu, ctx.xshape, ctx.has_b, ctx.half = bool(relu), x.shape, b is not None, bool(half)
         return y.reshape(*x.shape[:-1], N)
 
     @staticmethod
@@ -359,8 +364,9 @@ class DenseFn(Function):
         db = torch.empty(N, device=dy.device, dtype=torch.float32) if ctx.has_b else None
         wsb = int(_C.load().cnr_dense_bwd_workspace_bytes(M, K, N))
         ws = torch.empty(max(wsb, 16), device=dy.device, dtype=torch.uint8)
-        _C.call("cnr_dense_bwd", x2, W.contiguous(), y, dy2, dx, dW, db, M, K, N, int(ctx.relu), ws, wsb)
-        return (dx.reshape(ctx.xshape) if dx is not None else None), dW, db, None
+        _C.call("cnr_dense_bwd", x2, W.contiguous(), y, dy2, dx, dW, db, M, K, N, int(ctx.relu), ws, wsb, int(ctx.half),
+                DENSE_GRAD_SCALE)
+        return (dx.reshape(ctx.xshape) if dx is not None else None), dW, db, None, None
 
 
 # cnr_field_bwd variants: "split" = two block-split launches (csrc/fused_bwd.hip), "pipe2"/"pipe3" = the single

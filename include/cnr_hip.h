@@ -214,10 +214,15 @@ int cnr_field_bwd(const float* pts, const float* B, const void* packed, const fl
  * workspace: >= cnr_dense_bwd_workspace_bytes(M, K, N) bytes (0 for M <= 256): the dW product is split over
  * chunks of samples whose partial results are added in a fixed order (reproducible, no atomics). */
 int cnr_dense_fwd(const float* x, const float* W, const float* b, float* y, int M, int K, int N, int relu,
-                  void* stream);
+                  int f16_operands, void* stream);
 int64_t cnr_dense_bwd_workspace_bytes(int M, int K, int N);
 int cnr_dense_bwd(const float* x, const float* W, const float* y, const float* dy, float* dx, float* dW, float* db,
-                  int M, int K, int N, int relu, void* workspace, int64_t workspace_bytes, void* stream);
+                  int M, int K, int N, int relu, void* workspace, int64_t workspace_bytes, int f16_operands,
+                  float grad_scale, void* stream);
+/* f16_operands != 0: both operands of every product are rounded to f16 as they are staged in LDS and the matrix instruction
+ * is v_mfma_f32_32x32x16_f16 (fp32 accumulation, fp32 results): the f16 tier of the background model.  In the backward the
+ * gradient operand is multiplied by grad_scale (a power of two, the loss scale of the f16 chain; <= 0: 1) on the way in and
+ * the products by 1 / grad_scale on the way out. */
 
 /* ---- ray-pool construction from frames (src/scene_cateogries.py:164-260, 262-325) ------------
  * images (F,W,H,3) u8, depth (F,W,H) f32, obj_mask (F,W,H) i32 (instance id per pixel, -1 unknown), rays_dir (W,H,3):

@@ -67,3 +67,55 @@ def test_whole_iteration_in_one_graph_equals_the_two_steps_run_separately(cnr, d
     assert torch.equal(tr_a.theta, tr_b.theta) and torch.equal(tr_a.losses, tr_b.losses)
     assert rel_l2(_flat(bg_a), _flat(bg_b)) < 1e-4 and rel_l2(bg_a.losses, bg_b.losses) < 1e-3
     assert tr_a.steps_done == 11 and bg_a.steps_done == 11
+
+
+@pytest.mark.parametrize("M,K,N,relu", [(16800, 215, 128, True), (1000, 87, 128, True), (513, 128, 3, False)])
+def test_f16_dense_mode_against_torch_emulation(cnr, dev, M, K, N, relu):
+    """cnr_dense_fwd / cnr_dense_bwd with f16_operands: both operands rounded to f16, fp32 accumulation -- against torch on
+    f16-rounded operands in fp64 (forward 1e-5: same products, fp32 summation order), and against the exact layer at the f16
+    level; the gradient operand carries a 2^10 loss scale so that small gradients do not fall into f16 subnormals."""
+    gen = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=gen).to(dev)
+    W = (torch.randn(N, K, generator=gen) * 0.2).to(dev).requires_grad_()
+    b = (torch.randn(N, generator=gen) * 0.1).to(dev).requires_grad_()
+    xg = x.clone().requires_grad_()
+    y = cnr.ops.DenseFn.apply(xg, W, b, relu, True)
+    q = lambda t: t.half().double()
+    pre = q(x) @ q(W.detach()).T + b.detach().double()
+    want = torch.relu(pre) if relu else pre
+    assert rel_l2(y, want) < 1e-5
+    exact = torch.nn.functional.linear(x, W.detach(), b.detach())
+    assert rel_l2(y, torch.relu(exact) if relu else exact) < 2e-3
+    dy = (torch.randn(M, N, generator=gen) * 1e-4).to(dev)            # small upstream gradients, like 1 / rays
+    y.backward(dy)
+    dpre = dy.double() * ((pre > 0).double() if relu else 1.0)
+    s = cnr.ops.DENSE_GRAD_SCALE
+    dq = (dpre * s).half().double() / s
+    assert rel_l2(xg.grad, dq @ q(W.detach())) < 1e-4
+    assert rel_l2(W.grad, dq.T @ q(x)) < 1e-4 and rel_l2(b.grad, dq.sum(0)) < 1e-4
+    assert rel_l2(W.grad, dpre.T @ x.double()) < 3e-3                 # against the exact gradient: the f16 level
+
+
+def test_background_f16_tier_tracks_the_fp32_tier(cnr, dev):
+    """BackgroundStep(precision="f16"): same samples, same losses to the f16 level over the first steps, and faster."""
+    import time
+    a, b = _bg(cnr, dev, R=1200), _bg(cnr, dev, R=1200)
+    b.trainer.fc_occ_map.half = True
+    for it in range(4):
+        a.step(use_graph=False)
+        b.step(use_graph=False)
+        torch.cuda.synchronize()
+        assert torch.equal(a.bufs["z"], b.bufs["z"])
+        assert rel_l2(b.losses, a.losses) < (2e-3 if it == 0 else 2e-2), (it, a.losses, b.losses)
+    out = {}
+    for name, bg in (("fp32", a), ("f16", b)):
+        for _ in range(6):
+            bg.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            bg.step()
+        torch.cuda.synchronize()
+        out[name] = (time.perf_counter() - t0) / 50 * 1e3
+    print(f"background step 1200 x 13, hidden 128, captured: fp32 tier {out['fp32']:.3f} ms, f16 tier {out['f16']:.3f} ms")
+    assert out["f16"] < out["fp32"]
