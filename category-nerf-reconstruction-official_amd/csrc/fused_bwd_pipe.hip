@@ -632,7 +632,7 @@ extern "C" int cnr_field_bwd_pipe(const float* pts, const float* B, const void* 
   if (C <= 0 || R <= 0 || S <= 0 || !(scale > 0.f) || !(grad_scale > 0.f)) return CNR_E_ARG;
   if (!pipe_waves_ok(chain_waves)) return CNR_E_ARG;
   // the pipeline keeps per-object row sums in one accumulator block: class-major rows, at most ROWS_LDS per class
-  // (ROWS_MAX = 7 in the 8-wave kernel).
+  // (ROWS_MAX = 15 in the 8-wave kernel).
   // Everything else (one row per ray, many objects) takes the block-split kernels.
   if (ray_row == nullptr || rows_per_class < 1 || rows_per_class > (chain_waves == 4 ? cnr_rec::ROWS_MAX : ROWS_LDS)) {
     if (rows_fix || skip_reduce) return CNR_E_ARG;   // those two need the pipelined kernel's per-object rows

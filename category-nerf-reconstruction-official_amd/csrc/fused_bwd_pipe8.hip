@@ -37,10 +37,11 @@ __device__ long long g_pipe8_stamps[8 * 64];
 #define P8STAMP_RESET() do {} while (0)
 #endif
 #define P8SYNC() do { P8STAMP(); role_barrier(); P8STAMP(); } while (0)
-constexpr int C8_BYTES = E1IMG_BYTES + E2IMG_BYTES + 2 * HSIMG_BYTES + 512;  // LDS per chain wave
+constexpr int K8_SMALL_BYTES = (cnr_rec::ROWS_MAX + 1) * 64;  // row one-hot table: ROWS_MAX rows + the ones row, 32 halfs each
+constexpr int C8_BYTES = E1IMG_BYTES + E2IMG_BYTES + 2 * HSIMG_BYTES + K8_SMALL_BYTES;  // LDS per chain wave
 constexpr int L8_BL = PK_BYTES, L8_BR = L8_BL + 272, L8_CHAIN = L8_BR + cnr_rec::ROWS_MAX * 128 * 4;
 constexpr int RS8_REGION = NBLOCKS;
-constexpr int BK_RS = 100;  // pseudo kind of the row-sum block in the ownership tables
+constexpr int BK_RS = 100, BK_RS2 = 101;  // pseudo kinds of the row-sum blocks in the ownership tables
 constexpr int XCH_BYTES = 2 * 4 * 8 * 4;  // one-launch step: four chain waves x eight floats, two copies (iteration parity)
 __host__ __device__ constexpr int l8_xch(int nch) { return L8_CHAIN + nch * C8_BYTES; }
 __host__ __device__ constexpr int l8_total(int nch) {
@@ -60,25 +61,27 @@ static_assert(l8_total(4) <= 160 * 1024, "LDS budget");
 
 // Which dW wave owns a block kind, and the block's index among that wave's accumulators: at most 5 accumulators per
 // wave, one unit of work per wave and layer step (cat_layer: dW3 two)
-//     dW0: row sums, viewdir[y], xyz[e1 0..31]          dW1: rgb.0 (+ rgb.2 rows 16..18), texture_1, cat[y], viewdir[e2 0..31], xyz[e1 32..63]
+//     dW0: row sums (one block; two with more than 7 object rows), viewdir[y], xyz[e1 0..31]          dW1: rgb.0 (+ rgb.2 rows 16..18), texture_1, cat[y], viewdir[e2 0..31], xyz[e1 32..63]
 //     dW2: enc_shape, shape_2, cat[e1 0..31], viewdir[e2 32..], xyz[e1 64..]      dW3: shape_1, cat[e1 32..63], cat[e1 64..]
 template <int NDW> __host__ __device__ constexpr int owner8(int kind);
 template <int NDW> __host__ __device__ constexpr int local8(int kind);
 template <> __host__ __device__ constexpr int owner8<4>(int kind) {
-  return (kind == BK_RS || kind == BK_VD_Y || kind == BK_XYZ_E0) ? 0
+  return (kind == BK_RS || kind == BK_RS2 || kind == BK_VD_Y || kind == BK_XYZ_E0) ? 0
        : (kind == BK_R0 || kind == BK_T1 || kind == BK_CAT_Y || kind == BK_VD_E0 || kind == BK_XYZ_E1) ? 1
        : (kind == BK_ES || kind == BK_S2 || kind == BK_CAT_E0 || kind == BK_VD_E1 || kind == BK_XYZ_E2) ? 2 : 3;
 }
 template <> __host__ __device__ constexpr int local8<4>(int kind) {
-  return kind == BK_RS ? 0 : kind == BK_VD_Y ? 1 : kind == BK_XYZ_E0 ? 2
+  return kind == BK_RS ? 0 : kind == BK_VD_Y ? 1 : kind == BK_XYZ_E0 ? 2 : kind == BK_RS2 ? 3
        : kind == BK_R0 ? 0 : kind == BK_T1 ? 1 : kind == BK_CAT_Y ? 2 : kind == BK_VD_E0 ? 3 : kind == BK_XYZ_E1 ? 4
        : kind == BK_ES ? 0 : kind == BK_S2 ? 1 : kind == BK_CAT_E0 ? 2 : kind == BK_VD_E1 ? 3 : kind == BK_XYZ_E2 ? 4
        : kind == BK_S1 ? 0 : kind == BK_CAT_E1 ? 1 : 2 /* BK_CAT_E2 */;
 }
 
-// WIDE: more than four object rows per class (up to ROWS_MAX): the row stride of the row-sum block is then a run-time
-// value; with <= 4 rows it is the constant 4 and the index arithmetic folds (1 us of the kernel at 2048 x 64).
-template <int NCH, int NDW, bool WIDE, int KR, bool TWO, bool PAD>
+// WIDE: more than four object rows per class: the row stride of the row-sum block is then a run-time value; with <= 4
+// rows it is the constant 4 and the index arithmetic folds (1 us of the kernel at 2048 x 64).  WIDE = 1: up to 7 rows,
+// one row-sum block [4 latent slots x rows | 2 plain biases] (4 * 7 + 2 <= 32 block rows).  WIDE = 2: up to ROWS_MAX =
+// 15 rows, two blocks: A = [slots 0, 1 x rows | 2 plain biases], B = [slots 2, 3 x rows]; a layer step feeds one of them.
+template <int NCH, int NDW, int WIDE, int KR, bool TWO, bool PAD>
 __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
     const float* __restrict__ pts, const float* __restrict__ Bdir, const unsigned char* __restrict__ packed,
     const float* __restrict__ biasrows, const int* __restrict__ ray_row, float inv_scale,
@@ -89,12 +92,13 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
   static_assert(!TWO || KR == 1, "two rays per tile only with one tile per ray");
   static_assert(!TWO || PAD, "16-slot rays are the padded form");   // PAD = false: S == SP exactly (the plain index arithmetic)
   constexpr int SP = TWO ? 16 : (KR > 0 ? 32 * KR : 32);   // padded sample slots per ray (one-launch form)
-  constexpr int NCHW = NCH, NTHR = (NCH + NDW) * 64, NACC = 5, LI_RS = local8<NDW>(BK_RS);
+  constexpr int NCHW = NCH, NTHR = (NCH + NDW) * 64, NACC = 5, LI_RS = local8<NDW>(BK_RS), LI_RS2 = local8<NDW>(BK_RS2);
+  constexpr int RS_ROWS = WIDE == 2 ? cnr_rec::ROWS_MAX : WIDE == 1 ? 7 : 4;  // most object rows this instance takes
   // per chain wave: E1 image, E2 image, dPre / input slot, row one-hot table (the flush reuses it for the wave's
   // partial sums)
   constexpr int K_E1 = 0, K_E2 = E1IMG_BYTES, K_D = K_E2 + E2IMG_BYTES, K_X = K_D + HSIMG_BYTES,
                 K_SMALL = K_X + HSIMG_BYTES, K_BYTES = C8_BYTES;
-  static_assert(K_BYTES == K_SMALL + 512, "layout");
+  static_assert(K_BYTES == K_SMALL + K8_SMALL_BYTES && K8_SMALL_BYTES >= 512, "layout");
   static_assert(NACC >= 4, "the chain role parks its partial sums in accumulators 0..3");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int c = blockIdx.y;
@@ -302,7 +306,7 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
         const int rl = row - c * rows_per_class;
         const int rs = WIDE ? rows_per_class : 4;  // rows per latent slot in the row-sum block; the ones row follows
 #pragma unroll
-        for (int r = 0; r < (WIDE ? cnr_rec::ROWS_MAX : 4); r += 2)  // lane half h writes rows h, h + 2, ...
+        for (int r = 0; r < RS_ROWS; r += 2)  // lane half h writes rows h, h + 2, ...
           if (!WIDE || r + h < rs) rowoh[(r + h) * 32 + col] = rl == r + h ? (_Float16)1 : (_Float16)0;
         if (h == 0) rowoh[rs * 32 + col] = (_Float16)1;
       }
@@ -673,11 +677,13 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
     // row m of the row-sum block: m = rs * latent slot + object row for the four latent layers, then one
     // "ones" row each for the two plain biases (encoding_shape: group 4, rgb.0: group 5)
     const int rs = WIDE ? rows_per_class : 4;  // rows per latent slot (a constant unless WIDE)
-    const int nlat_rows = 4 * rs;
+    // (WIDE = 2: block A holds slots 0, 1 and the two bias rows, block B slots 2, 3)
+    const int nlat_rows = (WIDE == 2 ? 2 : 4) * rs;
     const int rpc_inv = (65536 + rs - 1) / rs;  // m / rs = (m * rpc_inv) >> 16 for m < 32
     const int col_slot = (col * rpc_inv) >> 16;
     const int m_row = col < nlat_rows ? col - col_slot * rs : rs,
-              m_grp = col < nlat_rows ? col_slot : 4 + (col - nlat_rows);
+              m_grp = col < nlat_rows ? col_slot : 4 + (col - nlat_rows),
+              m_grpB = col < nlat_rows ? 2 + col_slot : -1;
     // Where this lane's column of each owned block goes in the record: every block kind is affine in the output row,
     // idx(o) = i0 + o * st (weights: st = the layer's row length; a bias column: st = 1), i0 < 0 = not a parameter.
     // Computed here, while the chain waves recompute the first forward: the flush then stores accumulators straight to
@@ -769,9 +775,11 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
           if constexpr (OWN3) mma_blk(w, IC<K3>{}, IC<SL3>{});
           if constexpr (DO_RS) {
             // RS[m][:] += sum over the tile's samples in m's group of dPre
-            const unsigned int lm = (m_grp == RS_GRP) ? 0xffffffffu : 0u;
-            Wacc[LI_RS] = MFMA(__builtin_bit_cast(h8, (u4v)(fR[w % DEPTH][0] & lm)), fD[w % DEPTH][0], Wacc[LI_RS]);
-            Wacc[LI_RS] = MFMA(__builtin_bit_cast(h8, (u4v)(fR[w % DEPTH][1] & lm)), fD[w % DEPTH][1], Wacc[LI_RS]);
+            constexpr bool BLK_B = WIDE == 2 && (RS_GRP == 2 || RS_GRP == 3);
+            constexpr int LI = BLK_B ? LI_RS2 : LI_RS;
+            const unsigned int lm = ((BLK_B ? m_grpB : m_grp) == RS_GRP) ? 0xffffffffu : 0u;
+            Wacc[LI] = MFMA(__builtin_bit_cast(h8, (u4v)(fR[w % DEPTH][0] & lm)), fD[w % DEPTH][0], Wacc[LI]);
+            Wacc[LI] = MFMA(__builtin_bit_cast(h8, (u4v)(fR[w % DEPTH][1] & lm)), fD[w % DEPTH][1], Wacc[LI]);
           }
         }
       };
@@ -821,14 +829,16 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
     }
     if (dwid == owner8<NDW>(BK_RS)) {  // the row-sum block: [m][feature], m = rows_per_class * latent slot + object row | then the two biases
 #pragma unroll
+      for (int blk = 0; blk < (WIDE == 2 ? 2 : 1); ++blk)
+#pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int m = acc_row(reg, h);
-        const float v = Wacc[LI_RS][reg] * inv_gs;
-        if (m == nlat_rows) rec[OFF_ES_B + col] = v;
-        else if (m == nlat_rows + 1) { if (col < 16) rec[OFF_R0_B + col] = v; }
+        const float v = (blk ? Wacc[LI_RS2][reg] : Wacc[LI_RS][reg]) * inv_gs;
+        if (blk == 0 && m == nlat_rows) rec[OFF_ES_B + col] = v;
+        else if (blk == 0 && m == nlat_rows + 1) { if (col < 16) rec[OFF_R0_B + col] = v; }
         else if (m < nlat_rows && m - ((m * rpc_inv) >> 16) * rs < rows_per_class) {
-          const int slot = (m * rpc_inv) >> 16;
-          const int i = (m - slot * rs) * 128 + slot * 32 + col;  // dbiasrows [row][latent slot][feature]
+          const int slot = 2 * blk + ((m * rpc_inv) >> 16);
+          const int i = (m - ((m * rpc_inv) >> 16) * rs) * 128 + slot * 32 + col;  // dbiasrows [row][latent slot][feature]
           rec[TRUNK + 126 + i] = v;
           if (rows_fix)
             atomicAdd(reinterpret_cast<unsigned long long*>(
@@ -870,7 +880,7 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
 }  // namespace
 
 // launched by cnr_field_bwd_pipe (fused_bwd_pipe.hip) for chain_waves = 4: same argument checks, same records
-template <bool WIDE, int KR, bool TWO = false, bool PAD = false>
+template <int WIDE, int KR, bool TWO = false, bool PAD = false>
 static int launch_p8(const float* pts, const float* B, const void* packed, const float* biasrows, const int* ray_row,
                      float scale, const float* d_sigma, const float* d_rgb, float grad_scale, int C, int R, int S,
                      int rows_per_class, int blocks, void* workspace, int64_t B_stride, long long* rows_fix,
@@ -897,10 +907,13 @@ extern "C" int cnr_field_bwd_pipe8_launch(const float* pts, const float* B, cons
                                           void* workspace, int64_t B_stride, long long* rows_fix, int* clamp_flags,
                                           void* stream) {
   const TrainArgs none{};
-  if (rows_per_class > 4)
-    return launch_p8<true, 0, false, false>(pts, B, packed, biasrows, ray_row, scale, d_sigma, d_rgb, grad_scale, C, R, S, rows_per_class,
+  if (rows_per_class > 7)
+    return launch_p8<2, 0, false, false>(pts, B, packed, biasrows, ray_row, scale, d_sigma, d_rgb, grad_scale, C, R, S, rows_per_class,
                               blocks, workspace, B_stride, rows_fix, clamp_flags, none, stream);
-  return launch_p8<false, 0, false, false>(pts, B, packed, biasrows, ray_row, scale, d_sigma, d_rgb, grad_scale, C, R, S, rows_per_class,
+  if (rows_per_class > 4)
+    return launch_p8<1, 0, false, false>(pts, B, packed, biasrows, ray_row, scale, d_sigma, d_rgb, grad_scale, C, R, S, rows_per_class,
+                              blocks, workspace, B_stride, rows_fix, clamp_flags, none, stream);
+  return launch_p8<0, 0, false, false>(pts, B, packed, biasrows, ray_row, scale, d_sigma, d_rgb, grad_scale, C, R, S, rows_per_class,
                              blocks, workspace, B_stride, rows_fix, clamp_flags, none, stream);
 }
 
@@ -944,18 +957,18 @@ extern "C" int cnr_field_train(const float* pts, const float* B, const void* pac
   return launch_p8<WIDE, KR, TWO, PAD>(pts, B, packed, biasrows, ray_row, scale, nullptr, nullptr, grad_scale, C, R, S, \
                                        rows_per_class, blocks, records, B_stride, rows_fix, clamp_flags, ta, stream)
   const bool pad = S != sp;   // exact fit: the plain index arithmetic (2 % faster at configs[1] than the padded form)
-  if (rows_per_class > 4) {
-    if (sp == 16) CNR_FT(true, 1, true, true);
-    if (sp == 32) { if (pad) CNR_FT(true, 1, false, true); CNR_FT(true, 1, false, false); }
-    if (sp == 64) { if (pad) CNR_FT(true, 2, false, true); CNR_FT(true, 2, false, false); }
-    if (pad) CNR_FT(true, 4, false, true);
-    CNR_FT(true, 4, false, false);
+#define CNR_FT_ALL(W)                                                                                    \
+  {                                                                                                      \
+    if (sp == 16) CNR_FT(W, 1, true, true);                                                              \
+    if (sp == 32) { if (pad) CNR_FT(W, 1, false, true); CNR_FT(W, 1, false, false); }                    \
+    if (sp == 64) { if (pad) CNR_FT(W, 2, false, true); CNR_FT(W, 2, false, false); }                    \
+    if (pad) CNR_FT(W, 4, false, true);                                                                  \
+    CNR_FT(W, 4, false, false);                                                                          \
   }
-  if (sp == 16) CNR_FT(false, 1, true, true);
-  if (sp == 32) { if (pad) CNR_FT(false, 1, false, true); CNR_FT(false, 1, false, false); }
-  if (sp == 64) { if (pad) CNR_FT(false, 2, false, true); CNR_FT(false, 2, false, false); }
-  if (pad) CNR_FT(false, 4, false, true);
-  CNR_FT(false, 4, false, false);
+  if (rows_per_class > 7) CNR_FT_ALL(2)
+  if (rows_per_class > 4) CNR_FT_ALL(1)
+  CNR_FT_ALL(0)
+#undef CNR_FT_ALL
 #undef CNR_FT
 }
 

@@ -135,14 +135,14 @@ class FusedCategoryTrainer:
         self.theta2 = torch.stack([theta0, theta0.clone()])
         self.parity = 0
         # gradient of the flat parameters and of the per-object bias rows in ONE allocation: one fill per step
-        # ... plus (<= 7 objects per class with the 8-wave backward, <= 4 otherwise) the int64 fixed-point table of the per-object bias-row sums
+        # ... plus (<= 15 objects per class with the 8-wave backward, <= 4 otherwise) the int64 fixed-point table of the per-object bias-row sums
         # that the field backward fills with integer atomics for cnr_step_tail
         n_th, n_db = self.theta.numel(), n_cls * n_obj * 128
         # the field backward leaves per-workgroup records + the fixed-point table; ONE later launch reduces them next to
         # the latent backward: with AdamW and the epilogue when no gradient exchange follows (cnr_step_tail: single GPU,
         # class sharding), gradient only when rays are sharded (cnr_step_grad: the all-reduce comes between gradient and
         # optimiser)
-        self.use_records = n_obj <= (7 if ops.FIELD_BWD_VARIANT == "pipe4" else 4) and ops.FIELD_BWD_VARIANT.startswith("pipe")
+        self.use_records = n_obj <= (15 if ops.FIELD_BWD_VARIANT == "pipe4" else 4) and ops.FIELD_BWD_VARIANT.startswith("pipe")
         self.grad_exchange = self.shard == "ray" and self.world > 1
         self.fused_tail = not self.grad_exchange and self.use_records
         fix_off = (n_th + n_db + 3) // 4 * 4                      # 16-byte aligned
@@ -317,7 +317,7 @@ class FusedCategoryTrainer:
                 _C.call("cnr_latent_bwd", self.theta, *lat_args, zl, self.dbias, self._reg, self.grad, self.n_obj_cls)
 
     def _step_back(self):
-        """Last launch (cnr_step_tail): the fixed-order reduction of the field backward's records (single GPU, <= 7
+        """Last launch (cnr_step_tail): the fixed-order reduction of the field backward's records (single GPU, <= 15
         objects per class; otherwise cnr_field_bwd_pipe did it), latent backward + code regulariser (single GPU; with a
         process group it ran before the all-reduce), AdamW out of place into the other parameter copy, and the
         epilogue (loss values +

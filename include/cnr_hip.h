@@ -376,7 +376,7 @@ int cnr_step_grad(const float* theta, float* grad, int64_t class_stride, int64_t
  * workgroup barrier.  chain_waves = 2 or 3: four waves per workgroup, 4 - chain_waves of them on the weight
  * gradients (csrc/fused_bwd_pipe.hip); chain_waves = 4: eight waves, 4 + 4, two per SIMD (csrc/fused_bwd_pipe8.hip,
  * the fastest form and the trainer's default).  max_blocks / workspace as above.
- * Class-major rows: up to 4 per class (chain_waves 2, 3) or 7 per class (chain_waves 4) stay on this path -- their
+ * Class-major rows: up to 4 per class (chain_waves 2, 3) or 15 per class (chain_waves 4) stay on this path -- their
  * bias-row sums travel in the records (and in rows_fix); anything else (no ray_row, more rows) is handed to
  * cnr_field_bwd (rows_fix / skip_reduce must then be NULL / 0). */
 /* rows_fix (optional): per-object bias-row sums also accumulated as 2^-40 fixed point into this (8, C, n_obj, 4, 32)
@@ -417,7 +417,7 @@ int cnr_field_fwd_fp8(const float* pts, const float* B, const void* packed, cons
  * `records` (>= C * cnr_field_train_blocks() * record size = cnr_field_bwd_workspace_bytes(C, blocks); reduce with
  * cnr_step_tail / cnr_step_grad, nwg = cnr_field_train_blocks()), rows_fix as cnr_field_bwd_pipe, and per-block loss
  * partials in loss_workspace (>= cnr_field_train_workspace_bytes()) for cnr_step_tail with rl_blocks =
- * cnr_field_train_blocks().  Returns CNR_E_SHAPE for S > 128 or more than 7 rows per class (use the two calls). */
+ * cnr_field_train_blocks().  Returns CNR_E_SHAPE for S > 128 or more than 15 rows per class (use the two calls). */
 int cnr_field_train_blocks(int R, int S, int max_blocks);
 int64_t cnr_field_train_workspace_bytes(int C, int R, int S, int max_blocks);
 int cnr_field_train(const float* pts, const float* B, const void* packed, const float* biasrows, const int* ray_row,

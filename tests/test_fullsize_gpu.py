@@ -166,7 +166,7 @@ def test_full_size_train_step_against_oracle(cnr, dev, C, R, n1, n2, L):
     assert agree / total > 0.98, agree / total
 
 
-@pytest.mark.parametrize("C,n_obj,L", [(1, 4, 256), (2, 3, 32), (1, 7, 64), (1, 1, 32)])
+@pytest.mark.parametrize("C,n_obj,L", [(1, 4, 256), (2, 3, 32), (1, 7, 64), (1, 1, 32), (2, 12, 32)])
 def test_latent_bwd_against_autograd(cnr, dev, C, n_obj, L):
     """cnr_latent_fwd / cnr_latent_bwd (a7 + the four latent layers + the code regulariser, src/model.py:38-51,
     src/loss.py:5-15) against torch autograd on given bias-row gradients: <= 1e-5; trunk entries are ADDED."""
@@ -202,7 +202,7 @@ def test_latent_bwd_against_autograd(cnr, dev, C, n_obj, L):
     assert torch.equal(gv["B"], g0v["B"])                           # not touched
 
 
-@pytest.mark.parametrize("C,n_obj,L,nwg", [(1, 4, 256, 256), (2, 3, 32, 37), (1, 7, 64, 64)])
+@pytest.mark.parametrize("C,n_obj,L,nwg", [(1, 4, 256, 256), (2, 3, 32, 37), (1, 7, 64, 64), (2, 15, 32, 50)])
 def test_step_grad_and_tail_reduce_records_and_fixed_point_rows(cnr, dev, C, n_obj, L, nwg):
     """The gradient half of the step's last launch on synthetic inputs: per-workgroup records (fixed-order float sums),
     the int64 2^-40 fixed-point table of the per-object bias-row sums (8 copies), latent backward.  cnr_step_grad

@@ -341,12 +341,14 @@ def test_forward_render_one_launch_equals_two(cnr, dev, C, R, S, L):
 
 
 @pytest.mark.parametrize("C,R,S,n_obj", [(1, 2048, 64, 4), (2, 1000, 96, 4), (1, 8192, 128, 4), (1, 77, 240, 4), (2, 50, 33, 4),
-                                         (1, 1, 1, 4), (2, 700, 64, 7), (1, 2048, 64, 5), (1, 300, 32, 1)])
+                                         (1, 1, 1, 4), (2, 700, 64, 7), (1, 2048, 64, 5), (1, 300, 32, 1),
+                                         (1, 300, 32, 8), (2, 700, 64, 12), (1, 2048, 64, 15)])
 def test_field_bwd_full_size_all_variants_agree_and_repeat(cnr, dev, C, R, S, n_obj):
     """BASELINE sizes: every cnr_field_bwd implementation computes the same f16 pipeline, so the gradients agree to
     fp32 summation order (1e-5 relative L2 per output against the block-split kernels), and a repeated call returns
     the same bits (records + fixed-order reduction).  The repeat is the check that caught a register hazard which the
-    small fixtures never showed: hundreds of workgroups with several iterations each are needed to hit it."""
+    small fixtures never showed: hundreds of workgroups with several iterations each are needed to hit it.
+    (n_obj 5-7: the 8-wave kernel's run-time row stride; 8-15: its two row-sum blocks.)"""
     ops, _C = cnr.ops, cnr._C
     L = 256
     gen = torch.Generator().manual_seed(3)

@@ -130,7 +130,7 @@ def test_eager_one_graph_and_two_graphs_train_identically(cnr, dev):
         assert torch.equal(t, thetas[0][0]) and torch.equal(l, thetas[0][1]) and cur == thetas[0][2]
 
 
-@pytest.mark.parametrize("C,n_obj,L", [(1, 4, 256), (3, 2, 32), (2, 7, 64)])
+@pytest.mark.parametrize("C,n_obj,L", [(1, 4, 256), (3, 2, 32), (2, 7, 64), (2, 15, 32)])
 def test_param_prep_equals_separate_calls(cnr, dev, C, n_obj, L):
     """cnr_param_prep (pack | latent rows | zero fill side by side in one grid) == cnr_pack_weights +
     cnr_latent_fwd + a memset: operand image bit-identical, rows identical (same code path), buffer zero."""
@@ -329,9 +329,9 @@ def test_full_size_step_sampling_invariants(cnr, dev, C, R, n1, n2):
         assert state.max() <= 2
 
 
-@pytest.mark.parametrize("n_obj", [4, 6])
+@pytest.mark.parametrize("n_obj", [4, 6, 10])
 def test_many_epochs_graph_equals_eager(cnr, dev, n_obj):
-    """(Four objects per class, and six: up to seven stay on the record path of the 8-wave backward.)  Sixty steps over a pool of eight slices (a reshuffle every seven steps: new permutation, new per-slice max-depth
+    """(Four objects per class, six and ten: up to fifteen stay on the record path of the 8-wave backward.)  Sixty steps over a pool of eight slices (a reshuffle every seven steps: new permutation, new per-slice max-depth
     table, cursor back to zero) -- the captured graphs must keep following the device-side state across epochs: same
     losses and parameters, bitwise, as the eager trainer."""
     res = {}
@@ -358,13 +358,16 @@ def test_many_epochs_graph_equals_eager(cnr, dev, n_obj):
                                                # samples: two rays per tile), an odd ray count, 16 of 16, 24 of 32, 40 of
                                                # 64, 100 of 128 slots
                                                (1, 480, 1, 9, 4, 256), (2, 249, 1, 9, 5, 32), (1, 77, 2, 14, 4, 32),
-                                               (1, 130, 4, 20, 4, 32), (2, 100, 8, 32, 4, 32), (1, 50, 12, 88, 4, 32)])
+                                               (1, 130, 4, 20, 4, 32), (2, 100, 8, 32, 4, 32), (1, 50, 12, 88, 4, 32),
+                                               # 8-15 objects per class: two row-sum blocks
+                                               (2, 250, 4, 28, 9, 32), (1, 480, 1, 9, 15, 32), (1, 256, 8, 56, 12, 32),
+                                               (1, 96, 16, 112, 8, 32)])
 def test_one_launch_step_equals_forward_render_plus_backward(cnr, dev, C, R, n1, n2, n_obj, L):
     """cnr_field_train (a8-a15 forward, losses, loss gradient and the field backward in ONE launch, the ray's tiles
     exchanging composite partials between waves) against cnr_field_fwd_render + cnr_field_bwd_pipe: same f16 pipeline,
     same samples -> renders and loss values to fp32 summation order, the complete gradient (trunk, latent layers, B,
     codes) to 1e-4, parameters after AdamW; ragged tile counts (dead tiles in the last workgroup iteration), 5-7
-    objects per class (the run-time row-sum stride), S = 32 / 64 / 128 (1, 2, 4 tiles per ray) and rays padded to
+    objects per class (the run-time row-sum stride), 8-15 (two row-sum blocks), S = 32 / 64 / 128 (1, 2, 4 tiles per ray) and rays padded to
     16 / 32 / 64 / 128 sample slots (dead lanes; two 16-slot rays per tile for S <= 16)."""
     res = {}
     for name, one in (("two", False), ("one", True)):
