@@ -215,6 +215,7 @@ def main():
                          "(there is no fp8 train step: see DESIGN.md section 3.4); prints its own JSON line")
     ap.add_argument("--bwd-blocks", type=int, default=0)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--unroll", type=int, default=16, help="train steps per hipGraph launch (2 = one graph launch per two steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -271,7 +272,8 @@ def main():
              for c in ids]
     tr = cnr_amd.fused.FusedCategoryTrainer(cfg, C, n_obj, pools, R, dev, seed=0, generator=gen,
                                             bwd_blocks=args.bwd_blocks, process_group=pg, use_graph=not args.no_graph,
-                                            shard=shard, n_cls_global=C_glob, class_ids=ids if shard == "class" else None)
+                                            shard=shard, n_cls_global=C_glob, class_ids=ids if shard == "class" else None,
+                                            unroll=args.unroll)
     rays_per_step_global = C_glob * Rg
 
     def sync():
@@ -283,8 +285,7 @@ def main():
     def timed(n_steps):
         sync()
         t0 = time.perf_counter()
-        for _ in range(n_steps):
-            tr.step()
+        tr.run(n_steps)        # = n_steps x tr.step(); groups of tr.unroll steps go out as one hipGraph launch each
         sync()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -294,8 +295,7 @@ def main():
         return dt
 
     dbg("trainer built")
-    for _ in range(max(args.warmup, 4)):
-        tr.step()
+    tr.run(max(args.warmup, 4))
     dbg("warmup issued")
     dt = timed(args.steps)                      # EXACTLY --steps steps between barriers + synchronize, max over ranks
     dbg("timed region done")
@@ -368,7 +368,7 @@ def main():
                                   f"synthetic pool, random init",
                       "rays_per_step_global": rays_per_step_global, "rays_per_gpu": C * R, "samples_per_ray": S,
                       "parallelism": par, "shard": shard,
-                      "hipgraph": ("one graph per state parity" if not tr.grad_exchange else "two graphs around the all-reduce, per state parity") if not args.no_graph else False,
+                      "hipgraph": (f"{tr.unroll} steps per graph launch (one step per launch at epoch ends)" if not tr.grad_exchange else "two graphs around the all-reduce, per state parity") if not args.no_graph else False,
                       "n_cu": info["n_cu"]},
            "long_run": long_run, "roofline": roofline}
     if world > 1 and shard == "ray":   # outside the timed region: every rank must hold bitwise identical parameters after the run

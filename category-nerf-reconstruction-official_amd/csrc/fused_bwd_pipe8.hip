@@ -23,22 +23,28 @@
 namespace {
 #ifdef CNR_PIPE_STAMPS  // tools/exp only: cycle stamps of every wave of workgroup 0 (its last iteration)
 __device__ long long g_pipe8_stamps[8 * 64];
-#define P8STAMP() do { if (blockIdx.x == 0 && lane == 0) \
+#ifndef CNR_STAMP_ITER
+#define CNR_STAMP_ITER 0   // which iteration (1-based) of workgroup 0 the barrier stamps and marks record; 0 = every one (the last stays)
+#endif
+#define P8STAMP() do { if (blockIdx.x == 0 && lane == 0 && (CNR_STAMP_ITER == 0 || p8_iter == CNR_STAMP_ITER)) \
     g_pipe8_stamps[wv * 64 + (pstamp_i++)] = (long long)__builtin_readcyclecounter(); } while (0)
-#define P8STAMP_RESET() int pstamp_i = 0
+#define P8STAMP_RESET() int pstamp_i = 0; do { if (blockIdx.x == 0 && lane == 0 && p8_iter < 12) \
+    g_pipe8_stamps[wv * 64 + 30 + (p8_iter++)] = (long long)__builtin_readcyclecounter(); } while (0)
+#define P8ITER_DECL() int p8_iter = 0
 #define P8PHASE(k) do { if (blockIdx.x == 0 && lane == 0) \
     g_pipe8_stamps[wv * 64 + 56 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
-#define P8MARK(k) do { if (blockIdx.x == 0 && lane == 0) \
+#define P8MARK(k) do { if (blockIdx.x == 0 && lane == 0 && (CNR_STAMP_ITER == 0 || p8_iter == CNR_STAMP_ITER)) \
     g_pipe8_stamps[wv * 64 + 44 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
 #define P8MARK(k) do {} while (0)
 #define P8PHASE(k) do {} while (0)
 #define P8STAMP() do {} while (0)
 #define P8STAMP_RESET() do {} while (0)
+#define P8ITER_DECL() do {} while (0)
 #endif
 #define P8SYNC() do { P8STAMP(); role_barrier(); P8STAMP(); } while (0)
 constexpr int K8_SMALL_BYTES = (cnr_rec::ROWS_MAX + 1) * 64;  // row one-hot table: ROWS_MAX rows + the ones row, 32 halfs each
-constexpr int C8_BYTES = E1IMG_BYTES + E2IMG_BYTES + 2 * HSIMG_BYTES + K8_SMALL_BYTES;  // LDS per chain wave
+constexpr int C8_BYTES = E1IMG_BYTES + E2IMG_BYTES + 4 * HSIMG_BYTES + K8_SMALL_BYTES;  // LDS per chain wave
 constexpr int L8_BL = PK_BYTES, L8_BR = L8_BL + 272, L8_CHAIN = L8_BR + cnr_rec::ROWS_MAX * 128 * 4;
 constexpr int RS8_REGION = NBLOCKS;
 constexpr int BK_RS = 100, BK_RS2 = 101;  // pseudo kinds of the row-sum blocks in the ownership tables
@@ -96,14 +102,18 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
   constexpr int RS_ROWS = WIDE == 2 ? cnr_rec::ROWS_MAX : WIDE == 1 ? 7 : 4;  // most object rows this instance takes
   // per chain wave: E1 image, E2 image, dPre / input slot, row one-hot table (the flush reuses it for the wave's
   // partial sums)
-  constexpr int K_E1 = 0, K_E2 = E1IMG_BYTES, K_D = K_E2 + E2IMG_BYTES, K_X = K_D + HSIMG_BYTES,
-                K_SMALL = K_X + HSIMG_BYTES, K_BYTES = C8_BYTES;
+  // The dPre / input images are double-buffered (K_PAR apart): layer step k uses copy k & 1, so the chain wave stages step
+  // k + 1 while the dW waves still read step k -- ONE workgroup barrier per layer step ("images of step k are complete";
+  // copy (k + 1) & 1 was last read in step k - 1, which the dW waves finished before they arrived at that barrier).
+  constexpr int K_E1 = 0, K_E2 = E1IMG_BYTES, K_D = K_E2 + E2IMG_BYTES, K_X = K_D + HSIMG_BYTES, K_PAR = 2 * HSIMG_BYTES,
+                K_SMALL = K_X + HSIMG_BYTES + K_PAR, K_BYTES = C8_BYTES;
   static_assert(K_BYTES == K_SMALL + K8_SMALL_BYTES && K8_SMALL_BYTES >= 512, "layout");
   static_assert(NACC >= 4, "the chain role parks its partial sums in accumulators 0..3");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int c = blockIdx.y;
   const int lane = threadIdx.x & 63, h = lane >> 5, col = lane & 31;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  P8ITER_DECL();
   P8PHASE(0);
   const bool is_chain = wv < NCHW;
   const int dwid = wv - NCHW;
@@ -151,8 +161,10 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
     unsigned char* cw = chain_base + wv * K_BYTES;
     unsigned char* E1img = cw + K_E1;
     unsigned char* E2img = cw + K_E2;
-    unsigned char* Dimg = cw + K_D;
-    unsigned char* Ximg = cw + K_X;
+    unsigned char* Dimg0 = cw + K_D;            // layer steps 0, 2, .. (rgb.2, texture_1, enc_shape, cat, xyz)
+    unsigned char* Ximg0 = cw + K_X;
+    unsigned char* Dimg1 = cw + K_D + K_PAR;    // layer steps 1, 3, .. (rgb.0, viewdir, shape_2, shape_1)
+    unsigned char* Ximg1 = cw + K_X + K_PAR;
     // [rows_per_class + 1][32] (<= 8 rows): (object row of sample k == r), last row ones
     _Float16* rowoh = reinterpret_cast<_Float16*>(cw + K_SMALL);
     const float* Bl_h = reinterpret_cast<const float*>(smem + L8_BL) + 33 * h;
@@ -237,6 +249,7 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
     }
     float* xch = reinterpret_cast<float*>(smem + l8_xch(NCH));   // [4][8]
     TileIn cur = fetch(blockIdx.x * NCHW + wv), nxt = cur;
+    bool any_iter = false;
     for (int tile = blockIdx.x * NCHW + wv, t0 = blockIdx.x * NCHW; t0 < ntiles; t0 += tile_step, tile += tile_step) {
       asm volatile("" ::: "memory");
       P8STAMP_RESET();
@@ -302,6 +315,7 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
 #pragma unroll
       for (int s = 0; s < 6; ++s) wq[s] = lds_frag(smem, KK_XYZ + s, lane);
       acc = acc_init(cf + CF_B_XYZ, h);
+      if (any_iter) P8SYNC();   // the previous iteration's last barrier: the dW waves are done with this wave's images
       {
         const int rl = row - c * rows_per_class;
         const int rs = WIDE ? rows_per_class : 4;  // rows per latent slot in the row-sum block; the ones row follows
@@ -535,11 +549,11 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
         }
       }
       // staged into feature columns 16..18: dW0 accumulates rgb.2 into rows 16..18 of rgb.0's block
-      stage_hs(Dimg, D1, D0, col, h);
+      stage_hs(Dimg0, D1, D0, col, h);
       {
         h8 one = zero8();
         if (h == 0) one[0] = (_Float16)1;  // feature 16 of the a7 image := 1 -> d b(rgb.2)
-        stage_hs(Ximg, A7a, one, col, h);
+        stage_hs(Ximg0, A7a, one, col, h);
       }
       acc = MFMA(wq[1], D0, zero16());  // d a7 (rows 0..15)
       P8MARK(6);
@@ -548,20 +562,18 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
       u4v Mn0 = relu_mask(A6a), Mn1 = relu_mask(A6b);
       acc = MFMA(Wn0, D0, zero16());  // d a6
       Wn0 = lds_frag(bwf, KT_T1 + 0, lane); Wn1 = lds_frag(bwf, KT_T1 + 1, lane);
-      P8SYNC();                   // B(R2)
       // ---- step R0
-      stage_hs(Dimg, D0, D1, col, h);
-      stage_hs(Ximg, A6a, A6b, col, h);
+      stage_hs(Dimg1, D0, D1, col, h);
+      stage_hs(Ximg1, A6a, A6b, col, h);
       P8SYNC();                   // A(R0)
       D0 = pack8_and(acc, 0, Mn0); D1 = pack8_and(acc, 1, Mn1);
       Mn0 = relu_mask(A5a); Mn1 = relu_mask(A5b);
       acc = MFMA(Wn0, D0, zero16());
       acc = MFMA(Wn1, D1, acc);  // d a5
       Wn0 = lds_frag(bwf, KT_VD_Y + 0, lane); Wn1 = lds_frag(bwf, KT_VD_Y + 1, lane);
-      P8SYNC();                   // B(R0)
       // ---- step T1
-      stage_hs(Dimg, D0, D1, col, h);
-      stage_hs(Ximg, A5a, A5b, col, h);
+      stage_hs(Dimg0, D0, D1, col, h);
+      stage_hs(Ximg0, A5a, A5b, col, h);
       P8SYNC();                   // A(T1)
       D0 = pack8_and(acc, 0, Mn0); D1 = pack8_and(acc, 1, Mn1);
       acc = MFMA(Wn0, D0, zero16());
@@ -573,10 +585,9 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
         de2[b] = MFMA(lds_frag(bwf, KT_VD_E + 2 * b + 1, lane), D1, de2[b]);
       }
       Wn0 = lds_frag(bwf, KT_ES + 0, lane); Wn1 = lds_frag(bwf, KT_ES + 1, lane);
-      P8SYNC();                   // B(T1)
       // ---- step VD : inputs [y4 | e2]
-      stage_hs(Dimg, D0, D1, col, h);
-      stage_hs(Ximg, Y4a, Y4b, col, h);
+      stage_hs(Dimg1, D0, D1, col, h);
+      stage_hs(Ximg1, Y4a, Y4b, col, h);
       P8SYNC();                   // A(VD)
       {  // + sigma head: d y4 += w_sigma * draw
         const f16v wsg = acc_init(cf + CF_W_SG, h);
@@ -590,20 +601,18 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
       Wn0 = lds_frag(bwf, KT_S2 + 0, lane); Wn1 = lds_frag(bwf, KT_S2 + 1, lane);
       de2[2] = de2[1];
       pe_backward(de2, 2, 4, 22);  // bands 4 and 5 -> dB
-      P8SYNC();                   // B(VD)
       // ---- step ES (no activation)
-      stage_hs(Dimg, D0, D1, col, h);
-      stage_hs(Ximg, A3a, A3b, col, h);
+      stage_hs(Dimg0, D0, D1, col, h);
+      stage_hs(Ximg0, A3a, A3b, col, h);
       P8SYNC();                   // A(ES)
       D0 = pack8_and(acc, 0, Mn0); D1 = pack8_and(acc, 1, Mn1);
       Mn0 = relu_mask(A2a); Mn1 = relu_mask(A2b);
       acc = MFMA(Wn0, D0, zero16());
       acc = MFMA(Wn1, D1, acc);  // d a2
       Wn0 = lds_frag(bwf, KT_CAT_Y + 0, lane); Wn1 = lds_frag(bwf, KT_CAT_Y + 1, lane);
-      P8SYNC();                   // B(ES)
       // ---- step S2 : input a2
-      stage_hs(Dimg, D0, D1, col, h);
-      stage_hs(Ximg, A2a, A2b, col, h);
+      stage_hs(Dimg1, D0, D1, col, h);
+      stage_hs(Ximg1, A2a, A2b, col, h);
       P8SYNC();                   // A(S2)
       D0 = pack8_and(acc, 0, Mn0); D1 = pack8_and(acc, 1, Mn1);
       Mn0 = relu_mask(A1a); Mn1 = relu_mask(A1b);
@@ -612,10 +621,9 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
       Wn0 = lds_frag(bwf, KT_S1 + 0, lane); Wn1 = lds_frag(bwf, KT_S1 + 1, lane);
       const h8 Dc0 = D0, Dc1 = D1;  // dPre(cat): its d e1 part is formed together with encoding_xyz's
       nxt = fetch(tile + tile_step);  // next iteration's inputs: their latency hides under the last three steps
-      P8SYNC();                   // B(S2)
       // ---- step CAT : inputs [a1 | e1]
-      stage_hs(Dimg, D0, D1, col, h);
-      stage_hs(Ximg, A1a, A1b, col, h);
+      stage_hs(Dimg0, D0, D1, col, h);
+      stage_hs(Ximg0, A1a, A1b, col, h);
       P8SYNC();                   // A(CAT)
       D0 = pack8_and(acc, 0, Mn0); D1 = pack8_and(acc, 1, Mn1);
       Mn0 = relu_mask(A0a); Mn1 = relu_mask(A0b);
@@ -627,10 +635,9 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
         de[b] = MFMA(lds_frag(bwf, KT_CAT_E + 2 * b + 0, lane), Dc0, zero16());
         de[b] = MFMA(lds_frag(bwf, KT_CAT_E + 2 * b + 1, lane), Dc1, de[b]);
       }
-      P8SYNC();                   // B(CAT)
       // ---- step S1 : input a0
-      stage_hs(Dimg, D0, D1, col, h);
-      stage_hs(Ximg, A0a, A0b, col, h);
+      stage_hs(Dimg1, D0, D1, col, h);
+      stage_hs(Ximg1, A0a, A0b, col, h);
       P8SYNC();                   // A(S1)
       D0 = pack8_and(acc, 0, Mn0); D1 = pack8_and(acc, 1, Mn1);
 #pragma unroll
@@ -638,14 +645,14 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
         de[b] = MFMA(lds_frag(bwf, KT_XYZ_E + 2 * b + 0, lane), D0, de[b]);
         de[b] = MFMA(lds_frag(bwf, KT_XYZ_E + 2 * b + 1, lane), D1, de[b]);
       }
-      P8SYNC();                   // B(S1)
       // ---- step XYZ : input e1 (its image)
-      stage_hs(Dimg, D0, D1, col, h);
+      stage_hs(Dimg0, D0, D1, col, h);
       P8SYNC();                   // A(XYZ)
       pe_backward(de, 3, 0, 44);        // d e1 -> dB, bands 0..3
       cur = nxt;
-      P8SYNC();                   // B(XYZ): the dW waves are done with this tile's images
-    }
+      any_iter = true;   // the barrier "dW waves are done with this tile's images" follows at the next iteration's image
+    }                    // writes (below the PE arithmetic, which so runs beside the dW waves' last step), or here:
+    if (any_iter) role_barrier();
     {  // publish this wave's partial sums (the last barrier has passed: the dW waves no longer read the row table
        // this aliases): [0..31] d w_sigma, [32] d b_sigma, [64..126] dB
       float* small = reinterpret_cast<float*>(cw + K_SMALL);
@@ -684,6 +691,18 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
     const int m_row = col < nlat_rows ? col - col_slot * rs : rs,
               m_grp = col < nlat_rows ? col_slot : 4 + (col - nlat_rows),
               m_grpB = col < nlat_rows ? 2 + col_slot : -1;
+    // lane-dependent parts of the LDS read addresses (see consume): swizzled 32 x 32 images (lo / hi row quads), the two PE
+    // images, the row one-hot table
+    int p_hs_lo, p_hs_hi, p_e1, p_e2, p_r;
+    {
+      const int i = lane & 15, g16 = lane >> 4, q = i >> 2, pp = i & 3, hh = g16 >> 1;
+      const int r = 8 * hh + q, chunk = 4 * (g16 & 1) + pp;
+      p_hs_lo = r * 64 + ((chunk ^ ((r >> 1) & 7)) << 3);
+      p_hs_hi = (r + 4) * 64 + ((chunk ^ (((r + 4) >> 1) & 7)) << 3);
+      p_e1 = r * ST_E1 + (16 * (g16 & 1) + 4 * pp) * 2;
+      p_e2 = r * ST_E2 + (16 * (g16 & 1) + 4 * pp) * 2;
+      p_r = (m_row * 32 + 8 * h) * 2;
+    }
     // Where this lane's column of each owned block goes in the record: every block kind is affine in the output row,
     // idx(o) = i0 + o * st (weights: st = the layer's row length; a bias column: st = 1), i0 < 0 = not a parameter.
     // Computed here, while the chain waves recompute the first forward: the flush then stores accumulators straight to
@@ -711,8 +730,9 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
       P8STAMP();
       // one layer step over the six tiles; KIND* = the block kinds of the step (X source: 0 = slot X image,
       // 1 = E2 image, 2 = E1 image; col0 = first feature column), RS_GRP >= 0: row sums of the step (dW0)
-      auto consume = [&](auto dw_c, auto nx_c, auto k0_c, auto k1_c, auto k2_c, auto k3_c, auto grp_c) {
+      auto consume = [&](auto dw_c, auto nx_c, auto k0_c, auto k1_c, auto k2_c, auto k3_c, auto grp_c, auto par_c) {
         constexpr int DW = decltype(dw_c)::value, NX = decltype(nx_c)::value, RS_GRP = decltype(grp_c)::value;
+        constexpr int PAR = decltype(par_c)::value * K_PAR;   // which copy of the dPre / input images the step uses
         constexpr int K0 = decltype(k0_c)::value, K1 = decltype(k1_c)::value, K2 = decltype(k2_c)::value,
                       K3 = decltype(k3_c)::value;
         // which of the step's blocks this dW wave owns, and their operand slots (all compile-time: the accumulator
@@ -725,6 +745,28 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
         // at most two owned blocks per wave and step; DEPTH tiles in flight (transposing reads are convergent: the
         // compiler keeps them in source order, so the lookahead is spelled out): all four, the registers are there
         constexpr int DEPTH = NCHW;
+        // The lane-dependent parts of the LDS addresses (one VGPR per access pattern, formed once before the loop) are made
+        // opaque per step: a read's address is then ONE add of a constant here, instead of ~30 loop-invariant address
+        // registers hoisted out of the iteration loop (4 tiles x 7 images lie further apart than a 16-bit ds offset reaches),
+        // which spilled -- and instead of re-deriving the patterns from the lane index, which costs the dW wave ~300
+        // cycles at the start of every step, where the chain waves wait for it.
+        int a_lo = p_hs_lo, a_hi = p_hs_hi, a_e1 = p_e1, a_e2 = p_e2, a_r = p_r;
+        asm volatile("" : "+v"(a_lo), "+v"(a_hi), "+v"(a_e1), "+v"(a_e2), "+v"(a_r));
+        auto rd_hs = [&](const unsigned char* img, int sl) {   // = tr_frag_hs(img, sl, lane)
+          typedef __attribute__((address_space(3))) s4v* lds_s4;
+          h8 out;
+          out.lo = __builtin_bit_cast(h4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(img + sl * 1024 + a_lo)));
+          out.hi = __builtin_bit_cast(h4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(img + sl * 1024 + a_hi)));
+          return out;
+        };
+        auto rd_pe = [&](const unsigned char* img, int stride, int col0, int sl) {   // = tr_frag(img, stride, col0, sl, lane)
+          typedef __attribute__((address_space(3))) s4v* lds_s4;
+          const unsigned char* a = img + (stride == ST_E1 ? a_e1 : a_e2) + 16 * sl * stride + col0 * 2;
+          h8 out;
+          out.lo = __builtin_bit_cast(h4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(a)));
+          out.hi = __builtin_bit_cast(h4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(a + 4 * stride)));
+          return out;
+        };
         h8 fD[DEPTH][2], fX[DEPTH][2][2];
         u4v fR[DEPTH][2];          // row one-hot operand of the row sums
         auto load_blk = [&](int w, auto kind_c, auto slot_c) {
@@ -736,13 +778,13 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
           else if (kind == BK_CAT_E0 || kind == BK_XYZ_E0) { ximg = cb + K_E1; stride = ST_E1; col0 = 0; }
           else if (kind == BK_CAT_E1 || kind == BK_XYZ_E1) { ximg = cb + K_E1; stride = ST_E1; col0 = 32; }
           else if (kind == BK_CAT_E2 || kind == BK_XYZ_E2) { ximg = cb + K_E1; stride = ST_E1; col0 = 64; }
-          else ximg = cb + K_X;
+          else ximg = cb + K_X + PAR;
           if (stride == 0) {  // the step's input image (swizzled rows)
-            fX[w % DEPTH][slot][0] = tr_frag_hs(ximg, 0, lane);
-            fX[w % DEPTH][slot][1] = tr_frag_hs(ximg, 1, lane);
+            fX[w % DEPTH][slot][0] = rd_hs(ximg, 0);
+            fX[w % DEPTH][slot][1] = rd_hs(ximg, 1);
           } else {            // a PE image
-            fX[w % DEPTH][slot][0] = tr_frag(ximg, stride, col0, 0, lane);
-            fX[w % DEPTH][slot][1] = tr_frag(ximg, stride, col0, 1, lane);
+            fX[w % DEPTH][slot][0] = rd_pe(ximg, stride, col0, 0);
+            fX[w % DEPTH][slot][1] = rd_pe(ximg, stride, col0, 1);
           }
         };
         auto mma_blk = [&](int w, auto kind_c, auto slot_c) {
@@ -752,16 +794,16 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
         };
         auto load_tile = [&](int w) {
           const unsigned char* cb = chain_base + w * K_BYTES;
-          fD[w % DEPTH][0] = tr_frag_hs(cb + K_D, 0, lane);
-          fD[w % DEPTH][1] = tr_frag_hs(cb + K_D, 1, lane);
+          fD[w % DEPTH][0] = rd_hs(cb + K_D + PAR, 0);
+          fD[w % DEPTH][1] = rd_hs(cb + K_D + PAR, 1);
           if constexpr (OWN0) load_blk(w, IC<K0>{}, IC<SL0>{});
           if constexpr (OWN1) load_blk(w, IC<K1>{}, IC<SL1>{});
           if constexpr (OWN2) load_blk(w, IC<K2>{}, IC<SL2>{});
           if constexpr (OWN3) load_blk(w, IC<K3>{}, IC<SL3>{});
           if constexpr (DO_RS) {
-            const _Float16* rowoh = reinterpret_cast<const _Float16*>(cb + K_SMALL);
-            fR[w % DEPTH][0] = __builtin_bit_cast(u4v, *reinterpret_cast<const h8*>(rowoh + m_row * 32 + 0 + 8 * h));
-            fR[w % DEPTH][1] = __builtin_bit_cast(u4v, *reinterpret_cast<const h8*>(rowoh + m_row * 32 + 16 + 8 * h));
+            const unsigned char* rowoh = cb + K_SMALL + a_r;   // [m_row][32] halfs: this lane's k = 8 h .. and 16 + 8 h ..
+            fR[w % DEPTH][0] = __builtin_bit_cast(u4v, *reinterpret_cast<const h8*>(rowoh));
+            fR[w % DEPTH][1] = __builtin_bit_cast(u4v, *reinterpret_cast<const h8*>(rowoh + 32));
           }
         };
 #pragma unroll
@@ -784,22 +826,22 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
         }
       };
       if constexpr (KR > 1) { P8SYNC(); }   // the chain waves' composite exchange
-#define STEP8(NX, K0, K1, K2, K3, GRP)                                                                        \
+#define STEP8(PAR, NX, K0, K1, K2, K3, GRP)                                                                   \
   P8SYNC();                                                                                             \
-  if (dwid == 0) consume(IC<0>{}, IC<NX>{}, IC<K0>{}, IC<K1>{}, IC<K2>{}, IC<K3>{}, IC<GRP>{});               \
-  else if (dwid == 1) consume(IC<1>{}, IC<NX>{}, IC<K0>{}, IC<K1>{}, IC<K2>{}, IC<K3>{}, IC<GRP>{});          \
-  else if (dwid == 2) consume(IC<2>{}, IC<NX>{}, IC<K0>{}, IC<K1>{}, IC<K2>{}, IC<K3>{}, IC<GRP>{});          \
-  else consume(IC<3>{}, IC<NX>{}, IC<K0>{}, IC<K1>{}, IC<K2>{}, IC<K3>{}, IC<GRP>{});                         \
-  P8SYNC();
-      STEP8(1, BK_R0, BK_R0, BK_R0, BK_R0, -1)                               // rgb.2 (rows 16..18 of rgb.0's block)
-      STEP8(1, BK_R0, BK_R0, BK_R0, BK_R0, 5)                                // rgb.0
-      STEP8(1, BK_T1, BK_T1, BK_T1, BK_T1, 3)                                // texture_layer_1
-      STEP8(3, BK_VD_Y, BK_VD_E0, BK_VD_E1, BK_VD_E1, -1)                    // encoding_viewdir
-      STEP8(1, BK_ES, BK_ES, BK_ES, BK_ES, 4)                                // encoding_shape
-      STEP8(1, BK_S2, BK_S2, BK_S2, BK_S2, 2)                                // shape_layer_2
-      STEP8(4, BK_CAT_Y, BK_CAT_E0, BK_CAT_E1, BK_CAT_E2, 1)                 // cat_layer
-      STEP8(1, BK_S1, BK_S1, BK_S1, BK_S1, 0)                                // shape_layer_1
-      STEP8(3, BK_XYZ_E0, BK_XYZ_E1, BK_XYZ_E2, BK_XYZ_E2, -1)               // encoding_xyz
+  if (dwid == 0) consume(IC<0>{}, IC<NX>{}, IC<K0>{}, IC<K1>{}, IC<K2>{}, IC<K3>{}, IC<GRP>{}, IC<PAR>{});    \
+  else if (dwid == 1) consume(IC<1>{}, IC<NX>{}, IC<K0>{}, IC<K1>{}, IC<K2>{}, IC<K3>{}, IC<GRP>{}, IC<PAR>{}); \
+  else if (dwid == 2) consume(IC<2>{}, IC<NX>{}, IC<K0>{}, IC<K1>{}, IC<K2>{}, IC<K3>{}, IC<GRP>{}, IC<PAR>{}); \
+  else consume(IC<3>{}, IC<NX>{}, IC<K0>{}, IC<K1>{}, IC<K2>{}, IC<K3>{}, IC<GRP>{}, IC<PAR>{});
+      STEP8(0, 1, BK_R0, BK_R0, BK_R0, BK_R0, -1)                            // rgb.2 (rows 16..18 of rgb.0's block)
+      STEP8(1, 1, BK_R0, BK_R0, BK_R0, BK_R0, 5)                             // rgb.0
+      STEP8(0, 1, BK_T1, BK_T1, BK_T1, BK_T1, 3)                             // texture_layer_1
+      STEP8(1, 3, BK_VD_Y, BK_VD_E0, BK_VD_E1, BK_VD_E1, -1)                 // encoding_viewdir
+      STEP8(0, 1, BK_ES, BK_ES, BK_ES, BK_ES, 4)                             // encoding_shape
+      STEP8(1, 1, BK_S2, BK_S2, BK_S2, BK_S2, 2)                             // shape_layer_2
+      STEP8(0, 4, BK_CAT_Y, BK_CAT_E0, BK_CAT_E1, BK_CAT_E2, 1)              // cat_layer
+      STEP8(1, 1, BK_S1, BK_S1, BK_S1, BK_S1, 0)                             // shape_layer_1
+      STEP8(0, 3, BK_XYZ_E0, BK_XYZ_E1, BK_XYZ_E2, BK_XYZ_E2, -1)            // encoding_xyz
+      P8SYNC();   // done with this iteration's images (the chain waves wait for it before they write the next ones)
 #undef STEP8
     }
     // ---- this wave's blocks -> the workgroup's record, straight from the accumulators -------------------------

@@ -92,7 +92,7 @@ class FusedCategoryTrainer:
     def __init__(self, cfg, n_cls, n_obj, pools, rays_per_step, device, seed=0, generator=None,
                  grad_scale=None, bwd_blocks=0, process_group=None, use_graph=True, split_graph=False,
                  fuse_render=True, split_weights=None, shard=None, n_cls_global=None, class_ids=None,
-                 check_every=0, world_frame=None, dp_rank=None, dp_world=None, one_launch=None):
+                 check_every=0, world_frame=None, dp_rank=None, dp_world=None, one_launch=None, unroll=16):
         # n_obj: one count for every class, or one per (local) class -- the reference's categories differ (train.py:92-96).  The
         # flat layout uses the largest; a smaller class keeps unused rows (no ray refers to them, no regulariser on them)
         n_obj_list = [int(n_obj)] * n_cls if isinstance(n_obj, int) else [int(v) for v in n_obj]
@@ -188,6 +188,14 @@ class FusedCategoryTrainer:
         self.flags = torch.zeros(n_cls, device=self.device, dtype=torch.int32)
         self.clamp = torch.zeros(n_cls, device=self.device, dtype=torch.int32)
         self.check_every = int(check_every)
+        # run(n): `unroll` (even) steps per hipGraph launch.  Consecutive graph launches leave ~8 us of idle GPU between them
+        # (measured, rocprofv3 kernel trace: the kernels INSIDE a graph follow each other without a gap), which is 12 % of a
+        # 65 us step; the steps before the last of such a launch keep their loss values / flags in these slots
+        self.unroll = max(2, int(unroll) // 2 * 2)
+        self._loss_hist = torch.zeros(self.unroll - 1, 3, n_cls, device=self.device)
+        self._flags_hist = torch.zeros(self.unroll - 1, n_cls, device=self.device, dtype=torch.int32)
+        self._out_slot = None       # capture of a multi-step graph: which history slot the step being recorded writes
+        self._last_multi = 0        # steps in the last launch that left their values in the history slots
         self.dbias = self._gbuf[n_th:n_th + n_db].view(n_cls * n_obj, 4, 32)
         self._nwg = int(_C.load().cnr_field_bwd_pipe_blocks(self.R, self.S, int(ops.FIELD_BWD_VARIANT[-1]), self.bwd_blocks)) \
             if self.use_records else 0
@@ -327,7 +335,9 @@ class FusedCategoryTrainer:
         _C.call("cnr_step_tail", self.theta2[par], self.theta2[1 - par], self.grad, self.exp_avg, self.exp_avg_sq,
                 lay.total, lay.B[0], lay.latW[0], lay.latb[0], lay.shape[0], lay.tex[0], self.L, self.n_obj, C,
                 o["zl"], self.dbias, self._reg, 0 if self.grad_exchange else 1, self.lr, 0.9, 0.999, 1e-8, self.wd,
-                self.d_state2[par], self.d_state2[1 - par], self.Rg, o["rl_ws"], self.losses, self.flags,
+                self.d_state2[par], self.d_state2[1 - par], self.Rg, o["rl_ws"],
+                self.losses if self._out_slot is None else self._loss_hist[self._out_slot],
+                self.flags if self._out_slot is None else self._flags_hist[self._out_slot],
                 None, self.pool_rows, None, None, R,
                 o["bwd_ws"] if self.fused_tail else None, self._nwg if self.fused_tail else 0,
                 self.rows_fix if self.fused_tail else None, self._ft_blocks or self._rl_blocks, self.clamp, self.n_obj_cls)
@@ -369,7 +379,52 @@ class FusedCategoryTrainer:
             self.graphs[par][1].replay()
         else:
             self.graphs[par].replay()
+        self._last_multi = 0
         self._post_step()
+
+    def run(self, n, unroll=None):
+        """``n`` train steps, the same arithmetic as ``n`` calls of ``step()`` (bitwise: tests/test_trainer_gpu.py), with
+        groups of ``unroll`` steps captured in ONE hipGraph (2 x unroll x 3 kernel nodes, device-side cursor / RNG /
+        optimiser state and the parameter ping-pong carry from step to step inside it).  Between two graph launches the
+        GPU idles for ~8 us, inside a graph the kernels follow each other directly -- at a 65 us step that is the
+        difference between 30.7 and 35 M rays/s.  A group never crosses an epoch end (the reshuffle is host-launched)
+        and is not used around a gradient all-reduce; those steps go out one by one.  ``self.losses`` / ``self.flags``
+        hold the LAST step's values, ``loss_history()`` the values of every step of the last launch; ``check_flags``
+        looks at all of them."""
+        U = self.unroll if unroll is None else max(2, int(unroll) // 2 * 2)
+        U = min(U, self.unroll)
+        multi_ok = self.use_graph and not (self.grad_exchange or self.split_graph)
+        while n > 0:
+            if self.cursor >= self.pool_rows - self.Rg:
+                self._reshuffle()
+            left = -(-(self.pool_rows - self.Rg - self.cursor) // self.Rg)     # steps before the next reshuffle
+            if not (multi_ok and self.steps_done >= 2 and n >= U and left >= U):
+                self.step()
+                n -= 1
+                continue
+            key = (self.parity, U)
+            if key not in self.graphs:
+                par0 = self.parity
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    for i in range(U):
+                        self._out_slot = i if i < U - 1 else None
+                        self._step_body()
+                        self.parity ^= 1
+                self._out_slot, self.parity = None, par0
+                self.graphs[key] = g
+            self.graphs[key].replay()
+            self._last_multi = U - 1
+            before = self.steps_done
+            self.cursor += U * self.Rg
+            self.steps_done += U
+            n -= U
+            if self.check_every and self.steps_done // self.check_every != before // self.check_every:
+                self.check_flags()
+
+    def loss_history(self):
+        """(k, 3, C): the loss terms of the k steps of the last launch (k = 1 after ``step()``), oldest first."""
+        return torch.cat([self._loss_hist[:self._last_multi], self.losses[None]])
 
     def _pre_step(self):
         if self.cursor >= self.pool_rows - self.Rg:    # epoch end: reshuffle (i_batch >= N - n, scene_cateogries.py:439-449)
@@ -401,6 +456,9 @@ class FusedCategoryTrainer:
         flag words; bit 4 = the field backward clipped a scaled gradient this step (reported, not fatal)."""
         from .render_rays import LossExplode
         fl = self.flags.cpu()
+        if self._last_multi:           # every step of the last multi-step launch
+            for row in self._flags_hist[:self._last_multi].cpu():
+                fl = fl | row
         if bool((fl & 1).any()):
             raise LossExplode(f"loss explode: step {self.steps_done}, losses {self.losses.cpu().tolist()}")
         return fl

@@ -352,6 +352,40 @@ def test_many_epochs_graph_equals_eager(cnr, dev, n_obj):
     assert torch.equal(res["graph"][0], res["eager"][0]) and torch.equal(res["graph"][1], res["eager"][1])
 
 
+def test_run_with_multi_step_graphs_equals_single_steps(cnr, dev):
+    """run(n) captures groups of `unroll` steps in one hipGraph (no idle GPU between the steps of a group); cursor, RNG step,
+    optimiser step and the parameter ping-pong are device-side state, so 75 steps over a pool of 13 slices (epoch ends
+    inside: groups must not cross them) give bitwise the parameters, optimiser moments and per-step losses of 75 step()
+    calls; check_flags sees every step of a group."""
+    res = {}
+    for name in ("single", "multi"):
+        cfg = cnr.cfg.synthetic_config(device=str(dev), latent_dim=32, n_bins_cam2surface=4, n_bins=28)
+        gen = torch.Generator().manual_seed(3)
+        pools = [cnr.scene_cateogries.synthetic_pool(13 * 96, 4, gen, "cpu") for _ in range(2)]
+        tr = cnr.fused.FusedCategoryTrainer(cfg, 2, 4, pools, 96, dev, seed=1, generator=gen, unroll=6, check_every=10)
+        hist = []
+        if name == "single":
+            for _ in range(75):
+                tr.step()
+                hist.append(tr.losses.clone())
+        else:
+            for n in (3, 20, 1, 12, 39):
+                tr.run(n)
+                h = tr.loss_history()
+                hist.extend(h[k].clone() for k in range(h.shape[0]))
+            assert any(k[1] == 6 for k in tr.graphs if isinstance(k, tuple))      # groups of six were used
+        torch.cuda.synchronize()
+        res[name] = (tr.theta.clone(), tr.exp_avg.clone(), tr.exp_avg_sq.clone(), tr.steps_done, tr.cursor, tr.d_state.clone())
+        res[name + "_hist"] = hist
+    for a, b in zip(res["single"], res["multi"]):
+        assert (a == b) if not torch.is_tensor(a) else torch.equal(a, b)
+    # the multi run reports the steps of each launch: the last `k` of every run() call, all of them bitwise the single-step values
+    single = torch.stack(res["single_hist"])
+    got = res["multi_hist"]
+    assert len(got) >= 5 and all(any(torch.equal(g, s) for s in single) for g in got)
+    assert torch.equal(got[-1], single[-1])
+
+
 @pytest.mark.parametrize("C,R,n1,n2,n_obj,L", [(1, 2048, 8, 56, 4, 256), (2, 250, 4, 28, 4, 32), (2, 249, 8, 56, 6, 32),
                                                (1, 1023, 16, 112, 4, 32), (3, 64, 4, 28, 7, 32), (1, 1, 8, 56, 1, 32),
                                                # padded rays: the reference's real shape (120 rays per object x (1 + 9)

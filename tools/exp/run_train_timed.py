@@ -25,7 +25,9 @@ buf = (ctypes.c_longlong * (8 * 64))()
 lib.cnr_pipe8_read_stamps.argtypes = [ctypes.c_void_p]
 lib.cnr_pipe8_read_stamps(buf)
 b = list(buf)
-nb = 19 if (one and S > 32) else 18          # barriers per iteration (one composite exchange when a ray spans waves)
+# barriers per iteration: [chain only: the previous iteration's "images consumed"], [composite exchange when a ray spans waves],
+# one per layer step (9), [dW: "images consumed"]
+nb = 11 if (one and S > 32) else 10
 base = min(b[w * 64] for w in range(8))
 for w in range(8):
     st = b[w * 64: w * 64 + 2 * nb + 1]
@@ -36,8 +38,10 @@ for w in range(8):
     print("    wait", wait)
     mk = b[w * 64 + 44: w * 64 + 52]
     if w < 4 and one:
-        x1 = st[2]      # after the exchange barrier
-        print("    marks: fwd end->exch barrier", st[1] - mk[7], "| exch->sums", mk[0] - x1, "| var", mk[1] - mk[0], "| loss scalars", mk[2] - mk[1],
+        x1 = st[4]      # after the exchange barrier (the iteration's second)
+        print("    marks: fwd end->exch barrier", st[3] - mk[7], "| exch->sums", mk[0] - x1, "| var", mk[1] - mk[0], "| loss scalars", mk[2] - mk[1],
               "| suffix carry", mk[3] - mk[2], "| scan+docc", mk[4] - mk[3], "| dsg..DWS", mk[5] - mk[4], "| R2 stage+mfma", mk[6] - mk[5])
+    its = [v for v in b[w * 64 + 30: w * 64 + 42] if v]
+    print("    iteration starts (from loop start)", [v - b[w * 64 + 57] for v in its], "lengths", [its[i + 1] - its[i] for i in range(len(its) - 1)])
     ph = b[w * 64 + 56: w * 64 + 62]
     print("    phases: weights in LDS", ph[1] - ph[0], "| loops", ph[2] - ph[1], "| flush", ph[5] - ph[2], "| total", ph[5] - ph[0])
