@@ -724,6 +724,11 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
     CNR_PIDX8(BK_XYZ_E0) CNR_PIDX8(BK_XYZ_E1) CNR_PIDX8(BK_XYZ_E2)
 #undef CNR_PIDX8
     if (owner8<NDW>(BK_R0) == dwid) { r2i0 = block_index(BK_R2, 0, col); r2st = block_index(BK_R2, 1, col) - r2i0; }
+    // The role branches on the dW wave's index ONCE, around the whole iteration loop: with the branch inside every layer step
+    // the accumulator blocks met at a join after each step, and the compiler copied them between register ranges there (16
+    // moves behind the step's last MFMA, in front of the barrier the chain waves wait at).
+    auto dw_loop = [&](auto dwi_c) {
+    constexpr int DWI = decltype(dwi_c)::value;
     for (int t0 = blockIdx.x * NCHW; t0 < ntiles; t0 += tile_step) {
       asm volatile("" ::: "memory");
       P8STAMP_RESET();
@@ -828,10 +833,7 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
       if constexpr (KR > 1) { P8SYNC(); }   // the chain waves' composite exchange
 #define STEP8(PAR, NX, K0, K1, K2, K3, GRP)                                                                   \
   P8SYNC();                                                                                             \
-  if (dwid == 0) consume(IC<0>{}, IC<NX>{}, IC<K0>{}, IC<K1>{}, IC<K2>{}, IC<K3>{}, IC<GRP>{}, IC<PAR>{});    \
-  else if (dwid == 1) consume(IC<1>{}, IC<NX>{}, IC<K0>{}, IC<K1>{}, IC<K2>{}, IC<K3>{}, IC<GRP>{}, IC<PAR>{}); \
-  else if (dwid == 2) consume(IC<2>{}, IC<NX>{}, IC<K0>{}, IC<K1>{}, IC<K2>{}, IC<K3>{}, IC<GRP>{}, IC<PAR>{}); \
-  else consume(IC<3>{}, IC<NX>{}, IC<K0>{}, IC<K1>{}, IC<K2>{}, IC<K3>{}, IC<GRP>{}, IC<PAR>{});
+  consume(IC<DWI>{}, IC<NX>{}, IC<K0>{}, IC<K1>{}, IC<K2>{}, IC<K3>{}, IC<GRP>{}, IC<PAR>{});
       STEP8(0, 1, BK_R0, BK_R0, BK_R0, BK_R0, -1)                            // rgb.2 (rows 16..18 of rgb.0's block)
       STEP8(1, 1, BK_R0, BK_R0, BK_R0, BK_R0, 5)                             // rgb.0
       STEP8(0, 1, BK_T1, BK_T1, BK_T1, BK_T1, 3)                             // texture_layer_1
@@ -844,6 +846,11 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
       P8SYNC();   // done with this iteration's images (the chain waves wait for it before they write the next ones)
 #undef STEP8
     }
+    };
+    if (dwid == 0) dw_loop(IC<0>{});
+    else if (dwid == 1) dw_loop(IC<1>{});
+    else if (dwid == 2) dw_loop(IC<2>{});
+    else dw_loop(IC<3>{});
     // ---- this wave's blocks -> the workgroup's record, straight from the accumulators -------------------------
     float* rec = records + ((size_t)c * gridDim.x + blockIdx.x) * REC_FLOATS;
 #define CNR_PSTORE8(KIND, NROWS)                                                               \
