@@ -812,10 +812,15 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
           }
         };
 #pragma unroll
-        for (int w = 0; w < DEPTH - 1 && w < NCHW; ++w) load_tile(w);
+        for (int w = 0; w < NCHW; ++w) load_tile(w);
+#ifndef CNR_P8_NO_SCHED_BARRIER
+        // every read of the step is in flight before the first MFMA: left alone, the scheduler sinks the later tiles' reads
+        // between the MFMAs (fewer live registers, which this role has to spare) and the wave then waits out one LDS
+        // latency per tile instead of one per step
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (int w = 0; w < NCHW; ++w) {
-          if (w + DEPTH - 1 < NCHW) load_tile(w + DEPTH - 1);
           if constexpr (OWN0) mma_blk(w, IC<K0>{}, IC<SL0>{});
           if constexpr (OWN1) mma_blk(w, IC<K1>{}, IC<SL1>{});
           if constexpr (OWN2) mma_blk(w, IC<K2>{}, IC<SL2>{});
