@@ -117,7 +117,10 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
   P8PHASE(0);
   const bool is_chain = wv < NCHW;
   const int dwid = wv - NCHW;
-  {
+  // operands of the class -> LDS (weight fragments + constants, direction matrix, bias rows), by every thread.  Called inside the
+  // role branches: the chain waves first put their own first global requests in flight (first tile's inputs, step state),
+  // whose round trips then run under this copy instead of after it (~2 us of every workgroup at 2048 x 64)
+  auto copy_operands = [&]() {
     const unsigned char* src = packed + (size_t)c * PK_BYTES;
     for (int i = threadIdx.x * 16; i < PK_BYTES; i += NTHR * 16)
       *reinterpret_cast<f4*>(smem + i) = *reinterpret_cast<const f4*>(src + i);
@@ -128,9 +131,9 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
     }
     float* br = reinterpret_cast<float*>(smem + L8_BR);  // host guarantees 1 <= rows_per_class <= ROWS_MAX
     for (int i = threadIdx.x; i < rows_per_class * 128; i += NTHR) br[i] = biasrows[(size_t)c * rows_per_class * 128 + i];
-  }
-  __syncthreads();
-  P8PHASE(1);
+    __syncthreads();
+    P8PHASE(1);
+  };
   const float* cf = reinterpret_cast<const float*>(smem + PK_OFF_CONST);
   const unsigned char* bwf = smem + PK_OFF_BWD;
   unsigned char* chain_base = smem + L8_CHAIN;
@@ -235,12 +238,16 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
       t.g0 = ta.gt_rgb[ray * 3 + 0]; t.g1 = ta.gt_rgb[ray * 3 + 1]; t.g2 = ta.gt_rgb[ray * 3 + 2];
       t.lab = ta.labels[ray]; t.dm = ta.depth_mask[ray];
     };
+    TileIn cur = fetch(blockIdx.x * NCHW + wv), nxt = cur;     // in flight under the operand copy
+    int64_t cursor0 = 0;
+    if constexpr (KR > 0) cursor0 = ta.d_state ? ta.d_state[0] : 0;
+    copy_operands();
     // ---- one-launch step: this class's loss weights from the epoch's mask-count table, loss partial sums ------------
     float wd_c = 0.f, wc_c = 0.f, wo_c = 0.f, ld_acc = 0.f, lc_acc = 0.f, lo_acc = 0.f;
     int tab_flags = 0;
     if constexpr (KR > 0) {
       const int Cn = gridDim.y;
-      const float* tb = ta.counts_tab + (size_t)(ta.d_state ? ta.d_state[0] / R : 0) * (size_t)(Cn + 1) * 4;
+      const float* tb = ta.counts_tab + (size_t)(cursor0 / R) * (size_t)(Cn + 1) * 4;
       const bool e_d = tb[Cn * 4 + 0] != 0.f, e_c = tb[Cn * 4 + 1] != 0.f, e_o = tb[Cn * 4 + 2] != 0.f;
       wd_c = e_d ? 0.f : 1.0f / (tb[c * 4 + 0] + 1e-10f);
       wc_c = e_c ? 0.f : 1.0f / (tb[c * 4 + 1] + 1e-10f);
@@ -248,7 +255,6 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
       tab_flags = (e_d ? 2 : 0) | (e_c ? 4 : 0) | (e_o ? 8 : 0);
     }
     float* xch = reinterpret_cast<float*>(smem + l8_xch(NCH));   // [4][8]
-    TileIn cur = fetch(blockIdx.x * NCHW + wv), nxt = cur;
     bool any_iter = false;
     for (int tile = blockIdx.x * NCHW + wv, t0 = blockIdx.x * NCHW; t0 < ntiles; t0 += tile_step, tile += tile_step) {
       asm volatile("" ::: "memory");
@@ -681,6 +687,7 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
     // ===================================================================================================
     // dW role: 8 accumulator blocks per wave, six tiles per step
     // ===================================================================================================
+    copy_operands();
     // row m of the row-sum block: m = rs * latent slot + object row for the four latent layers, then one
     // "ones" row each for the two plain biases (encoding_shape: group 4, rgb.0: group 5)
     const int rs = WIDE ? rows_per_class : 4;  // rows per latent slot (a constant unless WIDE)

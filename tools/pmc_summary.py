@@ -31,7 +31,8 @@ for name in sorted(set(fetch) | set(write)):
     out["kernels"][key] = {"FETCH_SIZE_KB_raw": f, "WRITE_SIZE_KB": w, "hbm_bytes": hbm}
     if short not in ("field_fwd_kernel", "tail_kernel", "param_prep_kernel"):
         call += hbm
-    if short == "field_bwd_pipe8_kernel" and "true, 0>" not in key and "false, 0>" not in key:
+    targs = [t.strip() for t in key[key.find("<") + 1:key.rfind(">")].split(",")] if "<" in key else []
+    if short == "field_bwd_pipe8_kernel" and len(targs) >= 4 and targs[3] != "0":   # <NCH, NDW, WIDE, KR, TWO, PAD>: KR > 0
         out["cnr_field_train_call_hbm_bytes"] = hbm      # the one-launch step body (KR > 0 instantiation)
         # 12 B pts + 4 B z per sample in; per ray 18 B targets in + 24 B renders out; one 62 KB operand image and one
         # 58 KB record per workgroup are what the launch structure adds
