@@ -404,15 +404,7 @@ class FusedCategoryTrainer:
                 continue
             key = (self.parity, U)
             if key not in self.graphs:
-                par0 = self.parity
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    for i in range(U):
-                        self._out_slot = i if i < U - 1 else None
-                        self._step_body()
-                        self.parity ^= 1
-                self._out_slot, self.parity = None, par0
-                self.graphs[key] = g
+                self._capture_multi(self.parity, U)
             self.graphs[key].replay()
             self._last_multi = U - 1
             before = self.steps_done
@@ -421,6 +413,39 @@ class FusedCategoryTrainer:
             n -= U
             if self.check_every and self.steps_done // self.check_every != before // self.check_every:
                 self.check_flags()
+
+    def _capture_multi(self, par, U):
+        """Record (not run) U steps starting at state parity ``par`` as one graph."""
+        par0 = self.parity
+        self.parity = par
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for i in range(U):
+                self._out_slot = i if i < U - 1 else None
+                self._step_body()
+                self.parity ^= 1
+        self._out_slot, self.parity = None, par0
+        self.graphs[(par, U)] = g
+
+    def prepare_graphs(self, unroll=None):
+        """Capture every graph ``step()`` / ``run()`` can need -- one step and ``unroll`` steps, from either state parity --
+        without running them, so that no capture (a millisecond of host work) lands inside a timed or latency-sensitive
+        region later.  Needs two steps done (the buffers exist); a no-op without graphs or around a gradient all-reduce."""
+        if not self.use_graph or self.grad_exchange or self.split_graph or self.steps_done < 2:
+            return
+        U = min(self.unroll if unroll is None else max(2, int(unroll) // 2 * 2), self.unroll)
+        par0 = self.parity
+        for par in (0, 1):
+            if par not in self.graphs:
+                self.parity = par
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._step_body()
+                self.graphs[par] = g
+            self.parity = par0
+            if (par, U) not in self.graphs:
+                self._capture_multi(par, U)
+        self.parity = par0
 
     def loss_history(self):
         """(k, 3, C): the loss terms of the k steps of the last launch (k = 1 after ``step()``), oldest first."""

@@ -370,6 +370,9 @@ def test_run_with_multi_step_graphs_equals_single_steps(cnr, dev):
                 hist.append(tr.losses.clone())
         else:
             for n in (3, 20, 1, 12, 39):
+                if n == 20:
+                    tr.prepare_graphs()          # captures (does not run) the one-step and six-step graphs of both parities
+                    assert {0, 1, (0, 6), (1, 6)} <= set(tr.graphs)
                 tr.run(n)
                 h = tr.loss_history()
                 hist.extend(h[k].clone() for k in range(h.shape[0]))
