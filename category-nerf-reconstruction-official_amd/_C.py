@@ -56,7 +56,7 @@ SIGNATURES = {
     "cnr_adamw_epilogue": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64,
                            _vp, _vp, _i, _i, _vp],
     "cnr_step_tail": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _vp, _vp, _f, _i, _f, _f, _f,
-                      _f, _f, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp],
+                      _f, _f, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _f, _f, _vp],
     "cnr_step_grad": [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _vp, _vp, _f, _vp, _i, _vp, _vp, _vp],
     "cnr_field_fwd_render_blocks": [_i, _i],
     "cnr_field_fwd_render_workspace_bytes": [_i, _i, _i],

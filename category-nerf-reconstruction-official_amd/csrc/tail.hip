@@ -29,6 +29,7 @@ struct TailArgs {
   FlatLayout lay; int64_t off_B; int C;
   const float* zl; float* dbiasrows; float reg_scale;
   float lr, b1, b2, eps, wd;
+  float code_lr, code_wd;   // the code tables' own AdamW group (train.py:40,54-64: code_lr / code_weight_decay); = lr, wd when not given
   const int64_t* state_cur; int64_t* state_next; int64_t add_rows;
   const float* partials; int nb; float* losses; int32_t* flags;
   const float* depth; int64_t pool_rows; const int* perm; int R; float* max_bound;
@@ -42,8 +43,15 @@ struct TailArgs {
   int* clamp_flags;  // optional (C,): bits the field backward raised this step (cnr_field_bwd_pipe); or-ed into flags, cleared
 };
 
-__device__ __forceinline__ void adam_one(const TailArgs& a, int64_t e, float g, float step_size, float inv_bc2_sqrt) {
-  float pi = a.theta_in[e] * (1.0f - a.lr * a.wd);
+// (is_code: the element belongs to a shape / texture code table of its class row)
+__device__ __forceinline__ bool is_code_off(const cnr::FlatLayout& lay, int64_t q) {
+  const int64_t n = (int64_t)lay.n_obj * lay.L;
+  return (q >= lay.shape && q < lay.shape + n) || (q >= lay.tex && q < lay.tex + n);
+}
+__device__ __forceinline__ void adam_one(const TailArgs& a, int64_t e, float g, float step_size, float inv_bc2_sqrt,
+                                         bool is_code) {
+  float pi = a.theta_in[e] * (1.0f - (is_code ? a.code_lr * a.code_wd : a.lr * a.wd));
+  if (is_code) step_size *= a.code_lr / a.lr;
   const float mi = a.m[e] + (g - a.m[e]) * (1.0f - a.b1);
   const float vi = a.v[e] * a.b2 + (1.0f - a.b2) * g * g;
   const float denom = sqrtf(vi) * inv_bc2_sqrt + a.eps;
@@ -63,11 +71,12 @@ struct AdamSink {  // latent-path gradient element -> gradient buffer (kept for 
     const int64_t e = row0 + idx;
     a.grad[e] = g;
     if (a.grad_only) return;
-    float pi = p0 * (1.0f - a.lr * a.wd);
+    const bool is_code = is_code_off(a.lay, idx);
+    float pi = p0 * (1.0f - (is_code ? a.code_lr * a.code_wd : a.lr * a.wd));
     const float mi = m0 + (g - m0) * (1.0f - a.b1);
     const float vi = v0 * a.b2 + (1.0f - a.b2) * g * g;
     const float denom = sqrtf(vi) * inv_bc2_sqrt + a.eps;
-    pi -= step_size * (mi / denom);
+    pi -= (is_code ? step_size * (a.code_lr / a.lr) : step_size) * (mi / denom);
     a.theta_out[e] = pi; a.m[e] = mi; a.v[e] = vi;
   }
 };
@@ -216,7 +225,7 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
           if (t != 0.0f) { g += t; a.grad[e] = g; }
         }
       }
-      adam_one(a, e, g, step_size, inv_bc2_sqrt);
+      adam_one(a, e, g, step_size, inv_bc2_sqrt, is_code_off(a.lay, q));
     }
     return;
   } else {
@@ -268,7 +277,7 @@ extern "C" int cnr_step_tail(const float* theta_in, float* theta_out, float* gra
                              const void* rl_workspace, float* losses, int32_t* flags, const float* depth,
                              int64_t pool_rows, const int* perm, float* next_max_bound, int R, const void* records,
                              int nwg, const long long* rows_fix, int rl_blocks, int* clamp_flags, const int* n_obj_cls,
-                             void* stream) {
+                             float code_lr, float code_weight_decay, void* stream) {
   if (!theta_in || !theta_out || theta_in == theta_out || !grad || !exp_avg || !exp_avg_sq || class_stride <= 0 ||
       L <= 0 || n_obj <= 0 || C <= 0 || !state_cur || !state_next || state_cur == state_next || !rl_workspace ||
       !losses || !flags || R <= 0)
@@ -283,6 +292,8 @@ extern "C" int cnr_step_tail(const float* theta_in, float* theta_out, float* gra
   a.lay = FlatLayout{class_stride, off_latW, off_latb, off_shape, off_tex, L, n_obj};
   a.off_B = off_B; a.C = C; a.zl = zl; a.dbiasrows = dbiasrows; a.reg_scale = reg_scale; a.n_obj_cls = n_obj_cls;
   a.lr = lr; a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.wd = weight_decay;
+  a.code_lr = code_lr > 0.0f ? code_lr : lr; a.code_wd = code_lr > 0.0f ? code_weight_decay : weight_decay;
+  if (!(lr > 0.0f)) return CNR_E_ARG;
   a.state_cur = state_cur; a.state_next = state_next; a.add_rows = add_rows;
   const int rpb = cnr_rl::rl_rays_per_block(C, R);
   a.partials = (const float*)rl_workspace; a.nb = rl_blocks > 0 ? rl_blocks : (R + rpb - 1) / rpb;

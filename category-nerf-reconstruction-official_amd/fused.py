@@ -107,8 +107,9 @@ class FusedCategoryTrainer:
         self.L = cfg.net_hyperparams["latent_dim"]
         self.scale = float(cfg.obj_scale)
         self.lr, self.wd = cfg.learning_rate, cfg.weight_decay
-        assert cfg.code_learning_rate == cfg.learning_rate and cfg.code_weight_decay == cfg.weight_decay, \
-            "one flat AdamW group: the shipped configs use identical lr / weight decay for codes and networks"
+        # the code tables are an AdamW group of their own in the reference (train.py:40,54-64); the shipped configs give both
+        # groups the same values
+        self.code_lr, self.code_wd = float(cfg.code_learning_rate), float(cfg.code_weight_decay)
         # ---- sharding ---------------------------------------------------------------------------------------------
         self.pg = process_group
         pg_world = 1 if process_group is None else torch.distributed.get_world_size(process_group)
@@ -340,7 +341,8 @@ class FusedCategoryTrainer:
                 self.flags if self._out_slot is None else self._flags_hist[self._out_slot],
                 None, self.pool_rows, None, None, R,
                 o["bwd_ws"] if self.fused_tail else None, self._nwg if self.fused_tail else 0,
-                self.rows_fix if self.fused_tail else None, self._ft_blocks or self._rl_blocks, self.clamp, self.n_obj_cls)
+                self.rows_fix if self.fused_tail else None, self._ft_blocks or self._rl_blocks, self.clamp, self.n_obj_cls,
+                self.code_lr, self.code_wd)
 
     def step(self):
         """One train step.  Returns nothing; ``self.losses`` (3,C) / ``self.flags`` (C,) hold the device-side

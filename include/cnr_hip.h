@@ -348,7 +348,9 @@ int cnr_adamw_epilogue(float* param, const float* grad, float* exp_avg, float* e
  * cnr_field_bwd_pipe_blocks(...), and rows_fix the (8, C, n_obj, 4, 32) int64 table that call accumulated (2^-40 fixed
  * point, integer atomics: any order, same sum) -- zero it before every field backward.  dbiasrows then receives the
  * float form of that table.
- * rl_blocks: loss partials per class in rl_workspace; 0 = cnr_render_loss's own block count. */
+ * rl_blocks: loss partials per class in rl_workspace; 0 = cnr_render_loss's own block count.
+ * code_lr > 0: the shape / texture code tables are an AdamW group of their own (code_lr, code_weight_decay: train.py:40,
+ * 54-64, configs' code_lr / code_weight_decay); 0 = they share lr / weight_decay. */
 int cnr_step_tail(const float* theta_in, float* theta_out, float* grad, float* exp_avg, float* exp_avg_sq,
                   int64_t class_stride, int64_t off_B, int64_t off_latW, int64_t off_latb, int64_t off_shape,
                   int64_t off_tex, int L, int n_obj, int C, const float* zl, float* dbiasrows, float reg_scale,
@@ -356,7 +358,8 @@ int cnr_step_tail(const float* theta_in, float* theta_out, float* grad, float* e
                   const int64_t* state_cur, int64_t* state_next, int64_t add_rows, const void* rl_workspace,
                   float* losses, int32_t* flags, const float* depth, int64_t pool_rows, const int* perm,
                   float* next_max_bound, int R, const void* records, int nwg, const long long* rows_fix,
-                  int rl_blocks, int* clamp_flags, const int* n_obj_cls, void* stream);
+                  int rl_blocks, int* clamp_flags, const int* n_obj_cls, float code_lr, float code_weight_decay,
+                  void* stream);
 /* clamp_flags (optional, (C,) int32, zero before the first step): what cnr_field_bwd_pipe raised during this step -- bit 4
  * (16) = a scaled upstream gradient |d sigma| * grad_scale exceeded 8192 and was clipped for the f16 chain; the epilogue
  * or-s the word into flags[c] and clears it. */

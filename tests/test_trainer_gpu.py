@@ -352,6 +352,33 @@ def test_many_epochs_graph_equals_eager(cnr, dev, n_obj):
     assert torch.equal(res["graph"][0], res["eager"][0]) and torch.equal(res["graph"][1], res["eager"][1])
 
 
+def test_code_tables_are_their_own_adamw_group(cnr, dev):
+    """The reference gives the code tables their own AdamW group (code_lr / code_weight_decay, train.py:40,54-64).  With
+    different values for the two groups the networks' parameters after a step are bitwise what a run with equal values gives,
+    and the codes follow AdamW's first step with THEIR lr / weight decay: p (1 - lr wd) - lr g / (|g| + eps)."""
+    res = {}
+    for name, (clr, cwd) in (("same", (1e-3, 0.013)), ("own", (4e-3, 0.05))):
+        cfg = cnr.cfg.synthetic_config(device=str(dev), latent_dim=32, n_bins_cam2surface=4, n_bins=28)
+        cfg.code_learning_rate, cfg.code_weight_decay = clr, cwd
+        gen = torch.Generator().manual_seed(11)
+        pools = [cnr.scene_cateogries.synthetic_pool(4 * 200, 3, gen, "cpu") for _ in range(2)]
+        tr = cnr.fused.FusedCategoryTrainer(cfg, 2, 3, pools, 200, dev, seed=3, generator=gen, use_graph=False)
+        th0 = tr.theta.clone()
+        tr.step()
+        torch.cuda.synchronize()
+        res[name] = (th0, tr.theta.clone(), tr.grad.clone(), tr.lay)
+    th0, a, g, lay = res["same"]
+    b = res["own"][1]
+    assert torch.equal(th0, res["own"][0]) and torch.equal(g, res["own"][2])
+    net = slice(0, lay.shape[0])
+    assert torch.equal(a[:, net], b[:, net])
+    codes = slice(lay.shape[0], lay.total)
+    gd = g[:, codes].double()
+    for th, lr, wd in ((a, 1e-3, 0.013), (b, 4e-3, 0.05)):
+        want = th0[:, codes].double() * (1 - lr * wd) - lr * gd / (gd.abs() + 1e-8)
+        assert (th[:, codes].double() - want).abs().max() < 2e-6 * max(1.0, float(want.abs().max()))
+
+
 def test_run_with_multi_step_graphs_equals_single_steps(cnr, dev):
     """run(n) captures groups of `unroll` steps in one hipGraph (no idle GPU between the steps of a group); cursor, RNG step,
     optimiser step and the parameter ping-pong are device-side state, so 75 steps over a pool of 13 slices (epoch ends
