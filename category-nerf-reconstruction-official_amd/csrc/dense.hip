@@ -25,6 +25,7 @@ namespace {
 typedef float f16acc __attribute__((ext_vector_type(16)));
 typedef _Float16 hv8 __attribute__((ext_vector_type(8)));
 constexpr int TM = 64, TN = 64, TK = 32, LDT = TK + 1, LDH = TK + 8;   // LDH: f16 row stride (80 B: 16-byte aligned rows)
+constexpr int EPT = TM * TK / 256;                                     // slab elements per thread and operand
 
 struct DenseArgs {
   const float* A; int64_t lda; int a_trans;   // a_trans: A(i, r) = A[r * lda + i], else A[i * lda + r]
@@ -52,16 +53,17 @@ __global__ __launch_bounds__(256) void dense_kernel(DenseArgs p) {
   for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
   const int r_lo = blockIdx.z * p.r_chunk, r_hi = r_lo + p.r_chunk < p.Rn ? r_lo + p.r_chunk : p.Rn;
   float* Cz = p.C + (int64_t)blockIdx.z * p.c_zstride;
-  // ---- slab loads: 64 x 32 elements each, 8 per thread, consecutive threads along the contiguous dimension.  The loads of
+  // ---- slab loads: 64 x TK elements each, EPT per thread, consecutive threads along the contiguous dimension (TK = 64 was
+  // measured: 1.16 against 1.07 ms per background step -- the slab loop is bound by its per-element loads, not by round trips).  The loads of
   // slab k + 1 are issued before the products of slab k (registers -> LDS after them): a block used to walk load -> barrier
   // -> products -> barrier per slab, one memory round trip per 32 of K with nothing to overlap it
-  float an[8], bn[8];
+  float an[EPT], bn[EPT];
   auto load_slab = [&](int r0) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
+    for (int e = 0; e < EPT; ++e) {
       const int idx = e * 256 + threadIdx.x;
       int ii, rr;
-      if (p.a_trans) { ii = idx & 63; rr = idx >> 6; } else { rr = idx & 31; ii = idx >> 5; }
+      if (p.a_trans) { ii = idx & 63; rr = idx >> 6; } else { rr = idx & (TK - 1); ii = idx / TK; }
       const int gi = i0 + ii, gr = r0 + rr;
       float v = 0.0f;
       if (gi < p.I && gr < r_hi) {
@@ -72,10 +74,10 @@ __global__ __launch_bounds__(256) void dense_kernel(DenseArgs p) {
       an[e] = v;
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
+    for (int e = 0; e < EPT; ++e) {
       const int idx = e * 256 + threadIdx.x;
       int jj, rr;
-      if (p.b_trans) { jj = idx & 63; rr = idx >> 6; } else { rr = idx & 31; jj = idx >> 5; }
+      if (p.b_trans) { jj = idx & 63; rr = idx >> 6; } else { rr = idx & (TK - 1); jj = idx / TK; }
       const int gj = j0 + jj, gr = r0 + rr;
       float v = 0.0f;
       if (gr < r_hi) {
@@ -88,11 +90,11 @@ __global__ __launch_bounds__(256) void dense_kernel(DenseArgs p) {
   load_slab(r_lo);
   for (int r0 = r_lo; r0 < r_hi; r0 += TK) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
+    for (int e = 0; e < EPT; ++e) {
       const int idx = e * 256 + threadIdx.x;
       int ii, rr, jj, rb;
-      if (p.a_trans) { ii = idx & 63; rr = idx >> 6; } else { rr = idx & 31; ii = idx >> 5; }
-      if (p.b_trans) { jj = idx & 63; rb = idx >> 6; } else { rb = idx & 31; jj = idx >> 5; }
+      if (p.a_trans) { ii = idx & 63; rr = idx >> 6; } else { rr = idx & (TK - 1); ii = idx / TK; }
+      if (p.b_trans) { jj = idx & 63; rb = idx >> 6; } else { rb = idx & (TK - 1); jj = idx / TK; }
       if (HALF) {
         Ah[ii * LDH + rr] = (_Float16)fminf(fmaxf(an[e] * p.a_scale, -60000.0f), 60000.0f);
         Bh[jj * LDH + rb] = (_Float16)bn[e];
@@ -145,8 +147,16 @@ __global__ __launch_bounds__(256) void dense_reduce_kernel(const float* __restri
   const int ld = J + (has_extra ? 1 : 0);
   const int64_t n = (int64_t)I * ld;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
-    float s = 0.0f;
-    for (int z = 0; z < nz; ++z) s += ws[(int64_t)z * n + e];
+    float s = 0.0f;   // partials in order, eight loads in flight (one dependent load per partial was 13 of this launch's 15 us)
+    int z = 0;
+    for (; z + 8 <= nz; z += 8) {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = ws[(int64_t)(z + u) * n + e];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += t[u];
+    }
+    for (; z < nz; ++z) s += ws[(int64_t)z * n + e];
     const int i = (int)(e / ld), j = (int)(e % ld);
     if (j < J) out[(int64_t)i * J + j] = s;
     else if (extra) extra[i] = s;
