@@ -40,8 +40,20 @@ class BackgroundStep:
         self._zero = torch.zeros(1, device=dev, dtype=torch.int64)
         self.seed = int(seed) + 101
         self.params = list(self.trainer.fc_occ_map.parameters()) + list(self.trainer.pe.parameters())
-        self.opt = torch.optim.AdamW(self.params, lr=cfg.learning_rate, weight_decay=cfg.weight_decay, capturable=True,
-                                     foreach=True)
+        # one flat buffer for the parameters and one for their gradients (the modules' tensors become views): the optimiser is
+        # ONE launch (cnr_adamw_step, torch.optim.AdamW semantics, step count read from the device state) and the gradient
+        # reset one fill, instead of the ~50 small kernels of a capturable torch AdamW + per-tensor zero fills per step
+        n = sum(p.numel() for p in self.params)
+        self.flat = torch.empty(n, device=dev)
+        self.gflat = torch.zeros(n, device=dev)
+        off = 0
+        for p in self.params:
+            k = p.numel()
+            self.flat[off:off + k].copy_(p.data.reshape(-1))
+            p.data = self.flat[off:off + k].view_as(p)
+            p.grad = self.gflat[off:off + k].view_as(p)
+            off += k
+        self.exp_avg, self.exp_avg_sq = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
         self.bufs = {}
         self.loss = torch.zeros((), device=dev)
         self.losses = torch.zeros(3, device=dev)
@@ -59,6 +71,7 @@ class BackgroundStep:
     def _body(self):
         """sample -> PE -> OccupancyMap -> composite + losses -> backward -> AdamW -> advance (all stream-ordered)."""
         cfg, t = self.cfg, self.trainer
+        self.gflat.zero_()
         b = ops.sample_rays(self.pool["rgbs"], self.pool["depth"], self.pool["dirs"], self.pool["T"], self.n1, self.n2,
                             cfg.surface_eps, cfg.stop_eps, min_bound=cfg.min_depth, world_frame=True, seed=self.seed,
                             d_state=self.d_state, rays=self.R, out=self.bufs, perm=self.perm)
@@ -66,7 +79,8 @@ class BackgroundStep:
         loss, ld, _ = loss_mod.step_batch_loss(alpha[None], color[None], b["gt_depth"], b["gt_rgb"], b["labels"],
                                                b["depth_mask"], b["z"])
         loss.backward()
-        self.opt.step()
+        ops.adamw_step(self.flat, self.gflat, self.exp_avg, self.exp_avg_sq, cfg.learning_rate, (0.9, 0.999), 1e-8,
+                       cfg.weight_decay, 0, 1.0, d_state=self.d_state)          # step = d_state[2] + 1, advanced below
         self.loss.copy_(loss.detach())
         self.losses.copy_(torch.stack([ld["depth"][0], ld["color"][0], ld["opacity"][0]]).detach())
         _C.call("cnr_step_advance", self.d_state, self.R)
@@ -83,11 +97,9 @@ class BackgroundStep:
         """One background step; after three eager steps it is captured and replayed."""
         self.pre_step()
         if not use_graph or self.steps_done < 3:
-            self.opt.zero_grad(set_to_none=True)
             self._body()
         else:
             if self.graph is None:
-                self.opt.zero_grad(set_to_none=True)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     self._body()
@@ -112,12 +124,10 @@ class FullStepTrainer:
         b.pre_step()
         par = o.parity
         if self.steps_done < 3:
-            b.opt.zero_grad(set_to_none=True)
             b._body()
             o._step_body()
         else:
             if par not in self.graphs:
-                b.opt.zero_grad(set_to_none=True)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     b._body()
