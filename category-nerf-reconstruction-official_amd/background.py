@@ -54,6 +54,11 @@ class BackgroundStep:
             p.grad = self.gflat[off:off + k].view_as(p)
             off += k
         self.exp_avg, self.exp_avg_sq = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        # every Linear of the field is used once per step: its weight / bias gradients are written straight into their views
+        # of the flat gradient buffer by the dense backward (model.OccupancyMap.grad_out), no per-parameter add launch
+        import torch.nn as nn
+        self.trainer.fc_occ_map.grad_out = {id(m): (m.weight.grad, m.bias.grad if m.bias is not None else None)
+                                            for m in self.trainer.fc_occ_map.modules() if isinstance(m, nn.Linear)}
         self.bufs = {}
         self.loss = torch.zeros((), device=dev)
         self.losses = torch.zeros(3, device=dev)

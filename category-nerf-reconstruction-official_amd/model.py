@@ -77,6 +77,7 @@ class OccupancyMap(nn.Module):
     def __init__(self, emb_size1, emb_size2, hidden_size=256, do_color=True, hidden_layers_block=1):
         super().__init__()
         self.half = False     # True: the dense layers run on the f16-operand MFMA form (fp32 accumulate); not a parameter
+        self.grad_out = {}    # id(Linear) -> (dW, db) tensors the backward writes into directly (background.BackgroundStep)
         self.do_color = do_color
         self.embedding_size1, self.embedding_size2 = emb_size1, emb_size2
         self.in_layer = fc_block(emb_size1, hidden_size)
@@ -89,7 +90,7 @@ class OccupancyMap(nn.Module):
             self.out_color = nn.Linear(hidden_size, 3)
 
     def _fc(self, block, x):       # fc_block: Linear + ReLU in one kernel
-        return ops.DenseFn.apply(x, block[0].weight, block[0].bias, True, self.half)
+        return ops.DenseFn.apply(x, block[0].weight, block[0].bias, True, self.half, self.grad_out.get(id(block[0])))
 
     def forward(self, x, noise_std=None, do_alpha=True, do_color=True, do_cat=True):
         e1 = x[..., :self.embedding_size1]
@@ -102,12 +103,14 @@ class OccupancyMap(nn.Module):
             fc4 = self._fc(blk, fc4)
         alpha = None
         if do_alpha:
-            raw = ops.DenseFn.apply(fc4, self.out_alpha.weight, self.out_alpha.bias, False, False)   # the x10 logit stays fp32
+            raw = ops.DenseFn.apply(fc4, self.out_alpha.weight, self.out_alpha.bias, False, False,
+                                    self.grad_out.get(id(self.out_alpha)))                    # the x10 logit stays fp32
             if noise_std is not None:
                 raw = raw + torch.randn(raw.shape, device=x.device) * noise_std
             alpha = raw * 10.0                         # unisurf scaling, src/model.py:142
         color = None
         if self.do_color and do_color:
             fc5 = self._fc(self.color_linear, torch.cat((fc4, x[..., self.embedding_size1:]), dim=-1))
-            color = torch.sigmoid(ops.DenseFn.apply(fc5, self.out_color.weight, self.out_color.bias, False, self.half))
+            color = torch.sigmoid(ops.DenseFn.apply(fc5, self.out_color.weight, self.out_color.bias, False, self.half,
+                                                    self.grad_out.get(id(self.out_color))))
         return alpha, color

@@ -344,7 +344,11 @@ class DenseFn(Function):
     v_mfma_f32_32x32x16_f16, fp32 accumulation -- the f16 tier of the background model."""
 
     @staticmethod
-    def forward(ctx, x, W, b, relu, half=False):
+    def forward(ctx, x, W, b, relu, half=False, grad_out=None):
+        # grad_out = (dW, db) tensors: the backward WRITES the parameter gradients there and reports none to autograd -- for a
+        # host that keeps gradients in a flat buffer and uses the layer once per step (background.BackgroundStep: one add
+        # launch per parameter and step less)
+        ctx.grad_out = grad_out
         K, N = W.shape[1], W.shape[0]
         x2 = x.reshape(-1, K).contiguous()
         y = torch.empty(x2.shape[0], N, device=x.device, dtype=torch.float32)
@@ -360,13 +364,16 @@ class DenseFn(Function):
         M, K, N = x2.shape[0], W.shape[1], W.shape[0]
         dy2 = dy.reshape(M, N).contiguous()
         dx = torch.empty(M, K, device=dy.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
-        dW = torch.empty(N, K, device=dy.device, dtype=torch.float32)
-        db = torch.empty(N, device=dy.device, dtype=torch.float32) if ctx.has_b else None
+        direct = ctx.grad_out
+        dW = direct[0] if direct else torch.empty(N, K, device=dy.device, dtype=torch.float32)
+        db = (direct[1] if direct else torch.empty(N, device=dy.device, dtype=torch.float32)) if ctx.has_b else None
         wsb = int(_C.load().cnr_dense_bwd_workspace_bytes(M, K, N))
         ws = torch.empty(max(wsb, 16), device=dy.device, dtype=torch.uint8)
         _C.call("cnr_dense_bwd", x2, W.contiguous(), y, dy2, dx, dW, db, M, K, N, int(ctx.relu), ws, wsb, int(ctx.half),
                 DENSE_GRAD_SCALE)
-        return (dx.reshape(ctx.xshape) if dx is not None else None), dW, db, None, None
+        if direct:
+            return (dx.reshape(ctx.xshape) if dx is not None else None), None, None, None, None, None
+        return (dx.reshape(ctx.xshape) if dx is not None else None), dW, db, None, None, None
 
 
 # cnr_field_bwd variants: "split" = two block-split launches (csrc/fused_bwd.hip), "pipe2"/"pipe3" = the single
