@@ -163,6 +163,75 @@ __global__ __launch_bounds__(256) void dense_reduce_kernel(const float* __restri
   }
 }
 
+// dW (N x K, + column K = db) = (dy masked by y > 0)^T x over M samples, the contraction that matters for the background step
+// (M = 16 800, the result tiny): no LDS tiling at all.  The operand layout of v_mfma_f32_32x32x2_f32 IS a coalesced global
+// read here -- A[i = n][k = m]: lane (n, m & 1) reads dy[m][n0 + n]; B[k = m][j]: lane (j, m & 1) reads x[m][k0 + j] -- 128
+// contiguous bytes per half wave and instruction, eight sample pairs in flight per wave.  A workgroup = one 32 x 32 tile of
+// the result and one chunk of samples; its four waves split the chunk and add their accumulators through LDS, so one
+// partial per workgroup goes to the workspace (dense_reduce_kernel adds the partials in order).  46 -> ~15 us per layer
+// against the LDS-tiled form (whose 64-chunk split ran nine load -> barrier -> scatter -> barrier rounds per workgroup).
+__global__ __launch_bounds__(256) void dense_dw_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                       const float* __restrict__ x, float* __restrict__ ws, int M, int K,
+                                                       int N, int has_db, int chunk, int gx, int gy, int nz) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
+  // XCD-aware mapping of the 1-D grid: blocks b and b + 8 share an XCD (its L2), so ALL gx * gy result tiles of a sample
+  // chunk -- which read the same rows of dy, y and x -- are dealt to one XCD: chunk z = 8 (s / T) + (b & 7), tile s % T of the
+  // s = b >> 3-th block of that XCD.  Dealt tile-fastest instead, the eight L2s each fetched every chunk (25.7 us per launch).
+  const int T = gx * gy, sx = blockIdx.x >> 3;
+  const int z = 8 * (sx / T) + (blockIdx.x & 7), tt = sx % T;
+  if (z >= nz) return;
+  const int k0 = (tt % gx) * 32, n0 = (tt / gx) * 32;
+  const int ld = K + (has_db ? 1 : 0);
+  const int n = n0 + l31, kc = k0 + l31;
+  const bool n_ok = n < N, k_in = kc < K, k_one = has_db && kc == K;
+  const int m_lo = z * chunk, m_hi = min(M, m_lo + chunk);
+  const int per = ((m_hi - m_lo + 3) / 4 + 1) / 2 * 2;              // samples per wave (a quarter of the chunk), even
+  const int w_lo = m_lo + wv * per, w_hi = min(m_hi, w_lo + per);
+  f16acc acc;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+  constexpr int U = 8;
+  // two register sets: the loads of the next 16 samples are in flight while the MFMAs of the current 16 run (a wave walks only
+  // ~9 such blocks; without the overlap every block waited out a full memory round trip: 31 us per launch instead of ~12)
+  float a0[U], b0[U], k0m[U], a1[U], b1[U], k1m[U];
+  auto fetch = [&](float (&a)[U], float (&b)[U], float (&mk)[U], int m0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int m = m0 + 2 * u + half;
+      const bool ok = m < w_hi;
+      a[u] = (ok && n_ok) ? dy[(int64_t)m * N + n] : 0.0f;
+      mk[u] = (y && ok && n_ok) ? y[(int64_t)m * N + n] : 1.0f;
+      b[u] = ok ? (k_in ? x[(int64_t)m * K + kc] : (k_one ? 1.0f : 0.0f)) : 0.0f;
+    }
+  };
+  auto mma = [&](const float (&a)[U], const float (&b)[U], const float (&mk)[U]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(mk[u] > 0.0f ? a[u] : 0.0f, b[u], acc, 0, 0, 0);
+  };
+  fetch(a0, b0, k0m, w_lo);
+  for (int m0 = w_lo; m0 < w_hi; m0 += 4 * U) {
+    fetch(a1, b1, k1m, m0 + 2 * U);
+    mma(a0, b0, k0m);
+    fetch(a0, b0, k0m, m0 + 4 * U);
+    mma(a1, b1, k1m);
+  }
+  __shared__ float red[3][16][64];
+  if (wv > 0) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) red[wv - 1][q][lane] = acc[q];
+  }
+  __syncthreads();
+  if (wv == 0) {
+    float* out = ws + (int64_t)z * N * ld;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const float v = ((acc[q] + red[0][q][lane]) + red[1][q][lane]) + red[2][q][lane];
+      const int i = n0 + (q & 3) + 8 * (q >> 2) + 4 * half;
+      if (i < N && kc < ld) out[(int64_t)i * ld + kc] = v;
+    }
+  }
+}
+
 int launch(const DenseArgs& p, void* stream, int nz = 1, bool half = false) {
   const int jn = p.extra_j >= 0 ? p.J + 1 : p.J;
   dim3 grid((jn + TN - 1) / TN, (p.I + TM - 1) / TM, nz);
@@ -216,13 +285,17 @@ extern "C" int cnr_dense_bwd(const float* x, const float* W, const float* y, con
   const int ld = K + (db ? 1 : 0);
   if (!workspace || workspace_bytes < (int64_t)nz * N * ld * (int64_t)sizeof(float)) return CNR_E_ARG;
   const int chunk = ((M + nz - 1) / nz + TK - 1) / TK * TK;
-  DenseArgs p{dy, N, 1, x, K, 1, mask, 1, nullptr, 0, (float*)workspace, ld, nullptr, db ? K : -1, N, K, M, chunk,
-              (int64_t)N * ld, gs};
-  const int rc = launch(p, stream, (M + chunk - 1) / chunk, half);
-  if (rc) return rc;
+  const int nzl = (M + chunk - 1) / chunk;
+  {   // both tiers: fp32 operands straight from global memory (dense_dw_kernel; exact fp32 products also for the f16 tier)
+    const int gx = (ld + 31) / 32, gy = (N + 31) / 32;
+    dim3 grid((unsigned)(8 * ((nzl + 7) / 8) * gx * gy));
+    hipLaunchKernelGGL(dense_dw_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, mask, x, (float*)workspace, M, K, N,
+                       db ? 1 : 0, chunk, gx, gy, nzl);
+    CNR_LAUNCH_CHECK();
+  }
   const int64_t n = (int64_t)N * ld;
   hipLaunchKernelGGL(dense_reduce_kernel, dim3((unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024)), dim3(256), 0,
-                     (hipStream_t)stream, (const float*)workspace, (M + chunk - 1) / chunk, N, K, db ? 1 : 0, dW, db);
+                     (hipStream_t)stream, (const float*)workspace, nzl, N, K, db ? 1 : 0, dW, db);
   CNR_LAUNCH_CHECK();
   return CNR_OK;
 }
