@@ -389,12 +389,12 @@ def main():
             pools2 = [cnr_amd.scene_cateogries.synthetic_pool(64 * R2, n_obj, torch.Generator().manual_seed(99), "cpu")]
             tr2 = cnr_amd.fused.FusedCategoryTrainer(cfg2, 1, n_obj, pools2, R2, dev, seed=1,
                                                      generator=torch.Generator().manual_seed(5))
-            for _ in range(10):
-                tr2.step()
+            tr2.run(10)
+            tr2.prepare_graphs()
+            tr2.run(2 * tr2.unroll + 2)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(2000):
-                tr2.step()
+            tr2.run(2000)
             torch.cuda.synchronize()
             d2 = time.perf_counter() - t0
             out["extra_legs"] = {"real_config_480x10": {"workload": "1 category x 4 objects, 120 rays per object x 10 samples "
