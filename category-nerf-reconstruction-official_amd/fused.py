@@ -185,9 +185,10 @@ class FusedCategoryTrainer:
         self.grad_scale = float(grad_scale) if grad_scale else float(2 ** round(math.log2(max(self.Rg, 2))))
         # workgroups per class of the field kernels (0 = this default): every workgroup copies the class's 61 KB operand image in
         # and leaves a 58 KB gradient record, so with several classes per GPU fewer, longer-running workgroups per class win --
-        # about 512 in total keeps the 256 CUs level.  Measured (2048 x 64 per class): 16 classes 46.4 -> 55.4 M rays/s with 32
-        # per class instead of 256 (241 MB of records per step -> 30 MB), 4 classes 43.7 -> 48.7 M with 128
-        self.bwd_blocks = int(bwd_blocks) if int(bwd_blocks) > 0 else min(256, max(32, 512 // max(n_cls, 1)))
+        # 256 in total, one per CU, in one round.  Measured (2048 x 64 per class, M rays/s; 256 per class -> 256 / C per class):
+        # 2 classes 39.5 -> 43.1, 3: 41.2 (= at 170), 4: 43.7 -> 47.7 (48.7 at 128), 8: 50.9 (at 64) -> 53.7, 16: 46.4 -> 57.0
+        # (241 MB of records per step -> 15 MB); 1.5 rounds (2 x 192) is the worst choice: 33.5
+        self.bwd_blocks = int(bwd_blocks) if int(bwd_blocks) > 0 else max(4, 256 // max(n_cls, 1))
         self.bufs = {}
         self.losses = torch.zeros(3, n_cls, device=self.device)
         self.flags = torch.zeros(n_cls, device=self.device, dtype=torch.int32)

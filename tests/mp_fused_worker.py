@@ -22,7 +22,9 @@ def build(cnr, dev, mode, rank, world, pg, C, R, n_obj, L, graph, empty_class=No
             p["rgbs"][:, 3] = 0
         pools.append(p)
     gen = torch.Generator().manual_seed(42)             # same parameters on every rank
-    kw = dict(seed=3, generator=gen, use_graph=graph)
+    # (the workgroup count per class is fixed here: its default follows the number of classes ON THE GPU -- 256 / C, for speed -- and
+    #  the per-workgroup records are summed in order, so runs agree bit for bit when they split a class's rays the same way)
+    kw = dict(seed=3, generator=gen, use_graph=graph, bwd_blocks=32)
     if world == 1:
         return cnr.fused.FusedCategoryTrainer(cfg, C, n_obj, pools, Rg, dev, **kw)
     if mode == "class":
