@@ -96,28 +96,57 @@ __device__ __forceinline__ void latent_bwd_block(const float* __restrict__ th, c
   float* dpre = sm;
   float* inv_s = sm + n_obj * 128;
   float* inv_t = inv_s + n_obj;
-  for (int i = threadIdx.x; i < n_obj * 128; i += 256) {   // d z -> d pre
-    const int ob = i >> 7, k = (i >> 5) & 3, j = i & 31;
-    int w_off, b_off, ld;
-    latent_target(k, w_off, b_off, ld);
-    float s = 0.0f;
+  // (two entries / four code rows at a time with all their loads in flight: a class of 5-15 objects walks these loops several
+  //  times, and one memory round trip per pass was 8 us of the tail launch at seven objects; same arithmetic, same order)
+  for (int i0 = threadIdx.x; i0 < n_obj * 128; i0 += 2 * 256) {   // d z -> d pre
+    float wv_[2][32], zv[2];
 #pragma unroll
-    for (int o = 0; o < 32; ++o) s = fmaf(dbr[(ob * 4 + k) * 32 + o], th[w_off + o * ld + j], s);
-    dpre[i] = z[i] > 0.0f ? s : 0.0f;
+    for (int u = 0; u < 2; ++u) {
+      const int i = i0 + 256 * u < n_obj * 128 ? i0 + 256 * u : i0;
+      const int k = (i >> 5) & 3, j = i & 31;
+      int w_off, b_off, ld;
+      latent_target(k, w_off, b_off, ld);
+#pragma unroll
+      for (int o = 0; o < 32; ++o) wv_[u][o] = th[w_off + o * ld + j];
+      zv[u] = z[i];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int i = i0 + 256 * u;
+      if (i < n_obj * 128) {
+        const int ob = i >> 7, k = (i >> 5) & 3;
+        float s = 0.0f;
+#pragma unroll
+        for (int o = 0; o < 32; ++o) s = fmaf(dbr[(ob * 4 + k) * 32 + o], wv_[u][o], s);
+        dpre[i] = zv[u] > 0.0f ? s : 0.0f;
+      }
+    }
   }
   {  // code norms for the regulariser: one wave per code row
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int t = wv; t < 2 * n_obj; t += 4) {
-      const int ob = t % n_obj;
-      const float* code = th + (t < n_obj ? lay.shape : lay.tex) + (int64_t)ob * L;
-      float s = 0.0f, cv[4];
+    for (int t0 = wv; t0 < 2 * n_obj; t0 += 16) {
+      float cv[4][4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { const int l = lane + 64 * j; cv[j] = l < L ? code[l] : 0.0f; }   // loads in flight together
+      for (int u = 0; u < 4; ++u) {
+        const int t = t0 + 4 * u < 2 * n_obj ? t0 + 4 * u : t0;
+        const float* code = th + (t < n_obj ? lay.shape : lay.tex) + (int64_t)(t % n_obj) * L;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) s = fmaf(cv[j], cv[j], s);
-      for (int l = lane + 256; l < L; l += 64) s = fmaf(code[l], code[l], s);
-      s = wave_sum(s);
-      if (lane == 0) (t < n_obj ? inv_s : inv_t)[ob] = ob < n_real ? reg_scale / sqrtf(s) : 0.0f;
+        for (int j = 0; j < 4; ++j) { const int l = lane + 64 * j; cv[u][j] = l < L ? code[l] : 0.0f; }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = t0 + 4 * u;
+        if (t < 2 * n_obj) {     // (wave-uniform)
+          const int ob = t % n_obj;
+          const float* code = th + (t < n_obj ? lay.shape : lay.tex) + (int64_t)ob * L;
+          float s = 0.0f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) s = fmaf(cv[u][j], cv[u][j], s);
+          for (int l = lane + 256; l < L; l += 64) s = fmaf(code[l], code[l], s);
+          s = wave_sum(s);
+          if (lane == 0) (t < n_obj ? inv_s : inv_t)[ob] = ob < n_real ? reg_scale / sqrtf(s) : 0.0f;
+        }
+      }
     }
   }
   __syncthreads();
@@ -157,14 +186,26 @@ __device__ __forceinline__ void latent_bwd_block(const float* __restrict__ th, c
       const int i = t - n2, ob = i / L, l = i % L;
       sink.prefetch(lay.shape + i);
       float s = 0.0f;
-      for (int ko = 0; ko < 96; ++ko) s = fmaf(dpre[ob * 128 + ko], th[lay.latW + (int64_t)ko * L + l], s);
-      sink.latent_set(lay.shape + i, s + inv_s[ob] * th[lay.shape + i]);
+      const float own = th[lay.shape + i];
+#pragma unroll
+      for (int k0 = 0; k0 < 96; k0 += 32) {   // 32 weight loads in flight at a time (same additions, same order)
+        float w[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) w[u] = th[lay.latW + (int64_t)(k0 + u) * L + l];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) s = fmaf(dpre[ob * 128 + k0 + u], w[u], s);
+      }
+      sink.latent_set(lay.shape + i, s + inv_s[ob] * own);
     } else {
       const int i = t - n3, ob = i / L, l = i % L;
       sink.prefetch(lay.tex + i);
-      float s = 0.0f;
-      for (int o = 0; o < 32; ++o) s = fmaf(dpre[ob * 128 + 96 + o], th[lay.latW + (int64_t)(96 + o) * L + l], s);
-      sink.latent_set(lay.tex + i, s + inv_t[ob] * th[lay.tex + i]);
+      float s = 0.0f, w[32];
+      const float own = th[lay.tex + i];
+#pragma unroll
+      for (int o = 0; o < 32; ++o) w[o] = th[lay.latW + (int64_t)(96 + o) * L + l];
+#pragma unroll
+      for (int o = 0; o < 32; ++o) s = fmaf(dpre[ob * 128 + 96 + o], w[o], s);
+      sink.latent_set(lay.tex + i, s + inv_t[ob] * own);
     }
   }
 }

@@ -84,11 +84,24 @@ struct AdamSink {  // latent-path gradient element -> gradient buffer (kept for 
 // this class's (n_obj,4,32) bias-row gradient as floats in LDS, from the fixed-point table
 __device__ __forceinline__ void load_rows_fix(const TailArgs& a, int c, float* dst) {
   const int n = a.lay.n_obj * 128;
-  for (int i = threadIdx.x; i < n; i += 256) {
-    long long t = 0;
+  // four entries per thread at a time, all 32 table loads in flight together (one entry at a time was one memory round trip
+  // per 256 entries: four trips for a class of seven objects)
+  for (int i0 = threadIdx.x; i0 < n; i0 += 4 * 256) {
+    long long f[4][cnr_rec::ROWS_FIX_COPIES];
 #pragma unroll
-    for (int k = 0; k < cnr_rec::ROWS_FIX_COPIES; ++k) t += a.rows_fix[((size_t)k * a.C + c) * n + i];
-    dst[i] = (float)((double)t * (1.0 / cnr_rec::ROWS_FIX_SCALE));
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + 256 * u;
+#pragma unroll
+      for (int k = 0; k < cnr_rec::ROWS_FIX_COPIES; ++k) f[u][k] = i < n ? a.rows_fix[((size_t)k * a.C + c) * n + i] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + 256 * u;
+      long long t = 0;
+#pragma unroll
+      for (int k = 0; k < cnr_rec::ROWS_FIX_COPIES; ++k) t += f[u][k];
+      if (i < n) dst[i] = (float)((double)t * (1.0 / cnr_rec::ROWS_FIX_SCALE));
+    }
   }
   __syncthreads();
 }
@@ -149,6 +162,7 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
     }
     latent_bwd_block(a.theta_in + (int64_t)c * P, a.lay, a.zl + (int64_t)c * a.lay.n_obj * 128, dbr, reg_c,
                      scratch, sink, blk, a.NL, false, n_real);
+    TAIL_T1(0);
     return;
   }
   b -= nlat;

@@ -8,7 +8,7 @@ import cnr_amd
 from cnr_amd import _C
 _C.LIB_PATH = os.path.join(ROOT, "tools/exp/libs/libcnr_stamps.so")
 dev = torch.device("cuda:0")
-C, R, S, L, n_obj = 1, 2048, 64, 256, 4
+C, R, S, L, n_obj = 1, 2048, 64, 256, int(sys.argv[1]) if len(sys.argv) > 1 else 4
 cfg = cnr_amd.cfg.synthetic_config(device=str(dev), latent_dim=L, obj_scale=2.0, n_bins_cam2surface=S // 8, n_bins=S - S // 8)
 gen = torch.Generator().manual_seed(1234)
 pools = [cnr_amd.scene_cateogries.synthetic_pool(64 * R, n_obj, torch.Generator().manual_seed(5), "cpu") for _ in range(C)]
@@ -31,9 +31,4 @@ for it in range(6):
     lib.cnr_prep_stamps(pb, 0)
     t0 = pb[8]
     print("       prologue:", " | ".join(f"{n}: {(pb[2*i]-t0)/100:.2f} .. {(pb[2*i+1]-t0)/100:.2f} us" for i, n in enumerate(("pack", "latent fwd", "zero fill", "sample rays"))))
-    fb = (ctypes.c_ulonglong * 8)()
-    lib.cnr_fwd_render_stamps.argtypes = [ctypes.c_void_p]
-    lib.cnr_fwd_render_stamps(fb)
-    f = list(fb)
-    print("       fwd_render block 0 wave 0 (cycles): weights copy issued", f[1] - f[0], "| mask counts + barrier", f[2] - f[1],
-          "| tile 0 forward + composite", f[3] - f[2], "| tile 1", f[4] - f[3], "| losses + composite backward + stores", f[7] - f[4])
+
