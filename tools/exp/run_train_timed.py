@@ -15,8 +15,9 @@ one = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 dev = torch.device("cuda:0")
 cfg = cnr_amd.cfg.synthetic_config(device=str(dev), latent_dim=256, n_bins_cam2surface=S // 8, n_bins=S - S // 8)
 gen = torch.Generator().manual_seed(1)
-pools = [cnr_amd.scene_cateogries.synthetic_pool(8 * R, 4, gen, "cpu")]
-tr = cnr_amd.fused.FusedCategoryTrainer(cfg, 1, 4, pools, R, dev, seed=1, generator=gen, use_graph=False, one_launch=bool(one))
+NOBJ = int(sys.argv[4]) if len(sys.argv) > 4 else 4
+pools = [cnr_amd.scene_cateogries.synthetic_pool(8 * R, NOBJ, gen, "cpu")]
+tr = cnr_amd.fused.FusedCategoryTrainer(cfg, 1, NOBJ, pools, R, dev, seed=1, generator=gen, use_graph=False, one_launch=bool(one))
 for _ in range(4):
     tr.step()
 torch.cuda.synchronize()
