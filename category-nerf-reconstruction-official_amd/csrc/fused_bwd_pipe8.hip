@@ -83,8 +83,9 @@ template <> __host__ __device__ constexpr int local8<4>(int kind) {
        : kind == BK_S1 ? 0 : kind == BK_CAT_E1 ? 1 : 2 /* BK_CAT_E2 */;
 }
 
-// WIDE: more than four object rows per class: the row stride of the row-sum block is then a run-time value; with <= 4
-// rows it is the constant 4 and the index arithmetic folds (1 us of the kernel at 2048 x 64).  WIDE = 1: up to 7 rows,
+// WIDE: more than four object rows per class.  The row stride of the row-sum block is a constant of the instantiation -- 4, 7
+// or 15, the most rows it takes; a class with fewer leaves rows unused -- so that the index arithmetic folds (as a run-time
+// value it cost 2.4 us of the kernel at 2048 x 64).  WIDE = 1: up to 7 rows,
 // one row-sum block [4 latent slots x rows | 2 plain biases] (4 * 7 + 2 <= 32 block rows).  WIDE = 2: up to ROWS_MAX =
 // 15 rows, two blocks: A = [slots 0, 1 x rows | 2 plain biases], B = [slots 2, 3 x rows]; a layer step feeds one of them.
 template <int NCH, int NDW, int WIDE, int KR, bool TWO, bool PAD>
@@ -324,10 +325,10 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
       if (any_iter) P8SYNC();   // the previous iteration's last barrier: the dW waves are done with this wave's images
       {
         const int rl = row - c * rows_per_class;
-        const int rs = WIDE ? rows_per_class : 4;  // rows per latent slot in the row-sum block; the ones row follows
+        constexpr int rs = RS_ROWS;  // rows per latent slot in the row-sum block (4 / 7 / 15 by WIDE); the ones row follows
 #pragma unroll
         for (int r = 0; r < RS_ROWS; r += 2)  // lane half h writes rows h, h + 2, ...
-          if (!WIDE || r + h < rs) rowoh[(r + h) * 32 + col] = rl == r + h ? (_Float16)1 : (_Float16)0;
+          if (r + h < rs) rowoh[(r + h) * 32 + col] = rl == r + h ? (_Float16)1 : (_Float16)0;
         if (h == 0) rowoh[rs * 32 + col] = (_Float16)1;
       }
       {
@@ -690,7 +691,7 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
     copy_operands();
     // row m of the row-sum block: m = rs * latent slot + object row for the four latent layers, then one
     // "ones" row each for the two plain biases (encoding_shape: group 4, rgb.0: group 5)
-    const int rs = WIDE ? rows_per_class : 4;  // rows per latent slot (a constant unless WIDE)
+    constexpr int rs = RS_ROWS;  // rows per latent slot: a compile-time constant of the instantiation (a run-time stride cost 2.4 us)
     // (WIDE = 2: block A holds slots 0, 1 and the two bias rows, block B slots 2, 3)
     const int nlat_rows = (WIDE == 2 ? 2 : 4) * rs;
     const int rpc_inv = (65536 + rs - 1) / rs;  // m / rs = (m * rpc_inv) >> 16 for m < 32
