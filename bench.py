@@ -197,6 +197,70 @@ def fp8_leg(args):
                               "fragment where the f16 kernel needs one of the same rate"}))
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` outside a launcher: start N ranks of this script as a FRESH child process tree
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>`), pass rank 0's JSON
+    line through and exit with the children's code.  The parent has made no HIP call (it never replaces itself either: the
+    children are ordinary subprocesses), so an N-rank line or a failure are the only outcomes -- never a 1-rank line
+    that says N."""
+    import socket
+    import subprocess
+    if not os.environ.get("CNR_SINGLE_DEVICE_REHEARSAL") and os.environ.get("CNR_DIST_BACKEND", "nccl") == "nccl":
+        have = torch.cuda.device_count()                 # counts devices without initialising one
+        if have < n:
+            raise SystemExit(f"bench.py --gpus {n}: this node shows {have} GPU(s)")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"n_gpus"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0:
+        raise SystemExit(f"bench.py --gpus {n}: the {n}-rank launch failed (exit code {proc.returncode})")
+    if line is None or json.loads(line).get("n_gpus") != n:
+        raise SystemExit(f"bench.py --gpus {n}: the ranks produced no {n}-GPU result line")
+    print(line)
+    return 0
+
+
+def launch_check(args, rank, local_rank, world, backend):
+    """--launch-check: the process-group side of the bench alone.  Every rank joins the group (RCCL when the backend is
+    nccl, each rank on its own GPU), a one is all-reduced, and rank 0 prints what the BACKEND says the world is."""
+    got, name = 1, None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dev = torch.device("cuda", local_rank)
+            torch.distributed.init_process_group("nccl", device_id=dev)
+        else:
+            dev = torch.device("cpu")
+            torch.distributed.init_process_group(backend)
+        one = torch.ones(1, device=dev)
+        torch.distributed.all_reduce(one)
+        got, name = int(one.item()), torch.distributed.get_backend()
+        assert got == torch.distributed.get_world_size()
+        torch.distributed.barrier()
+    if got != args.gpus:
+        raise SystemExit(f"launch check: {got} ranks answered, --gpus says {args.gpus}")
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": got, "backend": name, "value": None,
+                          "metric": "launcher check only -- no kernel ran, not a benchmark result"}))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -219,13 +283,28 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--launch-check", action="store_true",
+                    help="bring the ranks up, all-reduce a one over the process group and print the world size the "
+                         "backend reports -- no kernel runs (a check of the launcher, not a benchmark)")
     args = ap.parse_args()
 
     if args.dtype == "fp8":
         return fp8_leg(args)
+    # ---- N ranks: --gpus N is what decides; the launcher's environment must agree ---------------------------------
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:                      # not under a launcher yet: become one (nothing has touched the GPU)
+            return launch_ranks(args.gpus, sys.argv[1:])
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={os.environ['WORLD_SIZE']}: "
+                         "the two must agree (the line would claim a GPU count that did not run)")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    backend = os.environ.get("CNR_DIST_BACKEND", "nccl") if world > 1 else None   # nccl = RCCL over xGMI; gloo only for rehearsals
+    if args.launch_check:
+        return launch_check(args, rank, local_rank, world, backend)
     if os.environ.get("CNR_SINGLE_DEVICE_REHEARSAL"):           # N ranks on one card (gloo), 1-GPU boxes only
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -233,12 +312,13 @@ def main():
     pg = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("CNR_DIST_BACKEND", "nccl")     # nccl = RCCL over xGMI; gloo only for rehearsals
         if backend == "nccl":
             torch.distributed.init_process_group("nccl", device_id=dev)
         else:
             torch.distributed.init_process_group(backend)
         pg = torch.distributed.group.WORLD
+        if torch.distributed.get_world_size() != args.gpus:
+            raise SystemExit(f"process group has {torch.distributed.get_world_size()} ranks, --gpus says {args.gpus}")
 
     dbg = (lambda *a: print(f"[bench rank {rank}]", *a, file=sys.stderr, flush=True)) if os.environ.get("CNR_BENCH_DEBUG") \
         else (lambda *a: None)
@@ -372,6 +452,11 @@ def main():
                                   f"synthetic pool, random init",
                       "rays_per_step_global": rays_per_step_global, "rays_per_gpu": C * R, "samples_per_ray": S,
                       "parallelism": par, "shard": shard,
+                      "world_size": torch.distributed.get_world_size() if world > 1 else 1,
+                      "dist_backend": torch.distributed.get_backend() if world > 1 else None,
+                      "operand_dtype": "f16 MFMA operands, fp32 accumulate, where BASELINE.json configs[1] says bf16: bf16 operands "
+                                       "miss north_star's 1e-3 parity bar (3.9e-3 / 5.1e-3, BASELINE.md section 4), f16 has the "
+                                       "same MFMA rate on gfx950 and three more mantissa bits",
                       "hipgraph": (f"{tr.unroll} steps per graph launch (one step per launch at epoch ends)" if not tr.grad_exchange else "two graphs around the all-reduce, per state parity") if not args.no_graph else False,
                       "n_cu": info["n_cu"]},
            "long_run": long_run, "roofline": roofline}
@@ -436,4 +521,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)
