@@ -48,15 +48,12 @@ SIGNATURES = {
     "cnr_dense_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "cnr_dense_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i64, _i, _f, _vp],
     "cnr_dense_bwd_workspace_bytes": [_i, _i, _i],
-    "cnr_step_prologue": [_vp, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _i64,
-                          _vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64, _vp, _i64, _vp, _i, _i, _i, _i, _f, _f, _f,
-                          _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "cnr_step_prologue": [_vp, _vp],          # (const cnr_step_prologue_args*, stream): STRUCTS below
     "cnr_slice_maskcounts": [_vp, _vp, _vp, _i64, _i, _i, _i, _f, _vp, _vp],
     "cnr_slice_maxdepth": [_vp, _vp, _i64, _i, _i, _i, _vp, _vp],
     "cnr_adamw_epilogue": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64,
                            _vp, _vp, _i, _i, _vp],
-    "cnr_step_tail": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _vp, _vp, _f, _i, _f, _f, _f,
-                      _f, _f, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _f, _f, _vp],
+    "cnr_step_tail": [_vp, _vp],
     "cnr_step_grad": [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _vp, _vp, _f, _vp, _i, _vp, _vp, _vp],
     "cnr_field_fwd_render_blocks": [_i, _i],
     "cnr_field_fwd_render_workspace_bytes": [_i, _i, _i],
@@ -67,8 +64,7 @@ SIGNATURES = {
     "cnr_field_fwd_fp8": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i64, _i, _vp],
     "cnr_field_train_blocks": [_i, _i, _i],
     "cnr_field_train_workspace_bytes": [_i, _i, _i, _i],
-    "cnr_field_train": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _vp, _vp, _vp, _vp,
-                        _i, _i, _i, _i, _i, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp],
+    "cnr_field_train": [_vp, _vp],
     "cnr_param_prep": [_vp, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp],
     "cnr_render_loss_workspace_bytes": [_i, _i],
     "cnr_render_loss": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp,
@@ -76,6 +72,48 @@ SIGNATURES = {
     "cnr_render_loss_finish": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "cnr_step_epilogue": [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i, _i, _vp],
 }
+# The three launches of the fused trainer's step take ONE versioned struct (include/cnr_hip.h: struct_size and abi_version
+# first, then these fields in this order).  call_struct() wants every field by NAME: a missing, misspelt or surplus argument
+# raises here instead of shifting 40 positional values by one.
+ABI_VERSION = 3
+_u32, _i32 = ctypes.c_uint32, ctypes.c_int32
+STRUCTS = {
+    "cnr_step_prologue": [
+        ("theta", _vp), ("class_stride", _i64), ("off_trunk", _i64), ("off_latW", _i64), ("off_latb", _i64), ("off_shape", _i64),
+        ("off_tex", _i64), ("L", _i32), ("n_obj", _i32), ("C", _i32), ("packed", _vp), ("packed_lo", _vp), ("zl", _vp),
+        ("biasrows", _vp), ("zero_buf", _vp), ("zero_count", _i64), ("rgbs", _vp), ("depth", _vp), ("dirs_c", _vp), ("T", _vp),
+        ("u", _vp), ("g", _vp), ("seed", _u64), ("offset", _u64), ("d_state", _vp), ("pool_rows", _i64), ("max_bound", _vp),
+        ("world_frame", _i32), ("R", _i32), ("n1", _i32), ("n2", _i32), ("eps", _f), ("stop_eps", _f), ("min_bound", _f),
+        ("z", _vp), ("pts", _vp), ("origins", _vp), ("dirs_o", _vp), ("gt_rgb", _vp), ("gt_depth", _vp), ("depth_mask", _vp),
+        ("labels", _vp), ("pool_indices", _vp), ("ray_row", _vp), ("perm", _vp), ("max_bound_slices", _i32), ("rng_c0", _i32),
+        ("rng_cstride", _i32), ("rng_R", _i32), ("rng_r0", _i32)],
+    "cnr_step_tail": [
+        ("theta_in", _vp), ("theta_out", _vp), ("grad", _vp), ("exp_avg", _vp), ("exp_avg_sq", _vp), ("class_stride", _i64),
+        ("off_B", _i64), ("off_latW", _i64), ("off_latb", _i64), ("off_shape", _i64), ("off_tex", _i64), ("L", _i32),
+        ("n_obj", _i32), ("C", _i32), ("zl", _vp), ("dbiasrows", _vp), ("reg_scale", _f), ("do_latent", _i32), ("lr", _f),
+        ("beta1", _f), ("beta2", _f), ("eps", _f), ("weight_decay", _f), ("state_cur", _vp), ("state_next", _vp),
+        ("add_rows", _i64), ("rl_workspace", _vp), ("losses", _vp), ("flags", _vp), ("depth", _vp), ("pool_rows", _i64),
+        ("perm", _vp), ("next_max_bound", _vp), ("R", _i32), ("records", _vp), ("nwg", _i32), ("rows_fix", _vp),
+        ("rl_blocks", _i32), ("clamp_flags", _vp), ("n_obj_cls", _vp), ("code_lr", _f), ("code_weight_decay", _f)],
+    "cnr_field_train": [
+        ("pts", _vp), ("B", _vp), ("packed", _vp), ("packed_lo", _vp), ("biasrows", _vp), ("ray_row", _vp), ("scale", _f),
+        ("z", _vp), ("gt_depth", _vp), ("gt_rgb", _vp), ("labels", _vp), ("depth_mask", _vp), ("counts_tab", _vp),
+        ("d_state", _vp), ("color_scaling", _f), ("opacity_scaling", _f), ("loss_scale", _f), ("grad_scale", _f),
+        ("depth", _vp), ("var", _vp), ("rgb", _vp), ("opacity", _vp), ("C", _i32), ("R", _i32), ("S", _i32),
+        ("rows_per_class", _i32), ("max_blocks", _i32), ("records", _vp), ("records_bytes", _i64), ("loss_workspace", _vp),
+        ("loss_workspace_bytes", _i64), ("B_stride", _i64), ("rows_fix", _vp), ("clamp_flags", _vp)],
+}
+_struct_types = {}
+
+
+def struct_type(name):
+    """ctypes.Structure of entry point `name`'s argument block (natural C alignment, like the header's typedef)."""
+    if name not in _struct_types:
+        fields = [("struct_size", _u32), ("abi_version", _u32)] + STRUCTS[name]
+        _struct_types[name] = type(name + "_args", (ctypes.Structure,), {"_fields_": fields})
+    return _struct_types[name]
+
+
 _RESTYPE64 = {"cnr_pack_bytes", "cnr_pack_lo_bytes", "cnr_field_bwd_workspace_bytes", "cnr_render_loss_workspace_bytes",
               "cnr_dense_bwd_workspace_bytes", "cnr_field_fwd_render_workspace_bytes", "cnr_field_train_workspace_bytes", "cnr_pack_fp8_bytes"}
 
@@ -141,13 +179,46 @@ def call(name, *args):
             conv.append(_ptr(a))
         else:
             conv.append(a)
-    # trailing arguments a caller leaves out are the optional ones the C-ABI grew over time: NULL / 0
+    # every parameter of the header's prototype, in order (optional pointers as an explicit None): a short or long argument
+    # list is a caller bug, never padded
+    if name in STRUCTS:
+        raise CnrError(f"{name} takes a versioned argument block: use call_struct({name!r}, field=value, ...)")
     types = SIGNATURES[name][:-1]
-    if len(conv) > len(types):
-        raise CnrError(f"{name}: {len(conv)} arguments for {len(types)} parameters")
-    for t in types[len(conv):]:
-        conv.append(None if t is _vp else 0)
+    if len(conv) != len(types):
+        raise CnrError(f"{name}: {len(conv)} arguments for {len(types)} parameters (include/cnr_hip.h)")
     rc = getattr(lib, name)(*conv, _stream())
+    if rc != 0:
+        raise CnrError(f"{name} failed with code {rc}" + (" (argument error)" if rc < 0 else " (hipError_t)"))
+
+
+def call_struct(name, **fields):
+    """Entry points with a versioned argument block: every field of STRUCTS[name] by keyword (tensors as device pointers,
+    None = NULL).  Unknown or missing names raise."""
+    spec = STRUCTS[name]
+    names = [n for n, _ in spec]
+    missing, unknown = [n for n in names if n not in fields], [n for n in fields if n not in names]
+    if missing or unknown:
+        raise CnrError(f"{name}: missing fields {missing}, unknown fields {unknown}")
+    if _double is not None:
+        rc = getattr(_double, name)(**fields)
+        if rc:
+            raise CnrError(f"{name} (test double) returned {rc}")
+        return
+    lib = load()
+    st = struct_type(name)()
+    st.struct_size, st.abi_version = ctypes.sizeof(st), ABI_VERSION
+    for n, t in spec:
+        v = fields[n]
+        if t is _vp:
+            v = _ptr(v) if torch.is_tensor(v) else v
+            if v is not None and not isinstance(v, int):
+                raise CnrError(f"{name}.{n}: expected a device tensor or None, got {type(fields[n]).__name__}")
+        elif torch.is_tensor(v) or v is None:
+            raise CnrError(f"{name}.{n}: expected a number, got {type(v).__name__}")
+        elif t is not _f:
+            v = int(v)
+        setattr(st, n, v)
+    rc = getattr(lib, name)(ctypes.byref(st), _stream())
     if rc != 0:
         raise CnrError(f"{name} failed with code {rc}" + (" (argument error)" if rc < 0 else " (hipError_t)"))
 
@@ -195,15 +266,20 @@ def kernel_timings_ms():
     return out
 
 
-_raw_call = call
+_raw_call, _raw_call_struct = call, call_struct
 
 
-def call(name, *args):  # noqa: F811
-    if _timing is not None and name in _timing:
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        _raw_call(name, *args)
-        b.record()
-        _timing[name].append((a, b))
-    else:
-        _raw_call(name, *args)
+def _timed(raw):
+    def wrapped(name, *args, **kw):
+        if _timing is not None and name in _timing:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            raw(name, *args, **kw)
+            b.record()
+            _timing[name].append((a, b))
+        else:
+            raw(name, *args, **kw)
+    return wrapped
+
+
+call, call_struct = _timed(_raw_call), _timed(_raw_call_struct)  # noqa: F811

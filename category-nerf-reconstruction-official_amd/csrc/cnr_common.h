@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 #include "../../include/cnr_hip.h"
 
@@ -10,6 +11,31 @@
     hipError_t _e = hipGetLastError();                       \
     if (_e != hipSuccess) return (int)_e;                    \
   } while (0)
+
+namespace cnr {
+// A kernel that needs more than 64 KB of dynamic LDS must be told so once per DEVICE (hipFuncSetAttribute is per function and
+// device).  One bit per device ordinal and kernel instantiation, set after the first successful call: idempotent, safe from
+// several host threads, and a process that drives several GPUs gets the attribute on each of them.
+struct DeviceOnce { std::atomic<uint64_t> mask{0}; };
+inline int set_max_dynamic_lds(DeviceOnce& once, const void* fn, int bytes) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  const uint64_t bit = 1ull << (dev & 63);
+  if (dev < 64 && (once.mask.load(std::memory_order_acquire) & bit)) return 0;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return (int)e;
+  if (dev < 64) once.mask.fetch_or(bit, std::memory_order_release);
+  return 0;
+}
+// true exactly once per device (for one-time device-side tables in static device storage)
+inline bool first_on_device(DeviceOnce& once) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev >= 64) return true;
+  const uint64_t bit = 1ull << dev;
+  return (once.mask.fetch_or(bit, std::memory_order_acq_rel) & bit) == 0;
+}
+}  // namespace cnr
 
 // fp32 trunk blob offsets (floats) -- see CNR_TRUNK_PARAMS in cnr_hip.h
 namespace cnr {

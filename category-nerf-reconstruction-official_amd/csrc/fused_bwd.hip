@@ -552,18 +552,18 @@ extern "C" int cnr_field_bwd(const float* pts, const float* B, const void* packe
   if (blocks > cap) blocks = cap;
   const int64_t need = (int64_t)C * blocks * REC_FLOATS * (int64_t)sizeof(float);
   if (workspace_bytes < need) return CNR_E_ARG;
-  static bool attr_set = false;
-  if (!attr_set) {
+  {  // once per device: the LDS attribute of the four instantiations and the constant table (static device storage)
+    static cnr::DeviceOnce once[4], table;
     const void* fns[4] = {(const void*)field_bwd_kernel<true, 0>, (const void*)field_bwd_kernel<true, 1>,
                           (const void*)field_bwd_kernel<false, 0>, (const void*)field_bwd_kernel<false, 1>};
-    for (const void* f : fns) {
-      hipError_t er = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
-      if (er != hipSuccess) return (int)er;
+    for (int i = 0; i < 4; ++i) {
+      const int er = cnr::set_max_dynamic_lds(once[i], fns[i], LDS_TOTAL);
+      if (er) return er;
     }
-    // one-time constant table in static device storage (no allocation); stream-ordered before the first use
-    hipLaunchKernelGGL(build_param_src_kernel, dim3(16), dim3(256), 0, (hipStream_t)stream);
-    hipLaunchKernelGGL(fill_param_src_kernel, dim3(16), dim3(256), 0, (hipStream_t)stream);
-    attr_set = true;
+    if (cnr::first_on_device(table)) {   // stream-ordered before the first use
+      hipLaunchKernelGGL(build_param_src_kernel, dim3(16), dim3(256), 0, (hipStream_t)stream);
+      hipLaunchKernelGGL(fill_param_src_kernel, dim3(16), dim3(256), 0, (hipStream_t)stream);
+    }
   }
   dim3 grid((unsigned)blocks, (unsigned)C);
 #define CNR_LAUNCH_BWD(BIG, PART)                                                                               \

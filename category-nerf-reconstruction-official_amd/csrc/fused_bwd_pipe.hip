@@ -664,18 +664,16 @@ extern "C" int cnr_field_bwd_pipe(const float* pts, const float* B, const void* 
     CNR_LAUNCH_CHECK();
     return CNR_OK;
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t er;
-#define CNR_ATTR(NCH)                                                                                \
-  er = hipFuncSetAttribute((const void*)field_bwd_pipe_kernel<NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                           p_lds_total<NCH>());                                                      \
-  if (er != hipSuccess) return (int)er;
-    CNR_ATTR(3) CNR_ATTR(2)
-#undef CNR_ATTR
-    hipLaunchKernelGGL(build_param_src_kernel, dim3(16), dim3(256), 0, (hipStream_t)stream);
-    hipLaunchKernelGGL(fill_param_src_kernel, dim3(16), dim3(256), 0, (hipStream_t)stream);
-    attr_set = true;
+  {  // once per device: the LDS attribute of both instantiations and the constant table (static device storage)
+    static cnr::DeviceOnce once3, once2, table;
+    int er = cnr::set_max_dynamic_lds(once3, (const void*)field_bwd_pipe_kernel<3>, p_lds_total<3>());
+    if (er) return er;
+    er = cnr::set_max_dynamic_lds(once2, (const void*)field_bwd_pipe_kernel<2>, p_lds_total<2>());
+    if (er) return er;
+    if (cnr::first_on_device(table)) {
+      hipLaunchKernelGGL(build_param_src_kernel, dim3(16), dim3(256), 0, (hipStream_t)stream);
+      hipLaunchKernelGGL(fill_param_src_kernel, dim3(16), dim3(256), 0, (hipStream_t)stream);
+    }
   }
   dim3 grid((unsigned)blocks, (unsigned)C);
 #define CNR_LAUNCH_PIPE(NCH)                                                                                  \

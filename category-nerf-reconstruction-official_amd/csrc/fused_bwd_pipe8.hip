@@ -43,16 +43,28 @@ __device__ long long g_pipe8_stamps[8 * 64];
 #define P8ITER_DECL() do {} while (0)
 #endif
 #define P8SYNC() do { P8STAMP(); role_barrier(); P8STAMP(); } while (0)
-constexpr int K8_SMALL_BYTES = (cnr_rec::ROWS_MAX + 1) * 64;  // row one-hot table: ROWS_MAX rows + the ones row, 32 halfs each
-constexpr int C8_BYTES = E1IMG_BYTES + E2IMG_BYTES + 4 * HSIMG_BYTES + K8_SMALL_BYTES;  // LDS per chain wave
-constexpr int L8_BL = PK_BYTES, L8_BR = L8_BL + 272, L8_CHAIN = L8_BR + cnr_rec::ROWS_MAX * 128 * 4;
-constexpr int RS8_REGION = NBLOCKS;
+// LDS layout of the 8-wave kernel, by instantiation (WIDE = which row-sum form, GEO = precise geometry branch):
+//   [ packed image PK_BYTES | GEO: residual fragments PK_LO_BYTES | B rows 272 | bias rows of the class | 4 chain waves | exchange ]
+// A class's bias rows (512 B per object row) sit in LDS except in the one instantiation where the budget is spent
+// (GEO with up to 15 rows: they are read from global there, ~1 k cycles per layer of the forward).
+__host__ __device__ constexpr int rs_rows8(int wide) { return wide == 2 ? cnr_rec::ROWS_MAX : wide == 1 ? 7 : 4; }
+__host__ __device__ constexpr bool brows_in_lds8(int wide, bool geo) { return !(geo && wide == 2); }
+// row one-hot table per chain wave: rows + the ones row, 32 halfs each; the flush reuses it for 127 floats of partial sums
+__host__ __device__ constexpr int k8_small(int wide) { return (rs_rows8(wide) + 1) * 64 > 512 ? (rs_rows8(wide) + 1) * 64 : 512; }
+// PE images without the trailing pads of the 4-wave kernels: an E2 read of the (discarded) slot columns 48..63 of row 31
+// runs 16 B past the image -- into this wave's dPre slot, which follows it
+constexpr int E1IMG8 = 32 * ST_E1, E2IMG8 = 32 * ST_E2;
+__host__ __device__ constexpr int c8_bytes(int wide) { return E1IMG8 + E2IMG8 + 4 * HSIMG_BYTES + k8_small(wide); }
+__host__ __device__ constexpr int l8_lo() { return PK_BYTES; }
+__host__ __device__ constexpr int l8_bl(bool geo) { return PK_BYTES + (geo ? PK_LO_BYTES : 0); }
+__host__ __device__ constexpr int l8_br(bool geo) { return l8_bl(geo) + 272; }
+__host__ __device__ constexpr int l8_chain(int wide, bool geo) {
+  return l8_br(geo) + (brows_in_lds8(wide, geo) ? rs_rows8(wide) * 128 * 4 : 0);
+}
 constexpr int BK_RS = 100, BK_RS2 = 101;  // pseudo kinds of the row-sum blocks in the ownership tables
 constexpr int XCH_BYTES = 2 * 4 * 8 * 4;  // one-launch step: four chain waves x eight floats, two copies (iteration parity)
-__host__ __device__ constexpr int l8_xch(int nch) { return L8_CHAIN + nch * C8_BYTES; }
-__host__ __device__ constexpr int l8_total(int nch) {
-  return l8_xch(nch) + XCH_BYTES > (RS8_REGION + 1) * 4096 ? l8_xch(nch) + XCH_BYTES : (RS8_REGION + 1) * 4096;
-}
+__host__ __device__ constexpr int l8_xch(int nch, int wide, bool geo) { return l8_chain(wide, geo) + nch * c8_bytes(wide); }
+__host__ __device__ constexpr int l8_total(int nch, int wide, bool geo) { return l8_xch(nch, wide, geo) + XCH_BYTES; }
 // KR > 0 (cnr_field_train): the render / loss side of the step, so that ONE launch runs field forward -> composite ->
 // losses -> their gradient -> composite backward -> field backward with no second forward and no d sigma / d colour
 // round trip through HBM.  A ray occupies SP = 32 KR padded sample slots (S <= SP; slots >= S are dead lanes): the KR chain
@@ -63,7 +75,8 @@ struct TrainArgs {
   const float* counts_tab; const int64_t* d_state; float color_scaling, opacity_scaling, loss_scale;
   float* depth_out; float* var_out; float* rgb_out; float* opacity_out; float* partials;
 };
-static_assert(l8_total(4) <= 160 * 1024, "LDS budget");
+static_assert(l8_total(4, 0, true) <= 160 * 1024 && l8_total(4, 1, true) <= 160 * 1024 && l8_total(4, 2, true) <= 160 * 1024 &&
+              l8_total(4, 2, false) <= 160 * 1024, "LDS budget");
 
 // Which dW wave owns a block kind, and the block's index among that wave's accumulators: at most 5 accumulators per
 // wave, one unit of work per wave and layer step (cat_layer: dW3 two)
@@ -88,16 +101,22 @@ template <> __host__ __device__ constexpr int local8<4>(int kind) {
 // value it cost 2.4 us of the kernel at 2048 x 64).  WIDE = 1: up to 7 rows,
 // one row-sum block [4 latent slots x rows | 2 plain biases] (4 * 7 + 2 <= 32 block rows).  WIDE = 2: up to ROWS_MAX =
 // 15 rows, two blocks: A = [slots 0, 1 x rows | 2 plain biases], B = [slots 2, 3 x rows]; a layer step feeds one of them.
-template <int NCH, int NDW, int WIDE, int KR, bool TWO, bool PAD>
+// GEO (one-launch form only): the forward's geometry branch as three products per fragment with the residual weight image
+// packed_lo (fused_common.h, NKK_GEO) -- what keeps the occupancy within 1e-3 of fp32 for trained weights.
+template <int NCH, int NDW, int WIDE, int KR, bool TWO, bool PAD, bool GEO>
 __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
     const float* __restrict__ pts, const float* __restrict__ Bdir, const unsigned char* __restrict__ packed,
-    const float* __restrict__ biasrows, const int* __restrict__ ray_row, float inv_scale,
+    const unsigned char* __restrict__ packed_lo, const float* __restrict__ biasrows, const int* __restrict__ ray_row, float inv_scale,
     const float* __restrict__ d_sigma, const float* __restrict__ d_rgb, float gscale, float* __restrict__ records,
     int N, int S, int R, int rows_per_class, int64_t B_stride, long long* __restrict__ rows_fix,
     int* __restrict__ clamp_flags, TrainArgs ta) {
   static_assert(KR == 0 || KR == 1 || KR == 2 || KR == 4, "tiles per ray");
   static_assert(!TWO || KR == 1, "two rays per tile only with one tile per ray");
   static_assert(!TWO || PAD, "16-slot rays are the padded form");   // PAD = false: S == SP exactly (the plain index arithmetic)
+  static_assert(!GEO || KR > 0, "the precise geometry branch belongs to the one-launch form (the forward that is rendered)");
+  constexpr int L8_BL = l8_bl(GEO), L8_BR = l8_br(GEO), L8_CHAIN = l8_chain(WIDE, GEO), C8_BYTES = c8_bytes(WIDE),
+                K8_SMALL_BYTES = k8_small(WIDE);
+  constexpr bool BROWS_LDS = brows_in_lds8(WIDE, GEO);
   constexpr int SP = TWO ? 16 : (KR > 0 ? 32 * KR : 32);   // padded sample slots per ray (one-launch form)
   constexpr int NCHW = NCH, NTHR = (NCH + NDW) * 64, NACC = 5, LI_RS = local8<NDW>(BK_RS), LI_RS2 = local8<NDW>(BK_RS2);
   constexpr int RS_ROWS = WIDE == 2 ? cnr_rec::ROWS_MAX : WIDE == 1 ? 7 : 4;  // most object rows this instance takes
@@ -106,9 +125,9 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
   // The dPre / input images are double-buffered (K_PAR apart): layer step k uses copy k & 1, so the chain wave stages step
   // k + 1 while the dW waves still read step k -- ONE workgroup barrier per layer step ("images of step k are complete";
   // copy (k + 1) & 1 was last read in step k - 1, which the dW waves finished before they arrived at that barrier).
-  constexpr int K_E1 = 0, K_E2 = E1IMG_BYTES, K_D = K_E2 + E2IMG_BYTES, K_X = K_D + HSIMG_BYTES, K_PAR = 2 * HSIMG_BYTES,
+  constexpr int K_E1 = 0, K_E2 = E1IMG8, K_D = K_E2 + E2IMG8, K_X = K_D + HSIMG_BYTES, K_PAR = 2 * HSIMG_BYTES,
                 K_SMALL = K_X + HSIMG_BYTES + K_PAR, K_BYTES = C8_BYTES;
-  static_assert(K_BYTES == K_SMALL + K8_SMALL_BYTES && K8_SMALL_BYTES >= 512, "layout");
+  static_assert(K_BYTES == K_SMALL + K8_SMALL_BYTES && K8_SMALL_BYTES >= 512 && K8_SMALL_BYTES >= (RS_ROWS + 1) * 64, "layout");
   static_assert(NACC >= 4, "the chain role parks its partial sums in accumulators 0..3");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int c = blockIdx.y;
@@ -130,8 +149,15 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
       const int hh = i / 33, k = i % 33, d = k / 3;
       Bl[i] = (hh == 1 && d == 10) ? 0.0f : Bdir[(size_t)c * B_stride + (11 * hh + d) * 3 + (k % 3)];
     }
-    float* br = reinterpret_cast<float*>(smem + L8_BR);  // host guarantees 1 <= rows_per_class <= ROWS_MAX
-    for (int i = threadIdx.x; i < rows_per_class * 128; i += NTHR) br[i] = biasrows[(size_t)c * rows_per_class * 128 + i];
+    if constexpr (GEO) {   // residual fragments of the geometry branch behind the packed image
+      const unsigned char* lsrc = packed_lo + (size_t)c * PK_LO_BYTES;
+      for (int i = threadIdx.x * 16; i < PK_LO_BYTES; i += NTHR * 16)
+        *reinterpret_cast<f4*>(smem + l8_lo() + i) = *reinterpret_cast<const f4*>(lsrc + i);
+    }
+    if constexpr (BROWS_LDS) {
+      float* br = reinterpret_cast<float*>(smem + L8_BR);  // host guarantees 1 <= rows_per_class <= RS_ROWS
+      for (int i = threadIdx.x; i < rows_per_class * 128; i += NTHR) br[i] = biasrows[(size_t)c * rows_per_class * 128 + i];
+    }
     __syncthreads();
     P8PHASE(1);
   };
@@ -255,7 +281,7 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
       wo_c = e_o ? 0.f : 1.0f / (tb[c * 4 + 2] + 1e-10f);
       tab_flags = (e_d ? 2 : 0) | (e_c ? 4 : 0) | (e_o ? 8 : 0);
     }
-    float* xch = reinterpret_cast<float*>(smem + l8_xch(NCH));   // [4][8]
+    float* xch = reinterpret_cast<float*>(smem + l8_xch(NCH, WIDE, GEO));   // [4][8]
     bool any_iter = false;
     for (int tile = blockIdx.x * NCHW + wv, t0 = blockIdx.x * NCHW; t0 < ntiles; t0 += tile_step, tile += tile_step) {
       asm volatile("" ::: "memory");
@@ -278,7 +304,8 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
         draw = scale_dsigma(cur.dsg);
         dr0 = cur.dr0 * gscale; dr1 = cur.dr1 * gscale; dr2 = cur.dr2 * gscale;
       }
-      const float* brow_l = reinterpret_cast<const float*>(smem + L8_BR) + (row - c * rows_per_class) * 128;
+      const float* brow_l = BROWS_LDS ? reinterpret_cast<const float*>(smem + L8_BR) + (row - c * rows_per_class) * 128
+                                      : biasrows + (size_t)row * 128;
 
       auto pe_backward = [&](const f16v (&de)[3], int nblk, int band0, int nq) {
         float pd[11], gpa[11];
@@ -310,18 +337,25 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
 
       // ------------------------------- forward recompute --------------------------------------------
       // (the previous iteration's last barrier has passed: every image of this wave is free)
-      h8 E1f[6], E2f[3];
+      h8 E1f[6], E2f[3], E1l[GEO ? 6 : 1];   // E1l: residual of the E1 features (GEO)
       {
         float Bh[33];
 #pragma unroll
         for (int i = 0; i < 33; ++i) Bh[i] = Bl_h[i];
-        pe_slots<true>(Bh, t0x, t1x, t2x, h, E1f, E2f);
+        pe_slots<true, GEO>(Bh, t0x, t1x, t2x, h, E1f, E2f, E1l);
       }
-      h8 wq[8];
-      f16v acc, bq;
+      // GEO: a geometry layer is three products per fragment, Wh xh + Wl xh + Wh xl (fused_common.h): wl = the residual
+      // fragments, X*l = the residual of the layer input, formed from the fp32 accumulators while the first products run
+      const unsigned char* lo_w = smem + l8_lo();
+      h8 wq[8], wl[GEO ? 6 : 1], wc[6];
+      f16v acc, bq, catp;
 #pragma unroll
-      for (int s = 0; s < 6; ++s) wq[s] = lds_frag(smem, KK_XYZ + s, lane);
+      for (int s = 0; s < 6; ++s) {
+        wq[s] = lds_frag(smem, KK_XYZ + s, lane);
+        if constexpr (!GEO) wc[s] = lds_frag(smem, KK_CAT + 2 + s, lane);
+      }
       acc = acc_init(cf + CF_B_XYZ, h);
+      catp = acc_init(brow_l + 1 * 32, h);
       if (any_iter) P8SYNC();   // the previous iteration's last barrier: the dW waves are done with this wave's images
       {
         const int rl = row - c * rows_per_class;
@@ -339,31 +373,68 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
 #pragma unroll
         for (int s = 0; s < 3; ++s) *reinterpret_cast<h8*>(b2 + 16 * s) = E2f[s];
       }
+      // encoding_xyz, and the e1 part of cat_layer right behind it (its own accumulator, started from the cat bias row): both
+      // read only the PE features, so the E1 operands die here, and the second runs under the packing of a0.
+      // GEO: six fragments in registers at a time -- Wh first (products with xh and xl), then Wl (product with xh); the
+      // scheduling barriers keep the compiler from fetching the next six early (24 fragments at once spill)
 #pragma unroll
       for (int s = 0; s < 6; ++s) acc = MFMA(wq[s], E1f[s], acc);
+      if constexpr (GEO) {
+#pragma unroll
+        for (int s = 0; s < 6; ++s) acc = MFMA(wq[s], E1l[s], acc);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 6; ++s) wl[s] = lds_frag(lo_w, KK_XYZ + s, lane);
+#pragma unroll
+        for (int s = 0; s < 6; ++s) acc = MFMA(wl[s], E1f[s], acc);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 6; ++s) wc[s] = lds_frag(smem, KK_CAT + 2 + s, lane);
+      }
+#pragma unroll
+      for (int s = 0; s < 6; ++s) catp = MFMA(wc[s], E1f[s], catp);
+      if constexpr (GEO) {
+#pragma unroll
+        for (int s = 0; s < 6; ++s) catp = MFMA(wc[s], E1l[s], catp);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 6; ++s) wl[s] = lds_frag(lo_w, KK_CAT + 2 + s, lane);
+#pragma unroll
+        for (int s = 0; s < 6; ++s) catp = MFMA(wl[s], E1f[s], catp);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // a 32-wide hidden layer on the input pair (xa, xb) = f16 of the previous accumulators; GEO: + the two residual products
+      auto hidden = [&](const h8& xa, const h8& xb, const f16v& prev, bool relu, const f16v& init) {
+        f16v o = MFMA(wq[0], xa, init);
+        o = MFMA(wq[1], xb, o);
+        if constexpr (GEO) {
+          o = MFMA(wl[0], xa, o);
+          o = MFMA(wl[1], xb, o);
+          const h8 la = pack8_lo(prev, 0, relu, xa), lb = pack8_lo(prev, 1, relu, xb);
+          o = MFMA(wq[0], la, o);
+          o = MFMA(wq[1], lb, o);
+        }
+        return o;
+      };
       wq[0] = lds_frag(smem, KK_S1 + 0, lane); wq[1] = lds_frag(smem, KK_S1 + 1, lane);
+      if constexpr (GEO) { wl[0] = lds_frag(lo_w, KK_S1 + 0, lane); wl[1] = lds_frag(lo_w, KK_S1 + 1, lane); }
       bq = acc_init(brow_l + 0 * 32, h);
       const h8 A0a = pack8(acc, 0, true), A0b = pack8(acc, 1, true);
-      acc = MFMA(wq[0], A0a, bq);
-      acc = MFMA(wq[1], A0b, acc);
-#pragma unroll
-      for (int s = 0; s < 8; ++s) wq[s] = lds_frag(smem, KK_CAT + s, lane);
-      bq = acc_init(brow_l + 1 * 32, h);
+      acc = hidden(A0a, A0b, acc, true, bq);
+      wq[0] = lds_frag(smem, KK_CAT + 0, lane); wq[1] = lds_frag(smem, KK_CAT + 1, lane);
+      if constexpr (GEO) { wl[0] = lds_frag(lo_w, KK_CAT + 0, lane); wl[1] = lds_frag(lo_w, KK_CAT + 1, lane); }
       const h8 A1a = pack8(acc, 0, true), A1b = pack8(acc, 1, true);
-      acc = MFMA(wq[0], A1a, bq);
-      acc = MFMA(wq[1], A1b, acc);
-#pragma unroll
-      for (int s = 0; s < 6; ++s) acc = MFMA(wq[2 + s], E1f[s], acc);
+      acc = hidden(A1a, A1b, acc, true, catp);
       wq[0] = lds_frag(smem, KK_S2 + 0, lane); wq[1] = lds_frag(smem, KK_S2 + 1, lane);
+      if constexpr (GEO) { wl[0] = lds_frag(lo_w, KK_S2 + 0, lane); wl[1] = lds_frag(lo_w, KK_S2 + 1, lane); }
       bq = acc_init(brow_l + 2 * 32, h);
       const h8 A2a = pack8(acc, 0, true), A2b = pack8(acc, 1, true);
-      acc = MFMA(wq[0], A2a, bq);
-      acc = MFMA(wq[1], A2b, acc);
+      acc = hidden(A2a, A2b, acc, true, bq);
       wq[0] = lds_frag(smem, KK_ES + 0, lane); wq[1] = lds_frag(smem, KK_ES + 1, lane);
+      if constexpr (GEO) { wl[0] = lds_frag(lo_w, KK_ES + 0, lane); wl[1] = lds_frag(lo_w, KK_ES + 1, lane); }
       bq = acc_init(cf + CF_B_ES, h);
       const h8 A3a = pack8(acc, 0, true), A3b = pack8(acc, 1, true);
-      acc = MFMA(wq[0], A3a, bq);
-      acc = MFMA(wq[1], A3b, acc);
+      acc = hidden(A3a, A3b, acc, true, bq);
 #pragma unroll
       for (int s = 0; s < 5; ++s) wq[s] = lds_frag(smem, KK_VD + s, lane);
       bq = acc_init(cf + CF_B_VD, h);
@@ -942,22 +1013,19 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
 }  // namespace
 
 // launched by cnr_field_bwd_pipe (fused_bwd_pipe.hip) for chain_waves = 4: same argument checks, same records
-template <int WIDE, int KR, bool TWO = false, bool PAD = false>
-static int launch_p8(const float* pts, const float* B, const void* packed, const float* biasrows, const int* ray_row,
-                     float scale, const float* d_sigma, const float* d_rgb, float grad_scale, int C, int R, int S,
-                     int rows_per_class, int blocks, void* workspace, int64_t B_stride, long long* rows_fix,
+template <int WIDE, int KR, bool TWO = false, bool PAD = false, bool GEO = false>
+static int launch_p8(const float* pts, const float* B, const void* packed, const void* packed_lo, const float* biasrows,
+                     const int* ray_row, float scale, const float* d_sigma, const float* d_rgb, float grad_scale, int C,
+                     int R, int S, int rows_per_class, int blocks, void* workspace, int64_t B_stride, long long* rows_fix,
                      int* clamp_flags, const TrainArgs& ta, void* stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t er = hipFuncSetAttribute((const void*)field_bwd_pipe8_kernel<4, 4, WIDE, KR, TWO, PAD>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, l8_total(4));
-    if (er != hipSuccess) return (int)er;
-    attr_set = true;
-  }
+  static cnr::DeviceOnce lds_attr;   // per instantiation, one bit per device
+  constexpr int LDS = l8_total(4, WIDE, GEO);
+  const int er = cnr::set_max_dynamic_lds(lds_attr, (const void*)field_bwd_pipe8_kernel<4, 4, WIDE, KR, TWO, PAD, GEO>, LDS);
+  if (er) return er;
   const int64_t N = (int64_t)R * S;
-  hipLaunchKernelGGL((field_bwd_pipe8_kernel<4, 4, WIDE, KR, TWO, PAD>), dim3((unsigned)blocks, (unsigned)C), dim3(512), l8_total(4),
-                     (hipStream_t)stream, pts, B, (const unsigned char*)packed, biasrows, ray_row, 1.0f / scale, d_sigma,
-                     d_rgb, grad_scale, (float*)workspace, (int)N, S, R, rows_per_class,
+  hipLaunchKernelGGL((field_bwd_pipe8_kernel<4, 4, WIDE, KR, TWO, PAD, GEO>), dim3((unsigned)blocks, (unsigned)C), dim3(512), LDS,
+                     (hipStream_t)stream, pts, B, (const unsigned char*)packed, (const unsigned char*)packed_lo, biasrows,
+                     ray_row, 1.0f / scale, d_sigma, d_rgb, grad_scale, (float*)workspace, (int)N, S, R, rows_per_class,
                      B_stride > 0 ? B_stride : (int64_t)63, rows_fix, clamp_flags, ta);
   CNR_LAUNCH_CHECK();
   return CNR_OK;
@@ -970,13 +1038,13 @@ extern "C" int cnr_field_bwd_pipe8_launch(const float* pts, const float* B, cons
                                           void* stream) {
   const TrainArgs none{};
   if (rows_per_class > 7)
-    return launch_p8<2, 0, false, false>(pts, B, packed, biasrows, ray_row, scale, d_sigma, d_rgb, grad_scale, C, R, S, rows_per_class,
-                              blocks, workspace, B_stride, rows_fix, clamp_flags, none, stream);
+    return launch_p8<2, 0>(pts, B, packed, nullptr, biasrows, ray_row, scale, d_sigma, d_rgb, grad_scale, C, R, S,
+                           rows_per_class, blocks, workspace, B_stride, rows_fix, clamp_flags, none, stream);
   if (rows_per_class > 4)
-    return launch_p8<1, 0, false, false>(pts, B, packed, biasrows, ray_row, scale, d_sigma, d_rgb, grad_scale, C, R, S, rows_per_class,
-                              blocks, workspace, B_stride, rows_fix, clamp_flags, none, stream);
-  return launch_p8<0, 0, false, false>(pts, B, packed, biasrows, ray_row, scale, d_sigma, d_rgb, grad_scale, C, R, S, rows_per_class,
-                             blocks, workspace, B_stride, rows_fix, clamp_flags, none, stream);
+    return launch_p8<1, 0>(pts, B, packed, nullptr, biasrows, ray_row, scale, d_sigma, d_rgb, grad_scale, C, R, S,
+                           rows_per_class, blocks, workspace, B_stride, rows_fix, clamp_flags, none, stream);
+  return launch_p8<0, 0>(pts, B, packed, nullptr, biasrows, ray_row, scale, d_sigma, d_rgb, grad_scale, C, R, S,
+                         rows_per_class, blocks, workspace, B_stride, rows_fix, clamp_flags, none, stream);
 }
 
 // ---- the ONE-launch step body: a8-a15 forward, losses, and the whole backward (see TrainArgs) ------------------------
@@ -994,42 +1062,46 @@ extern "C" int64_t cnr_field_train_workspace_bytes(int C, int R, int S, int max_
   const int nb = cnr_field_train_blocks(R, S, max_blocks);
   return nb ? ((int64_t)C * nb * 3 + (int64_t)C * 4) * (int64_t)sizeof(float) : 0;
 }
-extern "C" int cnr_field_train(const float* pts, const float* B, const void* packed, const float* biasrows,
-                               const int* ray_row, float scale, const float* z, const float* gt_depth,
-                               const float* gt_rgb, const uint8_t* labels, const uint8_t* depth_mask,
-                               const float* counts_tab, const int64_t* d_state, float color_scaling,
-                               float opacity_scaling, float loss_scale, float grad_scale, float* depth, float* var,
-                               float* rgb, float* opacity, int C, int R, int S, int rows_per_class, int max_blocks,
-                               void* records, int64_t records_bytes, void* loss_workspace, int64_t loss_workspace_bytes,
-                               int64_t B_stride, long long* rows_fix, int* clamp_flags, void* stream) {
-  if (!pts || !B || !packed || !biasrows || !ray_row || !z || !gt_depth || !gt_rgb || !labels || !depth_mask ||
-      !counts_tab || !records || !loss_workspace || C <= 0 || R <= 0 || !(scale > 0.f) || !(grad_scale > 0.f))
+extern "C" int cnr_field_train(const cnr_field_train_args* a, void* stream) {
+  if (!a || a->struct_size != sizeof(cnr_field_train_args) || a->abi_version != CNR_ABI_VERSION) return CNR_E_ARG;
+  const int C = a->C, R = a->R, S = a->S, rows_per_class = a->rows_per_class;
+  if (!a->pts || !a->B || !a->packed || !a->biasrows || !a->ray_row || !a->z || !a->gt_depth || !a->gt_rgb || !a->labels ||
+      !a->depth_mask || !a->counts_tab || !a->records || !a->loss_workspace || C <= 0 || R <= 0 || !(a->scale > 0.f) ||
+      !(a->grad_scale > 0.f))
     return CNR_E_ARG;
-  const int blocks = cnr_field_train_blocks(R, S, max_blocks);
+  const int blocks = cnr_field_train_blocks(R, S, a->max_blocks);
   if (!blocks || rows_per_class < 1 || rows_per_class > cnr_rec::ROWS_MAX) return CNR_E_SHAPE;
   const int sp = train_slots(S);
   if ((int64_t)C * R * sp >= ((int64_t)1 << 31)) return CNR_E_SHAPE;   // 32-bit slot indices inside the kernel
-  if (((uintptr_t)packed & 15) != 0 || ((uintptr_t)records & 15) != 0) return CNR_E_ALIGN;
-  if (records_bytes < (int64_t)C * blocks * REC_FLOATS * (int64_t)sizeof(float) ||
-      loss_workspace_bytes < cnr_field_train_workspace_bytes(C, R, S, max_blocks))
+  if (((uintptr_t)a->packed & 15) != 0 || ((uintptr_t)a->records & 15) != 0 || ((uintptr_t)a->packed_lo & 15) != 0 ||
+      ((uintptr_t)a->biasrows & 15) != 0)
+    return CNR_E_ALIGN;
+  if (a->records_bytes < (int64_t)C * blocks * REC_FLOATS * (int64_t)sizeof(float) ||
+      a->loss_workspace_bytes < cnr_field_train_workspace_bytes(C, R, S, a->max_blocks))
     return CNR_E_ARG;
-  const TrainArgs ta{z, gt_depth, gt_rgb, labels, depth_mask, counts_tab, d_state, color_scaling, opacity_scaling,
-                     loss_scale, depth, var, rgb, opacity, (float*)loss_workspace};
-#define CNR_FT(WIDE, KR, TWO, PAD)                                                                                    \
-  return launch_p8<WIDE, KR, TWO, PAD>(pts, B, packed, biasrows, ray_row, scale, nullptr, nullptr, grad_scale, C, R, S, \
-                                       rows_per_class, blocks, records, B_stride, rows_fix, clamp_flags, ta, stream)
+  const TrainArgs ta{a->z, a->gt_depth, a->gt_rgb, a->labels, a->depth_mask, a->counts_tab, a->d_state, a->color_scaling,
+                     a->opacity_scaling, a->loss_scale, a->depth, a->var, a->rgb, a->opacity, (float*)a->loss_workspace};
+#define CNR_FT(WIDE, KR, TWO, PAD, GEO)                                                                               \
+  return launch_p8<WIDE, KR, TWO, PAD, GEO>(a->pts, a->B, a->packed, a->packed_lo, a->biasrows, a->ray_row, a->scale, \
+                                            nullptr, nullptr, a->grad_scale, C, R, S, rows_per_class, blocks,         \
+                                            a->records, a->B_stride, a->rows_fix, a->clamp_flags, ta, stream)
   const bool pad = S != sp;   // exact fit: the plain index arithmetic (2 % faster at configs[1] than the padded form)
-#define CNR_FT_ALL(W)                                                                                    \
-  {                                                                                                      \
-    if (sp == 16) CNR_FT(W, 1, true, true);                                                              \
-    if (sp == 32) { if (pad) CNR_FT(W, 1, false, true); CNR_FT(W, 1, false, false); }                    \
-    if (sp == 64) { if (pad) CNR_FT(W, 2, false, true); CNR_FT(W, 2, false, false); }                    \
-    if (pad) CNR_FT(W, 4, false, true);                                                                  \
-    CNR_FT(W, 4, false, false);                                                                          \
+#define CNR_FT_ALL(W, G)                                                                                    \
+  {                                                                                                         \
+    if (sp == 16) CNR_FT(W, 1, true, true, G);                                                              \
+    if (sp == 32) { if (pad) CNR_FT(W, 1, false, true, G); CNR_FT(W, 1, false, false, G); }                 \
+    if (sp == 64) { if (pad) CNR_FT(W, 2, false, true, G); CNR_FT(W, 2, false, false, G); }                 \
+    if (pad) CNR_FT(W, 4, false, true, G);                                                                  \
+    CNR_FT(W, 4, false, false, G);                                                                          \
   }
-  if (rows_per_class > 7) CNR_FT_ALL(2)
-  if (rows_per_class > 4) CNR_FT_ALL(1)
-  CNR_FT_ALL(0)
+  if (a->packed_lo) {
+    if (rows_per_class > 7) CNR_FT_ALL(2, true)
+    if (rows_per_class > 4) CNR_FT_ALL(1, true)
+    CNR_FT_ALL(0, true)
+  }
+  if (rows_per_class > 7) CNR_FT_ALL(2, false)
+  if (rows_per_class > 4) CNR_FT_ALL(1, false)
+  CNR_FT_ALL(0, false)
 #undef CNR_FT_ALL
 #undef CNR_FT
 }

@@ -56,6 +56,14 @@ constexpr int PK_OFF_FWD = 0;
 constexpr int PK_OFF_CONST = NKK_FWD * FRAG_BYTES;                 // 30720
 constexpr int PK_OFF_BWD = PK_OFF_CONST + CF_FLOATS * 4;           // 31744
 constexpr int PK_BYTES = PK_OFF_BWD + NKK_BWD * FRAG_BYTES;        // 62464
+// Residual image ("lo"): f16(W - f16(W)) of the forward fragments of the GEOMETRY branch -- k-steps [0, NKK_GEO) =
+// encoding_xyz, shape_layer_1, cat_layer, shape_layer_2, encoding_shape, the layers between the ray sample and the x10
+// occupancy logit (src/model.py:56-75).  A kernel given this image computes those layers as three products
+//   W x  ~=  Wh xh + Wl xh + Wh xl      (Wh = f16(W), Wl = f16(W - Wh), xh = f16(x), xl = f16(x - xh); fp32 accumulate)
+// which carries ~22 mantissa bits through the branch: north_star's 1e-3 on the occupancy holds for TRAINED weights (plain
+// f16 operands give 1.8e-3 .. 2.0e-3 after 400 .. 5000 steps).  The colour branch stays plain f16.
+constexpr int NKK_GEO = KK_VD;                                      // 20 fragments
+constexpr int PK_LO_BYTES = NKK_GEO * FRAG_BYTES;                   // 20480
 
 // e-feature (0..128) held by slot q of lane-half h ; -1 = empty slot.  part 0 = E1, 1 = E2.
 __host__ __device__ inline int slot_feature(int part, int h, int q) {
@@ -114,6 +122,29 @@ __device__ __forceinline__ h8 pack8(const f16v& a, int s, bool relu) {
   }
   return r;
 }
+// the residual of pack8: f16(x - f16(x)) for the same 8 accumulator registers, x = max(a, 0) when relu
+__device__ __forceinline__ h8 pack8_lo(const f16v& a, int s, bool relu, const h8& hi) {
+  h8 r;
+#pragma unroll
+  for (int j = 0; j < 8; j += 2) {
+    const float x0 = relu ? fmaxf(a[8 * s + j], 0.0f) : a[8 * s + j];
+    const float x1 = relu ? fmaxf(a[8 * s + j + 1], 0.0f) : a[8 * s + j + 1];
+    f2 v = {__builtin_fmaf((float)hi[j], -1.0f, x0), __builtin_fmaf((float)hi[j + 1], -1.0f, x1)};   // v_fma_mix_f32
+    h2 p = __builtin_convertvector(v, h2);
+    r[j] = p[0]; r[j + 1] = p[1];
+  }
+  return r;
+}
+__device__ __forceinline__ h8 pack8f_lo(const float* v, const h8& hi) {
+  h8 r;
+#pragma unroll
+  for (int j = 0; j < 8; j += 2) {
+    f2 x = {__builtin_fmaf((float)hi[j], -1.0f, v[j]), __builtin_fmaf((float)hi[j + 1], -1.0f, v[j + 1])};
+    h2 p = __builtin_convertvector(x, h2);
+    r[j] = p[0]; r[j + 1] = p[1];
+  }
+  return r;
+}
 __device__ __forceinline__ h8 pack8f(const float* v) {
   h8 r;
 #pragma unroll
@@ -143,9 +174,9 @@ __device__ __forceinline__ h8 lds_frag(const unsigned char* lds_w, int kk, int l
 // Positional encoding of one sample in B-operand layout.  Bh: this lane-half's 11 direction rows
 // (row 10 of half 1 is zero).  ONES puts 1.0 into two empty half-0 slots (E1 slot 47, E2 slot 22): their
 // forward weights are zero, and in the backward's dW products they collect the bias gradients.
-template <bool ONES>
+template <bool ONES, bool LO = false>
 __device__ __forceinline__ void pe_slots(const float (&Bh)[33], float t0, float t1, float t2, int h,
-                                         h8 (&E1f)[6], h8 (&E2f)[3]) {
+                                         h8 (&E1f)[6], h8 (&E2f)[3], h8* E1lo = nullptr) {
   float v[72];
 #pragma unroll
   for (int d = 0; d < 11; ++d) {
@@ -163,6 +194,10 @@ __device__ __forceinline__ void pe_slots(const float (&Bh)[33], float t0, float 
   v[70] = one; v[71] = 0.0f;
 #pragma unroll
   for (int s = 0; s < 6; ++s) E1f[s] = pack8f(&v[8 * s]);
+  if constexpr (LO) {   // residual of the E1 features (the geometry branch's inputs): slots 44..47 (t, ones) included
+#pragma unroll
+    for (int s = 0; s < 6; ++s) E1lo[s] = pack8f_lo(&v[8 * s], E1f[s]);
+  }
 #pragma unroll
   for (int s = 0; s < 3; ++s) E2f[s] = pack8f(&v[48 + 8 * s]);
 }

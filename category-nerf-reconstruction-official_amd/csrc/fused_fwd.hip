@@ -71,17 +71,19 @@ __device__ __forceinline__ void pack_block(const float* __restrict__ Wt, unsigne
     }
   }
 }
-// residual fragments W - f16(W) (forward orientation only) for the split-weight forward: W x = f16(W) x + lo x, two
-// MFMAs per fragment, removes the weight-rounding share of the f16 error
-__global__ __launch_bounds__(256) void pack_lo_kernel(const float* __restrict__ trunk, unsigned char* __restrict__ lo) {
-  const int c = blockIdx.y, kk = blockIdx.x;
-  const float* Wt = trunk + (size_t)c * TRUNK;
-  _Float16* out = reinterpret_cast<_Float16*>(lo + ((size_t)c * NKK_FWD + kk) * FRAG_BYTES);
+// residual fragments f16(W - f16(W)) of the geometry branch's forward k-steps (fused_common.h, NKK_GEO): one block = one
+// fragment of the (C, PK_LO_BYTES) image
+__device__ __forceinline__ void pack_lo_block(const float* __restrict__ Wt, unsigned char* __restrict__ lo, int kk) {
+  _Float16* out = reinterpret_cast<_Float16*>(lo + (size_t)kk * FRAG_BYTES);
   for (int e = threadIdx.x; e < 64 * 8; e += 256) {
     const int lane = e >> 3, j = e & 7, r = lane & 31, h = lane >> 5;
     const float v = fwd_elem(Wt, kk, r, h, j);
     out[lane * 8 + j] = (_Float16)(v - (float)(_Float16)v);
   }
+}
+__global__ __launch_bounds__(256) void pack_lo_kernel(const float* __restrict__ trunk, unsigned char* __restrict__ lo) {
+  const int c = blockIdx.y;
+  pack_lo_block(trunk + (size_t)c * TRUNK, lo + (size_t)c * PK_LO_BYTES, blockIdx.x);
 }
 __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ trunk, unsigned char* __restrict__ packed) {
   const int c = blockIdx.y;
@@ -121,7 +123,8 @@ __global__ __launch_bounds__(256) void param_prep_kernel(const float* __restrict
                                                          int64_t off_trunk, unsigned char* __restrict__ packed,
                                                          float* __restrict__ zl, float* __restrict__ biasrows,
                                                          float* __restrict__ zero_buf, int64_t zero_count, int nzero,
-                                                         cnr_sample::SampleArgs sa, int nsample) {
+                                                         cnr_sample::SampleArgs sa, int nsample,
+                                                         unsigned char* __restrict__ packed_lo) {
   constexpr int NPACK = NKK_FWD + NKK_BWD + 1;
   const int c = blockIdx.y, C = gridDim.y;
   const float* th = theta + (int64_t)c * lay.stride;
@@ -129,6 +132,10 @@ __global__ __launch_bounds__(256) void param_prep_kernel(const float* __restrict
   PREP_T0();
   if (b < NPACK) { pack_block(th + off_trunk, packed + (size_t)c * PK_BYTES, b); PREP_T1(0); return; }
   b -= NPACK;
+  if (packed_lo) {   // + the residual image of the geometry branch (grid grown by NKK_GEO blocks)
+    if (b < NKK_GEO) { pack_lo_block(th + off_trunk, packed_lo + (size_t)c * PK_LO_BYTES, b); PREP_T1(0); return; }
+    b -= NKK_GEO;
+  }
   if (b < 4 * lay.n_obj) { cnr::latent_fwd_block(th, th + off_trunk, lay, zl, biasrows, b >> 2, b & 3, c); PREP_T1(1); return; }
   b -= 4 * lay.n_obj;
   if (b >= nzero) {  // a2-a5: four rays of class c per block
@@ -151,50 +158,59 @@ __global__ __launch_bounds__(256) void param_prep_kernel(const float* __restrict
 
 namespace {
 
-// One 32-sample tile through PE + the ten layers (SPLIT: every weight fragment as f16(W) + f16(W - f16(W))): this lane's sample is (t0, t1, t2) (already / scale), brow its
-// ray's effective bias rows.  Returns the sigma logit BEFORE the x10 (valid in every lane) and leaves the three colour
-// logits in acc[0..2] of lane half 0.
-// one weight fragment times one operand fragment: hi part, and in SPLIT mode the residual part on top
+// One 32-sample tile through PE + the ten layers: this lane's sample is (t0, t1, t2) (already / scale), brow its ray's
+// effective bias rows.  Returns the sigma logit BEFORE the x10 (valid in every lane) and leaves the three colour logits in
+// acc[0..2] of lane half 0.  SPLIT: the geometry branch (encoding_xyz .. encoding_shape) as three products per fragment,
+// Wh xh + Wl xh + Wh xl with the residual weight image smem_lo (fused_common.h, NKK_GEO); the colour branch plain f16.
 template <bool SPLIT>
-__device__ __forceinline__ f16v mma2(const unsigned char* smem, const unsigned char* smem_lo, int kk, int lane,
-                                     const h8& x, f16v acc) {
-  acc = MFMA(lds_frag(smem, kk, lane), x, acc);
-  if (SPLIT) acc = MFMA(lds_frag(smem_lo, kk, lane), x, acc);
+__device__ __forceinline__ f16v mma3(const unsigned char* smem, const unsigned char* smem_lo, int kk, int lane,
+                                     const h8& xh, const h8& xl, f16v acc) {
+  const h8 wh = lds_frag(smem, kk, lane);
+  acc = MFMA(wh, xh, acc);
+  if (SPLIT) {
+    acc = MFMA(lds_frag(smem_lo, kk, lane), xh, acc);
+    acc = MFMA(wh, xl, acc);
+  }
   return acc;
 }
 template <bool SPLIT>
 __device__ __forceinline__ float forward_tile(const unsigned char* smem, const unsigned char* smem_lo, const float* cf, const float (&Bh)[33],
                                               float t0, float t1, float t2, const float* __restrict__ brow, int lane,
                                               int h, f16v& acc_out) {
-  h8 E1f[6], E2f[3];
-  pe_slots<false>(Bh, t0, t1, t2, h, E1f, E2f);
+  h8 E1f[6], E2f[3], E1l[6];
+  pe_slots<false, SPLIT>(Bh, t0, t1, t2, h, E1f, E2f, E1l);
+  const h8 zl = {};   // (unused operand of the plain form)
 
   // L0 encoding_xyz
   f16v acc = acc_init(cf + CF_B_XYZ, h);
 #pragma unroll
-  for (int s = 0; s < 6; ++s) acc = mma2<SPLIT>(smem, smem_lo, KK_XYZ + s, lane, E1f[s], acc);
-  h8 H0 = pack8(acc, 0, true), H1 = pack8(acc, 1, true);
+  for (int s = 0; s < 6; ++s) acc = mma3<SPLIT>(smem, smem_lo, KK_XYZ + s, lane, E1f[s], SPLIT ? E1l[s] : zl, acc);
+  h8 H0 = pack8(acc, 0, true), H1 = pack8(acc, 1, true), L0 = zl, L1 = zl;
+  if (SPLIT) { L0 = pack8_lo(acc, 0, true, H0); L1 = pack8_lo(acc, 1, true, H1); }
   // L1 shape_layer_1 (latent slot 0 folded into the bias row)
   acc = acc_init(brow + 0 * 32, h);
-  acc = mma2<SPLIT>(smem, smem_lo, KK_S1 + 0, lane, H0, acc);
-  acc = mma2<SPLIT>(smem, smem_lo, KK_S1 + 1, lane, H1, acc);
+  acc = mma3<SPLIT>(smem, smem_lo, KK_S1 + 0, lane, H0, L0, acc);
+  acc = mma3<SPLIT>(smem, smem_lo, KK_S1 + 1, lane, H1, L1, acc);
   H0 = pack8(acc, 0, true); H1 = pack8(acc, 1, true);
+  if (SPLIT) { L0 = pack8_lo(acc, 0, true, H0); L1 = pack8_lo(acc, 1, true, H1); }
   // L2 cat_layer: [a1 | e1]
   acc = acc_init(brow + 1 * 32, h);
-  acc = mma2<SPLIT>(smem, smem_lo, KK_CAT + 0, lane, H0, acc);
-  acc = mma2<SPLIT>(smem, smem_lo, KK_CAT + 1, lane, H1, acc);
+  acc = mma3<SPLIT>(smem, smem_lo, KK_CAT + 0, lane, H0, L0, acc);
+  acc = mma3<SPLIT>(smem, smem_lo, KK_CAT + 1, lane, H1, L1, acc);
 #pragma unroll
-  for (int s = 0; s < 6; ++s) acc = mma2<SPLIT>(smem, smem_lo, KK_CAT + 2 + s, lane, E1f[s], acc);
+  for (int s = 0; s < 6; ++s) acc = mma3<SPLIT>(smem, smem_lo, KK_CAT + 2 + s, lane, E1f[s], SPLIT ? E1l[s] : zl, acc);
   H0 = pack8(acc, 0, true); H1 = pack8(acc, 1, true);
+  if (SPLIT) { L0 = pack8_lo(acc, 0, true, H0); L1 = pack8_lo(acc, 1, true, H1); }
   // L3 shape_layer_2
   acc = acc_init(brow + 2 * 32, h);
-  acc = mma2<SPLIT>(smem, smem_lo, KK_S2 + 0, lane, H0, acc);
-  acc = mma2<SPLIT>(smem, smem_lo, KK_S2 + 1, lane, H1, acc);
+  acc = mma3<SPLIT>(smem, smem_lo, KK_S2 + 0, lane, H0, L0, acc);
+  acc = mma3<SPLIT>(smem, smem_lo, KK_S2 + 1, lane, H1, L1, acc);
   H0 = pack8(acc, 0, true); H1 = pack8(acc, 1, true);
+  if (SPLIT) { L0 = pack8_lo(acc, 0, true, H0); L1 = pack8_lo(acc, 1, true, H1); }
   // L4 encoding_shape (no activation)
   acc = acc_init(cf + CF_B_ES, h);
-  acc = mma2<SPLIT>(smem, smem_lo, KK_ES + 0, lane, H0, acc);
-  acc = mma2<SPLIT>(smem, smem_lo, KK_ES + 1, lane, H1, acc);
+  acc = mma3<SPLIT>(smem, smem_lo, KK_ES + 0, lane, H0, L0, acc);
+  acc = mma3<SPLIT>(smem, smem_lo, KK_ES + 1, lane, H1, L1, acc);
   // sigma head in fp32 on the VALU: raw = w_sigma . y4 + b
   float raw;
   {
@@ -205,26 +221,26 @@ __device__ __forceinline__ float forward_tile(const unsigned char* smem, const u
     raw = part + __shfl_xor(part, 32, 64) + cf[CF_B_SG];
   }
   H0 = pack8(acc, 0, false); H1 = pack8(acc, 1, false);
-  // L6 encoding_viewdir: [y4 | e2]
+  // L6 encoding_viewdir: [y4 | e2]   (colour branch: plain f16 from here on)
   acc = acc_init(cf + CF_B_VD, h);
-  acc = mma2<SPLIT>(smem, smem_lo, KK_VD + 0, lane, H0, acc);
-  acc = mma2<SPLIT>(smem, smem_lo, KK_VD + 1, lane, H1, acc);
+  acc = MFMA(lds_frag(smem, KK_VD + 0, lane), H0, acc);
+  acc = MFMA(lds_frag(smem, KK_VD + 1, lane), H1, acc);
 #pragma unroll
-  for (int s = 0; s < 3; ++s) acc = mma2<SPLIT>(smem, smem_lo, KK_VD + 2 + s, lane, E2f[s], acc);
+  for (int s = 0; s < 3; ++s) acc = MFMA(lds_frag(smem, KK_VD + 2 + s, lane), E2f[s], acc);
   H0 = pack8(acc, 0, true); H1 = pack8(acc, 1, true);
   // L7 texture_layer_1
   acc = acc_init(brow + 3 * 32, h);
-  acc = mma2<SPLIT>(smem, smem_lo, KK_T1 + 0, lane, H0, acc);
-  acc = mma2<SPLIT>(smem, smem_lo, KK_T1 + 1, lane, H1, acc);
+  acc = MFMA(lds_frag(smem, KK_T1 + 0, lane), H0, acc);
+  acc = MFMA(lds_frag(smem, KK_T1 + 1, lane), H1, acc);
   H0 = pack8(acc, 0, true); H1 = pack8(acc, 1, true);
   // L8 rgb.0 (16 outputs = rows 0..15 = registers 0..7)
   acc = acc_init(cf + CF_B_R0, h);
-  acc = mma2<SPLIT>(smem, smem_lo, KK_R0 + 0, lane, H0, acc);
-  acc = mma2<SPLIT>(smem, smem_lo, KK_R0 + 1, lane, H1, acc);
+  acc = MFMA(lds_frag(smem, KK_R0 + 0, lane), H0, acc);
+  acc = MFMA(lds_frag(smem, KK_R0 + 1, lane), H1, acc);
   H0 = pack8(acc, 0, true);
   // L9 rgb.2 (3 outputs = rows 0..2 = registers 0..2 of half 0)
   acc = acc_init(cf + CF_B_R2, h);
-  acc = mma2<SPLIT>(smem, smem_lo, KK_R2, lane, H0, acc);
+  acc = MFMA(lds_frag(smem, KK_R2, lane), H0, acc);
   acc_out = acc;
   return raw;
 }
@@ -232,8 +248,8 @@ __device__ __forceinline__ float forward_tile(const unsigned char* smem, const u
 constexpr int LDS_LO_OFF = (PK_OFF_BWD + 66 * 4 + 8 + 15) / 16 * 16;  // residual fragments behind the [2][33] B rows
 // stage the residual fragments of class c (split-weight mode)
 __device__ __forceinline__ void stage_lo(unsigned char* smem, const unsigned char* __restrict__ packed_lo, int c) {
-  const unsigned char* src = packed_lo + (size_t)c * NKK_FWD * FRAG_BYTES;
-  for (int i = threadIdx.x * 16; i < NKK_FWD * FRAG_BYTES; i += 256 * 16)
+  const unsigned char* src = packed_lo + (size_t)c * PK_LO_BYTES;
+  for (int i = threadIdx.x * 16; i < PK_LO_BYTES; i += 256 * 16)
     *reinterpret_cast<f4*>(smem + LDS_LO_OFF + i) = *reinterpret_cast<const f4*>(src + i);
 }
 
@@ -587,7 +603,7 @@ extern "C" int cnr_field_fwd_render(const float* pts, const float* B, const void
   if (!nb) return CNR_E_SHAPE;
   if (workspace_bytes < cnr_field_fwd_render_workspace_bytes(C, R, S)) return CNR_E_ARG;
   if (((uintptr_t)packed & 15) != 0 || ((uintptr_t)biasrows & 15) != 0) return CNR_E_ALIGN;
-  const size_t lds = packed_lo ? (size_t)LDS_LO_OFF + fz::NKK_FWD * fz::FRAG_BYTES
+  const size_t lds = packed_lo ? (size_t)LDS_LO_OFF + fz::PK_LO_BYTES
                                : (size_t)fz::PK_OFF_BWD + 66 * sizeof(float) + 8;
   dim3 grid((unsigned)nb, (unsigned)C);
   // mask counts: inside the kernel from registers when they fit (few classes / rays), else by a one-block-per-class
@@ -600,8 +616,11 @@ extern "C" int cnr_field_fwd_render(const float* pts, const float* B, const void
   }
 #define CNR_FFR(KK, SP)                                                                                             \
   do {                                                                                                              \
-    if (SP) (void)hipFuncSetAttribute((const void*)field_fwd_render_kernel<KK, SP>,                                 \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
+    if (SP) {                                                                                                       \
+      static cnr::DeviceOnce once;                                                                                  \
+      const int er_ = cnr::set_max_dynamic_lds(once, (const void*)field_fwd_render_kernel<KK, SP>, (int)lds);       \
+      if (er_) return er_;                                                                                          \
+    }                                                                                                               \
     hipLaunchKernelGGL((field_fwd_render_kernel<KK, SP>), grid, dim3(256), lds, (hipStream_t)stream, pts, B,         \
                        (const unsigned char*)packed, biasrows, ray_row, 1.0f / scale, z, gt_depth, gt_rgb, labels,   \
                        depth_mask, color_scaling, opacity_scaling, grad_scale, d_sigmas, d_colors, depth, var, rgb,  \
@@ -642,54 +661,54 @@ extern "C" int cnr_param_prep(const float* theta, int64_t class_stride, int64_t 
   if (nzero > 256) nzero = 256;
   dim3 grid(fz::NKK_FWD + fz::NKK_BWD + 1 + 4 * n_obj + nzero, (unsigned)C);
   hipLaunchKernelGGL(param_prep_kernel, grid, dim3(256), 0, (hipStream_t)stream, theta, lay, off_trunk,
-                     (unsigned char*)packed, zl, biasrows, zero_buf, zero_count, nzero, cnr_sample::SampleArgs{}, 0);
+                     (unsigned char*)packed, zl, biasrows, zero_buf, zero_count, nzero, cnr_sample::SampleArgs{}, 0,
+                     (unsigned char*)nullptr);
   CNR_LAUNCH_CHECK();
   return CNR_OK;
 }
 
-extern "C" int cnr_step_prologue(
-    /* cnr_param_prep */ const float* theta, int64_t class_stride, int64_t off_trunk, int64_t off_latW, int64_t off_latb,
-    int64_t off_shape, int64_t off_tex, int L, int n_obj, int C, void* packed, float* zl, float* biasrows,
-    float* zero_buf, int64_t zero_count,
-    /* cnr_sample_rays */ const uint8_t* rgbs, const float* depth, const float* dirs_c, const float* T, const float* u,
-    const float* g, uint64_t seed, uint64_t offset, const int64_t* d_state, int64_t pool_rows, const float* max_bound,
-    int world_frame, int R, int n1, int n2, float eps, float stop_eps, float min_bound, float* z, float* pts,
-    float* origins, float* dirs_o, float* gt_rgb, float* gt_depth, uint8_t* depth_mask, uint8_t* labels,
-    const int64_t* pool_indices, int* ray_row, const int* perm, int max_bound_slices, int rng_c0, int rng_cstride,
-    int rng_R, int rng_r0, void* stream) {
-  if (rng_c0 < 0 || rng_cstride < 0 || rng_R < 0 || rng_r0 < 0 || (rng_R > 0 && rng_r0 + R > rng_R)) return CNR_E_ARG;
-  if (max_bound_slices < 0 || (max_bound_slices > 1 && (pool_rows <= 0 || !d_state))) return CNR_E_ARG;
-  if (!theta || !packed || !zl || !biasrows || L <= 0 || n_obj <= 0 || C <= 0 || zero_count < 0 ||
-      (zero_count > 0 && !zero_buf))
+extern "C" int cnr_step_prologue(const cnr_step_prologue_args* a, void* stream) {
+  if (!a || a->struct_size != sizeof(cnr_step_prologue_args) || a->abi_version != CNR_ABI_VERSION) return CNR_E_ARG;
+  const int L = a->L, n_obj = a->n_obj, C = a->C, R = a->R, n1 = a->n1, n2 = a->n2;
+  if (a->rng_c0 < 0 || a->rng_cstride < 0 || a->rng_R < 0 || a->rng_r0 < 0 || (a->rng_R > 0 && a->rng_r0 + R > a->rng_R))
     return CNR_E_ARG;
-  if (((uintptr_t)packed & 15) != 0 || ((uintptr_t)zero_buf & 15) != 0) return CNR_E_ALIGN;
-  if (!rgbs || !depth || !dirs_c || !T || !max_bound || !z || !pts || !gt_rgb || !depth_mask || !labels) return CNR_E_ARG;
+  if (a->max_bound_slices < 0 || (a->max_bound_slices > 1 && (a->pool_rows <= 0 || !a->d_state))) return CNR_E_ARG;
+  if (!a->theta || !a->packed || !a->zl || !a->biasrows || L <= 0 || n_obj <= 0 || C <= 0 || a->zero_count < 0 ||
+      (a->zero_count > 0 && !a->zero_buf))
+    return CNR_E_ARG;
+  if (((uintptr_t)a->packed & 15) != 0 || ((uintptr_t)a->zero_buf & 15) != 0 || ((uintptr_t)a->packed_lo & 15) != 0)
+    return CNR_E_ALIGN;
+  if (!a->rgbs || !a->depth || !a->dirs_c || !a->T || !a->max_bound || !a->z || !a->pts || !a->gt_rgb || !a->depth_mask ||
+      !a->labels)
+    return CNR_E_ARG;
   if (R <= 0 || n1 < 0 || n2 <= 0) return CNR_E_ARG;
   if (n2 > 128) return CNR_E_SHAPE;
-  if ((u == nullptr) != (g == nullptr)) return CNR_E_ARG;
-  if (pool_rows < 0 || (pool_rows > 0 && (!d_state || pool_rows < R))) return CNR_E_ARG;
-  if (ray_row && !pool_indices) return CNR_E_ARG;
-  if (perm && pool_rows == 0) return CNR_E_ARG;
-  cnr::FlatLayout lay{class_stride, off_latW, off_latb, off_shape, off_tex, L, n_obj};
-  int nzero = zero_count > 0 ? (int)((zero_count / 4 + 256 * 8 - 1) / (256 * 8) / C) : 0;
-  if (zero_count > 0 && nzero < 1) nzero = 1;
+  if ((a->u == nullptr) != (a->g == nullptr)) return CNR_E_ARG;
+  if (a->pool_rows < 0 || (a->pool_rows > 0 && (!a->d_state || a->pool_rows < R))) return CNR_E_ARG;
+  if (a->ray_row && !a->pool_indices) return CNR_E_ARG;
+  if (a->perm && a->pool_rows == 0) return CNR_E_ARG;
+  cnr::FlatLayout lay{a->class_stride, a->off_latW, a->off_latb, a->off_shape, a->off_tex, L, n_obj};
+  int nzero = a->zero_count > 0 ? (int)((a->zero_count / 4 + 256 * 8 - 1) / (256 * 8) / C) : 0;
+  if (a->zero_count > 0 && nzero < 1) nzero = 1;
   if (nzero > 256) nzero = 256;
   const int nsample = (R + 3) / 4;
-  cnr_sample::SampleArgs sa{rgbs, depth, dirs_c, T, u, g, seed, offset, d_state, pool_rows, max_bound, world_frame,
-                            C, R, n1, n2, eps, stop_eps, min_bound, z, pts, origins, dirs_o, gt_rgb, gt_depth,
-                            depth_mask, labels, pool_indices, n_obj, ray_row, perm, max_bound_slices, rng_c0, rng_cstride, rng_R, rng_r0};
-  dim3 grid(fz::NKK_FWD + fz::NKK_BWD + 1 + 4 * n_obj + nzero + nsample, (unsigned)C);
-  hipLaunchKernelGGL(param_prep_kernel, grid, dim3(256), 0, (hipStream_t)stream, theta, lay, off_trunk,
-                     (unsigned char*)packed, zl, biasrows, zero_buf, zero_count, nzero, sa, nsample);
+  cnr_sample::SampleArgs sa{a->rgbs, a->depth, a->dirs_c, a->T, a->u, a->g, a->seed, a->offset, a->d_state, a->pool_rows,
+                            a->max_bound, a->world_frame, C, R, n1, n2, a->eps, a->stop_eps, a->min_bound, a->z, a->pts,
+                            a->origins, a->dirs_o, a->gt_rgb, a->gt_depth, a->depth_mask, a->labels, a->pool_indices, n_obj,
+                            a->ray_row, a->perm, a->max_bound_slices, a->rng_c0, a->rng_cstride, a->rng_R, a->rng_r0};
+  dim3 grid(fz::NKK_FWD + fz::NKK_BWD + 1 + (a->packed_lo ? fz::NKK_GEO : 0) + 4 * n_obj + nzero + nsample, (unsigned)C);
+  hipLaunchKernelGGL(param_prep_kernel, grid, dim3(256), 0, (hipStream_t)stream, a->theta, lay, a->off_trunk,
+                     (unsigned char*)a->packed, a->zl, a->biasrows, a->zero_buf, a->zero_count, nzero, sa, nsample,
+                     (unsigned char*)a->packed_lo);
   CNR_LAUNCH_CHECK();
   return CNR_OK;
 }
 
-extern "C" int64_t cnr_pack_lo_bytes() { return (int64_t)fz::NKK_FWD * fz::FRAG_BYTES; }
+extern "C" int64_t cnr_pack_lo_bytes() { return (int64_t)fz::PK_LO_BYTES; }
 extern "C" int cnr_pack_weights_lo(const float* trunk, void* packed_lo, int C, void* stream) {
   if (!trunk || !packed_lo || C <= 0) return CNR_E_ARG;
   if (((uintptr_t)packed_lo & 15) != 0) return CNR_E_ALIGN;
-  hipLaunchKernelGGL(pack_lo_kernel, dim3(fz::NKK_FWD, (unsigned)C), dim3(256), 0, (hipStream_t)stream, trunk,
+  hipLaunchKernelGGL(pack_lo_kernel, dim3(fz::NKK_GEO, (unsigned)C), dim3(256), 0, (hipStream_t)stream, trunk,
                      (unsigned char*)packed_lo);
   CNR_LAUNCH_CHECK();
   return CNR_OK;
@@ -706,15 +725,13 @@ extern "C" int cnr_field_fwd(const float* pts, const float* B, const void* packe
   int64_t blocks = (ntiles + 3) / 4;
   static const int64_t cap = getenv("CNR_FWD_BLOCKS") ? atoll(getenv("CNR_FWD_BLOCKS")) : 2048;
   if (blocks > cap) blocks = cap;
-  const size_t lds = packed_lo ? (size_t)LDS_LO_OFF + fz::NKK_FWD * fz::FRAG_BYTES
+  const size_t lds = packed_lo ? (size_t)LDS_LO_OFF + fz::PK_LO_BYTES
                                : (size_t)fz::PK_OFF_BWD + 66 * sizeof(float) + 8;
   dim3 grid((unsigned)blocks, (unsigned)C);
   if (packed_lo) {
-    static bool attr = false;
-    if (!attr) {
-      (void)hipFuncSetAttribute((const void*)field_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr = true;
-    }
+    static cnr::DeviceOnce once;
+    const int er = cnr::set_max_dynamic_lds(once, (const void*)field_fwd_kernel<true>, (int)lds);
+    if (er) return er;
     hipLaunchKernelGGL(field_fwd_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, pts, B,
                        (const unsigned char*)packed, biasrows, ray_row, 1.0f / scale, sigmas, rgbs, N, S, R,
                        B_stride > 0 ? B_stride : (int64_t)63, (const unsigned char*)packed_lo);

@@ -414,11 +414,10 @@ extern "C" int cnr_mlp_bwd_f32(const float* e, const float* zlat, const float* t
   const int tpb = (int)((tiles + blocks - 1) / blocks);
   blocks = (tiles + tpb - 1) / tpb;
   const size_t lds = (size_t)(((TRUNK + 3) & ~3) + 4 * 2 * 64 * ST_LD) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t er = hipFuncSetAttribute((const void*)mlp_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (er != hipSuccess) return (int)er;
-    attr_set = true;
+  {
+    static cnr::DeviceOnce once;
+    const int er = cnr::set_max_dynamic_lds(once, (const void*)mlp_bwd_kernel, (int)lds);
+    if (er) return er;
   }
   dim3 grid((unsigned)blocks, (unsigned)C);
   hipLaunchKernelGGL(mlp_bwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, e, zlat, trunk, dsig, drgb, de,

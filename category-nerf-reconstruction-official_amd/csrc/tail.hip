@@ -283,15 +283,22 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
 }
 }  // namespace
 
-extern "C" int cnr_step_tail(const float* theta_in, float* theta_out, float* grad, float* exp_avg, float* exp_avg_sq,
-                             int64_t class_stride, int64_t off_B, int64_t off_latW, int64_t off_latb, int64_t off_shape,
-                             int64_t off_tex, int L, int n_obj, int C, const float* zl, float* dbiasrows,
-                             float reg_scale, int do_latent, float lr, float beta1, float beta2, float eps,
-                             float weight_decay, const int64_t* state_cur, int64_t* state_next, int64_t add_rows,
-                             const void* rl_workspace, float* losses, int32_t* flags, const float* depth,
-                             int64_t pool_rows, const int* perm, float* next_max_bound, int R, const void* records,
-                             int nwg, const long long* rows_fix, int rl_blocks, int* clamp_flags, const int* n_obj_cls,
-                             float code_lr, float code_weight_decay, void* stream) {
+extern "C" int cnr_step_tail(const cnr_step_tail_args* args, void* stream) {
+  if (!args || args->struct_size != sizeof(cnr_step_tail_args) || args->abi_version != CNR_ABI_VERSION) return CNR_E_ARG;
+  const float* theta_in = args->theta_in; float* theta_out = args->theta_out; float* grad = args->grad;
+  float* exp_avg = args->exp_avg; float* exp_avg_sq = args->exp_avg_sq;
+  const int64_t class_stride = args->class_stride, off_B = args->off_B, off_latW = args->off_latW, off_latb = args->off_latb,
+                off_shape = args->off_shape, off_tex = args->off_tex, add_rows = args->add_rows, pool_rows = args->pool_rows;
+  const int L = args->L, n_obj = args->n_obj, C = args->C, do_latent = args->do_latent, R = args->R, nwg = args->nwg,
+            rl_blocks = args->rl_blocks;
+  const float* zl = args->zl; float* dbiasrows = args->dbiasrows;
+  const float reg_scale = args->reg_scale, lr = args->lr, beta1 = args->beta1, beta2 = args->beta2, eps = args->eps,
+              weight_decay = args->weight_decay, code_lr = args->code_lr, code_weight_decay = args->code_weight_decay;
+  const int64_t* state_cur = args->state_cur; int64_t* state_next = args->state_next;
+  const void* rl_workspace = args->rl_workspace; float* losses = args->losses; int32_t* flags = args->flags;
+  const float* depth = args->depth; const int* perm = args->perm; float* next_max_bound = args->next_max_bound;
+  const void* records = args->records; const long long* rows_fix = args->rows_fix; int* clamp_flags = args->clamp_flags;
+  const int* n_obj_cls = args->n_obj_cls;
   if (!theta_in || !theta_out || theta_in == theta_out || !grad || !exp_avg || !exp_avg_sq || class_stride <= 0 ||
       L <= 0 || n_obj <= 0 || C <= 0 || !state_cur || !state_next || state_cur == state_next || !rl_workspace ||
       !losses || !flags || R <= 0)

@@ -92,7 +92,8 @@ class FusedCategoryTrainer:
     def __init__(self, cfg, n_cls, n_obj, pools, rays_per_step, device, seed=0, generator=None,
                  grad_scale=None, bwd_blocks=0, process_group=None, use_graph=True, split_graph=False,
                  fuse_render=True, split_weights=None, shard=None, n_cls_global=None, class_ids=None,
-                 check_every=0, world_frame=None, dp_rank=None, dp_world=None, one_launch=None, unroll=16):
+                 check_every=0, world_frame=None, dp_rank=None, dp_world=None, one_launch=None, unroll=16,
+                 precise_geometry=None):
         # n_obj: one count for every class, or one per (local) class -- the reference's categories differ (train.py:92-96).  The
         # flat layout uses the largest; a smaller class keeps unused rows (no ray refers to them, no regulariser on them)
         n_obj_list = [int(n_obj)] * n_cls if isinstance(n_obj, int) else [int(v) for v in n_obj]
@@ -205,10 +206,17 @@ class FusedCategoryTrainer:
         self.dbias = self._gbuf[n_th:n_th + n_db].view(n_cls * n_obj, 4, 32)
         self._nwg = int(_C.load().cnr_field_bwd_pipe_blocks(self.R, self.S, int(ops.FIELD_BWD_VARIANT[-1]), self.bwd_blocks)) \
             if self.use_records else 0
-        # split-weight forward (f16(W) + f16(W - f16(W)), two MFMAs per fragment): occupancy error 6.7e-4 -> 3.9e-4 at
-        # configs[1] for +2.7 us per step; off by default, CNR_SPLIT_WEIGHTS=1 or split_weights=True turns it on
-        self.split_weights = bool(int(os.environ.get("CNR_SPLIT_WEIGHTS", "0"))) if split_weights is None \
-            else bool(split_weights)
+        # Precise geometry branch (default ON): the layers between the sample and the x10 occupancy logit as three f16
+        # products per fragment, Wh xh + Wl xh + Wh xl (include/cnr_hip.h, cnr_pack_weights_lo).  Plain f16 operands hold
+        # north_star's 1e-3 on the occupancy only at initialisation (6.7e-4); after 400 / 5000 training steps they give
+        # 1.8e-3 / 2.0e-3 (the logit reaches hundreds), the three-product form 2e-6 (tests/test_trained_parity_gpu.py,
+        # DESIGN.md section 3.3).  precise_geometry=False / CNR_PRECISE_GEOMETRY=0: the plain-f16 forward, for the cost
+        # comparison only.  (split_weights: the former name of the option.)
+        if precise_geometry is None:
+            precise_geometry = split_weights
+        self.precise = bool(int(os.environ.get("CNR_PRECISE_GEOMETRY", "1"))) if precise_geometry is None \
+            else bool(precise_geometry)
+        self.split_weights = self.precise
         # forward + render/loss in one launch where the shape allows (S a multiple of 32 up to 128), else two launches
         self._rl_blocks = int(_C.load().cnr_field_fwd_render_blocks(self.R, self.S)) if fuse_render else 0
         # ... and forward + render / loss + the whole backward in ONE launch (cnr_field_train, the 8-wave kernel's record
@@ -219,7 +227,7 @@ class FusedCategoryTrainer:
         slots = 16 if self.S <= 16 else 32 if self.S <= 32 else 64 if self.S <= 64 else 128
         one = one and self.S <= 128 and self.S >= 0.6 * slots
         self._ft_blocks = int(_C.load().cnr_field_train_blocks(self.R, self.S, self.bwd_blocks)) \
-            if (one and fuse_render and self.use_records and ops.FIELD_BWD_VARIANT == "pipe4" and not self.split_weights) else 0
+            if (one and fuse_render and self.use_records and ops.FIELD_BWD_VARIANT == "pipe4") else 0
         if self._ft_blocks:
             self._nwg = self._ft_blocks
         self.use_graph = use_graph
@@ -256,6 +264,9 @@ class FusedCategoryTrainer:
             o["zl"] = torch.empty(C * n_obj, 4, 32, **kw)
             o["brows"] = torch.empty(C * n_obj, 4, 32, **kw)
             o["packed"] = torch.empty(C, _C.pack_bytes(), device=self.device, dtype=torch.uint8)
+            # residual weight image of the geometry branch, rebuilt from theta by the step's first launch like `packed`
+            o["packed_lo"] = torch.empty(C, int(_C.load().cnr_pack_lo_bytes()), device=self.device, dtype=torch.uint8) \
+                if self.precise else None
             o["sig"] = torch.empty(C, R, S, **kw)
             o["rgbs"] = torch.empty(C, R, S, 3, **kw)
             for name, shape in (("depth", (C, R)), ("var", (C, R)), ("rgb", (C, R, 3)), ("opa", (C, R)),
@@ -284,24 +295,16 @@ class FusedCategoryTrainer:
                               self.pool["depth"], self.pool["dirs"], self.pool["T"], self.n1, self.n2, cfg.surface_eps,
                               cfg.stop_eps, cfg.min_depth, self.seed, self.d_state2[self.parity], R, self.bufs,
                               self.slice_max, self.pool["indices"], self.perm, max_bound_slices=self.n_slices,
-                              rng=self._rng_map())
+                              rng=self._rng_map(), packed_lo=o["packed_lo"])
         ray_row = b["ray_row"]
-        lo = None
-        if self.split_weights:
-            if "packed_lo" not in o:
-                o["packed_lo"] = torch.empty(C, int(_C.load().cnr_pack_lo_bytes()), device=self.device, dtype=torch.uint8)
-            lo = o["packed_lo"]
-            _C.call("cnr_pack_weights_lo", v["trunk"] if C == 1 else v["trunk"].contiguous(), lo, C)
+        lo = o["packed_lo"]
         # the loss gradient of a ray carries 1 / (GLOBAL mask count of its class) out of counts_tab: ray shards add up to
         # the whole batch's gradient, nothing to rescale; the code regulariser is formed on every ray shard -> 1 / world
         inv_w = 1.0
         st = self.d_state2[self.parity]
         if self._ft_blocks:
             # a8-a15 forward, losses, their gradient and the field backward in ONE launch
-            _C.call("cnr_field_train", b["pts"], Bc, packed, brows, ray_row, self.scale, b["z"], b["gt_depth"], b["gt_rgb"],
-                    b["labels"], b["depth_mask"], self.counts_tab, st, 5.0, 10.0, inv_w, self.grad_scale, o["depth"],
-                    o["var"], o["rgb"], o["opa"], C, R, S, n_obj, self.bwd_blocks, o["bwd_ws"], o["bwd_ws"].numel(),
-                    o["rl_ws"], o["rl_ws"].numel(), P, self.rows_fix, self.clamp)
+            _C.call_struct("cnr_field_train", **self._field_train_args(b, o, Bc, st, inv_w, self.rows_fix, self.clamp))
         elif self._rl_blocks:
             # a8-a15 in one launch (S = 32 k): field forward, composite, losses, their gradient, composite backward;
             # sigma / colour per sample never leave registers
@@ -330,6 +333,16 @@ class FusedCategoryTrainer:
             else:
                 _C.call("cnr_latent_bwd", self.theta, *lat_args, zl, self.dbias, self._reg, self.grad, self.n_obj_cls)
 
+    def _field_train_args(self, b, o, Bc, st, loss_scale, rows_fix, clamp):
+        """the argument block of cnr_field_train on the live buffers of a step (include/cnr_hip.h, cnr_field_train_args)"""
+        return dict(pts=b["pts"], B=Bc, packed=o["packed"], packed_lo=o["packed_lo"], biasrows=o["brows"], ray_row=b["ray_row"],
+                    scale=self.scale, z=b["z"], gt_depth=b["gt_depth"], gt_rgb=b["gt_rgb"], labels=b["labels"],
+                    depth_mask=b["depth_mask"], counts_tab=self.counts_tab, d_state=st, color_scaling=5.0, opacity_scaling=10.0,
+                    loss_scale=float(loss_scale), grad_scale=self.grad_scale, depth=o["depth"], var=o["var"], rgb=o["rgb"],
+                    opacity=o["opa"], C=self.C, R=self.R, S=self.S, rows_per_class=self.n_obj, max_blocks=self.bwd_blocks,
+                    records=o["bwd_ws"], records_bytes=o["bwd_ws"].numel(), loss_workspace=o["rl_ws"],
+                    loss_workspace_bytes=o["rl_ws"].numel(), B_stride=self.lay.total, rows_fix=rows_fix, clamp_flags=clamp)
+
     def _step_back(self):
         """Last launch (cnr_step_tail): the fixed-order reduction of the field backward's records (single GPU, <= 15
         objects per class; otherwise cnr_field_bwd_pipe did it), latent backward + code regulariser (single GPU; with a
@@ -338,16 +351,18 @@ class FusedCategoryTrainer:
         flags from the render kernel's partials, the next slice's max depth, next step state into the other state
         copy) -- side by side in one grid."""
         C, R, o, par, lay = self.C, self.R, self.bufs, self.parity, self.lay
-        _C.call("cnr_step_tail", self.theta2[par], self.theta2[1 - par], self.grad, self.exp_avg, self.exp_avg_sq,
-                lay.total, lay.B[0], lay.latW[0], lay.latb[0], lay.shape[0], lay.tex[0], self.L, self.n_obj, C,
-                o["zl"], self.dbias, self._reg, 0 if self.grad_exchange else 1, self.lr, 0.9, 0.999, 1e-8, self.wd,
-                self.d_state2[par], self.d_state2[1 - par], self.Rg, o["rl_ws"],
-                self.losses if self._out_slot is None else self._loss_hist[self._out_slot],
-                self.flags if self._out_slot is None else self._flags_hist[self._out_slot],
-                None, self.pool_rows, None, None, R,
-                o["bwd_ws"] if self.fused_tail else None, self._nwg if self.fused_tail else 0,
-                self.rows_fix if self.fused_tail else None, self._ft_blocks or self._rl_blocks, self.clamp, self.n_obj_cls,
-                self.code_lr, self.code_wd)
+        _C.call_struct(
+            "cnr_step_tail", theta_in=self.theta2[par], theta_out=self.theta2[1 - par], grad=self.grad, exp_avg=self.exp_avg,
+            exp_avg_sq=self.exp_avg_sq, class_stride=lay.total, off_B=lay.B[0], off_latW=lay.latW[0], off_latb=lay.latb[0],
+            off_shape=lay.shape[0], off_tex=lay.tex[0], L=self.L, n_obj=self.n_obj, C=C, zl=o["zl"], dbiasrows=self.dbias,
+            reg_scale=self._reg, do_latent=0 if self.grad_exchange else 1, lr=self.lr, beta1=0.9, beta2=0.999, eps=1e-8,
+            weight_decay=self.wd, state_cur=self.d_state2[par], state_next=self.d_state2[1 - par], add_rows=self.Rg,
+            rl_workspace=o["rl_ws"], losses=self.losses if self._out_slot is None else self._loss_hist[self._out_slot],
+            flags=self.flags if self._out_slot is None else self._flags_hist[self._out_slot], depth=None,
+            pool_rows=self.pool_rows, perm=None, next_max_bound=None, R=R,
+            records=o["bwd_ws"] if self.fused_tail else None, nwg=self._nwg if self.fused_tail else 0,
+            rows_fix=self.rows_fix if self.fused_tail else None, rl_blocks=self._ft_blocks or self._rl_blocks,
+            clamp_flags=self.clamp, n_obj_cls=self.n_obj_cls, code_lr=self.code_lr, code_weight_decay=self.code_wd)
 
     def step(self):
         """One train step.  Returns nothing; ``self.losses`` (3,C) / ``self.flags`` (C,) hold the device-side
@@ -513,10 +528,8 @@ class FusedCategoryTrainer:
         fix = torch.zeros_like(self.rows_fix)
         clamp = torch.zeros_like(self.clamp)
         st = self.d_state2[self.parity]
-        run = lambda: _C.call("cnr_field_train", b["pts"], Bc, o["packed"], o["brows"], b["ray_row"], self.scale, b["z"],
-                              b["gt_depth"], b["gt_rgb"], b["labels"], b["depth_mask"], self.counts_tab, st, 5.0, 10.0, 1.0,
-                              self.grad_scale, o["depth"], o["var"], o["rgb"], o["opa"], C, R, S, self.n_obj, self.bwd_blocks,
-                              o["bwd_ws"], o["bwd_ws"].numel(), o["rl_ws"], o["rl_ws"].numel(), lay.total, fix, clamp)
+        args = self._field_train_args(b, o, Bc, st, 1.0, fix, clamp)
+        run = lambda: _C.call_struct("cnr_field_train", **args)
         for _ in range(3):
             run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

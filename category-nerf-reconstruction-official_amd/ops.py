@@ -271,7 +271,7 @@ def sample_rays(rgbs, depth, dirs_c, T, n1, n2, eps, stop_eps, min_bound=0.0, wo
 
 def step_prologue(theta, lay, L, n_obj, packed, zl, brows, zero_buf, rgbs, depth, dirs_c, T, n1, n2, eps, stop_eps,
                   min_bound, seed, d_state, rays, out, max_bound, pool_indices, perm, max_bound_slices=0,
-                  rng=(0, 0, 0, 0)):
+                  rng=(0, 0, 0, 0), packed_lo=None):
     """cnr_step_prologue: the parameter-only jobs (pack | latent rows | gradient zero fill) and the sampler of one
     fused-trainer step in ONE launch.  Same outputs dict as :func:`sample_rays` (device pools, device cursor).
     max_bound: (C,) max depth of this step's slice, or with max_bound_slices = k > 1 a (C, k) table over the epoch's
@@ -286,11 +286,15 @@ def step_prologue(theta, lay, L, n_obj, packed, zl, brows, zero_buf, rgbs, depth
     gt, gd = buf("gt_rgb", (C, R, 3)), buf("gt_depth", (C, R))
     dm, lab = buf("depth_mask", (C, R), torch.uint8), buf("labels", (C, R), torch.uint8)
     rr = buf("ray_row", (C, R), torch.int32)
-    _C.call("cnr_step_prologue", theta, lay.total, lay.trunk[0], lay.latW[0], lay.latb[0], lay.shape[0], lay.tex[0],
-            L, n_obj, C, packed, zl, brows, zero_buf, zero_buf.numel(),
-            rgbs, depth, dirs_c, T, None, None, int(seed), 0, d_state, depth.shape[1], max_bound, 0, R, n1, n2,
-            float(eps), float(stop_eps), float(min_bound), z, pts, None, None, gt, gd, dm, lab, pool_indices, rr, perm,
-            int(max_bound_slices), int(rng[0]), int(rng[1]), int(rng[2]), int(rng[3]))
+    _C.call_struct("cnr_step_prologue", theta=theta, class_stride=lay.total, off_trunk=lay.trunk[0], off_latW=lay.latW[0],
+                   off_latb=lay.latb[0], off_shape=lay.shape[0], off_tex=lay.tex[0], L=L, n_obj=n_obj, C=C, packed=packed,
+                   packed_lo=packed_lo, zl=zl, biasrows=brows, zero_buf=zero_buf, zero_count=zero_buf.numel(),
+                   rgbs=rgbs, depth=depth, dirs_c=dirs_c, T=T, u=None, g=None, seed=int(seed), offset=0, d_state=d_state,
+                   pool_rows=depth.shape[1], max_bound=max_bound, world_frame=0, R=R, n1=n1, n2=n2, eps=float(eps),
+                   stop_eps=float(stop_eps), min_bound=float(min_bound), z=z, pts=pts, origins=None, dirs_o=None, gt_rgb=gt,
+                   gt_depth=gd, depth_mask=dm, labels=lab, pool_indices=pool_indices, ray_row=rr, perm=perm,
+                   max_bound_slices=int(max_bound_slices), rng_c0=int(rng[0]), rng_cstride=int(rng[1]), rng_R=int(rng[2]),
+                   rng_r0=int(rng[3]))
     return out
 
 

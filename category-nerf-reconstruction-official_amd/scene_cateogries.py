@@ -36,7 +36,7 @@ def origin_dirs_W(T_WC, dirs_C):
     return T_WC[:, :3, -1], (T_WC[:, :3, :3] @ dirs_C[..., None]).squeeze(-1)
 
 
-def stratified_bins(min_depth, max_depth, n_bins, n_rays, type=torch.float32, device="cuda:0", z_fixed=False):
+def stratified_bins(min_depth, max_depth, n_bins, n_rays, type=torch.float32, device="cuda:0", z_fixed=False, generator=None):
     """src/scene_cateogries.py:51-81 (stand-alone form; the train step samples in cnr_sample_rays)."""
     lim = torch.linspace(0, 1, n_bins + 1, dtype=type, device=device)
     if not torch.is_tensor(min_depth):
@@ -48,7 +48,7 @@ def stratified_bins(min_depth, max_depth, n_bins, n_rays, type=torch.float32, de
     assert lower.shape == (n_rays, n_bins)
     # z_fixed is accepted and IGNORED, as in the reference (its fixed-z branch is commented out, :70-72): the probe
     # rays of category_registration.py:145 are jittered too
-    return lower + torch.rand(n_rays, n_bins, device=device, dtype=torch.float32) * (rng / n_bins)[..., None]
+    return lower + torch.rand(n_rays, n_bins, device=device, dtype=torch.float32, generator=generator) * (rng / n_bins)[..., None]
 
 
 def normal_bins_sampling(depth, n_bins, n_rays, delta, device="cuda:0"):
@@ -63,15 +63,19 @@ def normal_bins_sampling(depth, n_bins, n_rays, delta, device="cuda:0"):
 class cameraInfo:
     """src/scene_cateogries.py:600-629: pinhole directions, z-depth convention (not normalised)."""
 
-    def __init__(self, cfg) -> None:
+    def __init__(self, cfg, device="cpu") -> None:
+        """``device``: where the (W,H,3) cache is built and kept (the reference keeps it on the CPU, :617; pool construction
+        here is a device gather, so a device cache saves the upload)."""
         self.width, self.height = cfg.W, cfg.H
         self.fx, self.fy, self.cx, self.cy = cfg.fx, cfg.fy, cfg.cx, cfg.cy
+        self.device = torch.device(device)
         self.rays_dir_cache = self.get_rays_dirs()
 
     def get_rays_dirs(self, depth_type="z"):
-        dirs = torch.ones((self.width, self.height, 3))
-        dirs[:, :, 0] = ((torch.arange(end=self.width) - self.cx) / self.fx)[:, None]
-        dirs[:, :, 1] = ((torch.arange(end=self.height) - self.cy) / self.fy)
+        dev = self.device
+        dirs = torch.ones((self.width, self.height, 3), device=dev)
+        dirs[:, :, 0] = ((torch.arange(end=self.width, device=dev) - self.cx) / self.fx)[:, None]
+        dirs[:, :, 1] = ((torch.arange(end=self.height, device=dev) - self.cy) / self.fy)
         if depth_type == "euclidean":   # the reference raises here as well (:623-626)
             raise Exception("Get camera rays directions with euclidean depth not yet implemented")
         return dirs

@@ -170,10 +170,15 @@ int cnr_pack_weights(const float* trunk, void* packed, int C, void* stream);
 
 /* pts (C,R,S,3), B (C,21,3), packed (C,cnr_pack_bytes()), biasrows (rows,4,32) -> sigmas (C,R,S) = raw*10,
  * rgbs (C,R,S,3).  f16 MFMA operands / fp32 accumulate, fp32 PE, fp32 sigma head.  Any S. */
-/* Split-weight forward (packed_lo != NULL in cnr_field_fwd / cnr_field_fwd_render): every weight fragment is used as
- * f16(W) + f16(W - f16(W)), two MFMAs, which removes the weight-rounding share of the f16 error (activations stay
- * f16).  packed_lo: (C, cnr_pack_lo_bytes()) from cnr_pack_weights_lo(trunk (C,13892), ...).  The backward kernels
- * recompute with f16(W) alone. */
+/* Precise geometry branch (packed_lo != NULL in cnr_field_fwd / cnr_field_fwd_render / cnr_field_train): the layers
+ * between the sample position and the x10 occupancy logit (encoding_xyz, shape_layer_1, cat_layer, shape_layer_2,
+ * encoding_shape; src/model.py:56-75) are computed as THREE f16 products per fragment,
+ *     W x ~= Wh xh + Wl xh + Wh xl,   Wh = f16(W), Wl = f16(W - Wh), xh = f16(x), xl = f16(x - xh),   fp32 accumulate,
+ * i.e. with ~22 mantissa bits on both operands; the colour branch stays plain f16.  Needed for north_star's 1e-3 on the
+ * occupancy of TRAINED models: the logit reaches several hundred, and plain f16 operands then give 1.8e-3 .. 2.0e-3
+ * (weights and activations contribute equally; splitting either alone leaves 1.2e-3 .. 1.6e-3), this form 2e-6.
+ * packed_lo: (C, cnr_pack_lo_bytes()) = the 20 residual fragments Wl of those layers, from cnr_pack_weights_lo(trunk
+ * (C,13892), ...) or cnr_step_prologue.  The backward's data-gradient chain uses f16(W) alone. */
 int64_t cnr_pack_lo_bytes(void);
 int cnr_pack_weights_lo(const float* trunk, void* packed_lo, int C, void* stream);
 
@@ -278,19 +283,73 @@ int cnr_slice_maskcounts(const uint8_t* rgbs, const float* depth, const int* per
 int cnr_slice_maxdepth(const float* depth, const int* perm, int64_t pool_rows, int C, int R, int slices, float* out,
                        void* stream);
 
-/* cnr_param_prep and cnr_sample_rays side by side in ONE launch (same arguments, in that order; max_bound must be
- * given here, max_bound_slices = 0 or 1 for the per-class form): the sampler needs the ray pool and the step state only, so the first node of the fused trainer's step
- * runs it beside the parameter-only jobs instead of after them. */
-int cnr_step_prologue(const float* theta, int64_t class_stride, int64_t off_trunk, int64_t off_latW, int64_t off_latb,
-                      int64_t off_shape, int64_t off_tex, int L, int n_obj, int C, void* packed, float* zl,
-                      float* biasrows, float* zero_buf, int64_t zero_count,
-                      const uint8_t* rgbs, const float* depth, const float* dirs_c, const float* T, const float* u,
-                      const float* g, uint64_t seed, uint64_t offset, const int64_t* d_state, int64_t pool_rows,
-                      const float* max_bound, int world_frame, int R, int n1, int n2, float eps, float stop_eps,
-                      float min_bound, float* z, float* pts, float* origins, float* dirs_o, float* gt_rgb,
-                      float* gt_depth, uint8_t* depth_mask, uint8_t* labels, const int64_t* pool_indices,
-                      int* ray_row, const int* perm, int max_bound_slices, int rng_c0, int rng_cstride, int rng_R,
-                      int rng_r0, void* stream);
+/* ---- versioned argument blocks -----------------------------------------------------------------------------------------
+ * The three launches of the fused trainer's step (cnr_step_prologue -> cnr_field_train -> cnr_step_tail) take their
+ * arguments as ONE struct by pointer instead of 35-50 positional values: `struct_size` = sizeof(the struct) and
+ * `abi_version` = CNR_ABI_VERSION come first and the entry point returns CNR_E_ARG for any other value, so a caller
+ * compiled (or a ctypes table written) against another revision of this header is refused instead of reading shifted
+ * fields.  Field meaning is the positional entry points' of the calls they fuse (cnr_param_prep / cnr_sample_rays, ...). */
+#define CNR_ABI_VERSION 3
+
+/* cnr_param_prep and cnr_sample_rays side by side in ONE launch (max_bound must be given here, max_bound_slices = 0 or 1
+ * for the per-class form): the sampler needs the ray pool and the step state only, so the first node of the fused
+ * trainer's step runs it beside the parameter-only jobs instead of after them.  packed_lo (optional,
+ * (C, cnr_pack_lo_bytes())): the residual image of the geometry branch (cnr_pack_weights_lo) is built in the same launch. */
+typedef struct cnr_step_prologue_args {
+  uint32_t struct_size;
+  uint32_t abi_version;
+  const float* theta;
+  int64_t class_stride;
+  int64_t off_trunk;
+  int64_t off_latW;
+  int64_t off_latb;
+  int64_t off_shape;
+  int64_t off_tex;
+  int32_t L;
+  int32_t n_obj;
+  int32_t C;
+  void* packed;
+  void* packed_lo;
+  float* zl;
+  float* biasrows;
+  float* zero_buf;
+  int64_t zero_count;
+  const uint8_t* rgbs;
+  const float* depth;
+  const float* dirs_c;
+  const float* T;
+  const float* u;
+  const float* g;
+  uint64_t seed;
+  uint64_t offset;
+  const int64_t* d_state;
+  int64_t pool_rows;
+  const float* max_bound;
+  int32_t world_frame;
+  int32_t R;
+  int32_t n1;
+  int32_t n2;
+  float eps;
+  float stop_eps;
+  float min_bound;
+  float* z;
+  float* pts;
+  float* origins;
+  float* dirs_o;
+  float* gt_rgb;
+  float* gt_depth;
+  uint8_t* depth_mask;
+  uint8_t* labels;
+  const int64_t* pool_indices;
+  int32_t* ray_row;
+  const int32_t* perm;
+  int32_t max_bound_slices;
+  int32_t rng_c0;
+  int32_t rng_cstride;
+  int32_t rng_R;
+  int32_t rng_r0;
+} cnr_step_prologue_args;
+int cnr_step_prologue(const cnr_step_prologue_args* args, void* stream);
 /* rng_*: the Philox counter of ray r of local class c is ((c * rng_cstride + rng_c0) * rng_R + rng_r0 + r) * 64 + lane,
  * i.e. the ray's index in the GLOBAL batch when classes (rng_c0 = rank, rng_cstride = ranks) or rays (rng_R = global rays
  * per class, rng_r0 = rank * R) are sharded over GPUs: N ranks then draw exactly the samples one rank would.  All zero:
@@ -351,15 +410,53 @@ int cnr_adamw_epilogue(float* param, const float* grad, float* exp_avg, float* e
  * rl_blocks: loss partials per class in rl_workspace; 0 = cnr_render_loss's own block count.
  * code_lr > 0: the shape / texture code tables are an AdamW group of their own (code_lr, code_weight_decay: train.py:40,
  * 54-64, configs' code_lr / code_weight_decay); 0 = they share lr / weight_decay. */
-int cnr_step_tail(const float* theta_in, float* theta_out, float* grad, float* exp_avg, float* exp_avg_sq,
-                  int64_t class_stride, int64_t off_B, int64_t off_latW, int64_t off_latb, int64_t off_shape,
-                  int64_t off_tex, int L, int n_obj, int C, const float* zl, float* dbiasrows, float reg_scale,
-                  int do_latent, float lr, float beta1, float beta2, float eps, float weight_decay,
-                  const int64_t* state_cur, int64_t* state_next, int64_t add_rows, const void* rl_workspace,
-                  float* losses, int32_t* flags, const float* depth, int64_t pool_rows, const int* perm,
-                  float* next_max_bound, int R, const void* records, int nwg, const long long* rows_fix,
-                  int rl_blocks, int* clamp_flags, const int* n_obj_cls, float code_lr, float code_weight_decay,
-                  void* stream);
+typedef struct cnr_step_tail_args {
+  uint32_t struct_size;
+  uint32_t abi_version;
+  const float* theta_in;
+  float* theta_out;
+  float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  int64_t class_stride;
+  int64_t off_B;
+  int64_t off_latW;
+  int64_t off_latb;
+  int64_t off_shape;
+  int64_t off_tex;
+  int32_t L;
+  int32_t n_obj;
+  int32_t C;
+  const float* zl;
+  float* dbiasrows;
+  float reg_scale;
+  int32_t do_latent;
+  float lr;
+  float beta1;
+  float beta2;
+  float eps;
+  float weight_decay;
+  const int64_t* state_cur;
+  int64_t* state_next;
+  int64_t add_rows;
+  const void* rl_workspace;
+  float* losses;
+  int32_t* flags;
+  const float* depth;
+  int64_t pool_rows;
+  const int32_t* perm;
+  float* next_max_bound;
+  int32_t R;
+  const void* records;
+  int32_t nwg;
+  const long long* rows_fix;
+  int32_t rl_blocks;
+  int32_t* clamp_flags;
+  const int32_t* n_obj_cls;
+  float code_lr;
+  float code_weight_decay;
+} cnr_step_tail_args;
+int cnr_step_tail(const cnr_step_tail_args* args, void* stream);
 /* clamp_flags (optional, (C,) int32, zero before the first step): what cnr_field_bwd_pipe raised during this step -- bit 4
  * (16) = a scaled upstream gradient |d sigma| * grad_scale exceeded 8192 and was clipped for the f16 chain; the epilogue
  * or-s the word into flags[c] and clears it. */
@@ -423,13 +520,47 @@ int cnr_field_fwd_fp8(const float* pts, const float* B, const void* packed, cons
  * cnr_field_train_blocks().  Returns CNR_E_SHAPE for S > 128 or more than 15 rows per class (use the two calls). */
 int cnr_field_train_blocks(int R, int S, int max_blocks);
 int64_t cnr_field_train_workspace_bytes(int C, int R, int S, int max_blocks);
-int cnr_field_train(const float* pts, const float* B, const void* packed, const float* biasrows, const int* ray_row,
-                    float scale, const float* z, const float* gt_depth, const float* gt_rgb, const uint8_t* labels,
-                    const uint8_t* depth_mask, const float* counts_tab, const int64_t* d_state, float color_scaling,
-                    float opacity_scaling, float loss_scale, float grad_scale, float* depth, float* var, float* rgb,
-                    float* opacity, int C, int R, int S, int rows_per_class, int max_blocks, void* records,
-                    int64_t records_bytes, void* loss_workspace, int64_t loss_workspace_bytes, int64_t B_stride,
-                    long long* rows_fix, int* clamp_flags, void* stream);
+/* packed_lo (optional, (C, cnr_pack_lo_bytes()) from cnr_pack_weights_lo / cnr_step_prologue): the forward's geometry
+ * branch as three products per fragment (see cnr_pack_weights_lo) -- the trainer's default; NULL: plain f16 operands. */
+typedef struct cnr_field_train_args {
+  uint32_t struct_size;
+  uint32_t abi_version;
+  const float* pts;
+  const float* B;
+  const void* packed;
+  const void* packed_lo;
+  const float* biasrows;
+  const int32_t* ray_row;
+  float scale;
+  const float* z;
+  const float* gt_depth;
+  const float* gt_rgb;
+  const uint8_t* labels;
+  const uint8_t* depth_mask;
+  const float* counts_tab;
+  const int64_t* d_state;
+  float color_scaling;
+  float opacity_scaling;
+  float loss_scale;
+  float grad_scale;
+  float* depth;
+  float* var;
+  float* rgb;
+  float* opacity;
+  int32_t C;
+  int32_t R;
+  int32_t S;
+  int32_t rows_per_class;
+  int32_t max_blocks;
+  void* records;
+  int64_t records_bytes;
+  void* loss_workspace;
+  int64_t loss_workspace_bytes;
+  int64_t B_stride;
+  long long* rows_fix;
+  int32_t* clamp_flags;
+} cnr_field_train_args;
+int cnr_field_train(const cnr_field_train_args* args, void* stream);
 
 #ifdef __cplusplus
 }

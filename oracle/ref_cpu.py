@@ -313,3 +313,39 @@ def forward_loss(mlp, pe_B, scale, shape_tables, texture_tables, batch, reg_scal
                opacity=opacity, loss_depth=ld["depth"], loss_color=ld["color"],
                loss_opacity=ld["opacity"], reg_shape=rs, reg_texture=rt)
     return loss, aux
+
+
+# ----------------------------------------------------------------------------------------------
+# forward-only consumer: the uncertainty probe of category registration
+# ----------------------------------------------------------------------------------------------
+def calculate_reliability(metric, eta=0.9, m1=0.1, m2=0.15, M1=0.57, M2=0.65):
+    """src/utils.py:553-559."""
+    alpha_m = 2 * math.log(eta / (1 - eta)) / (m2 - m1)
+    beta_m = (m1 + m2) / 2
+    alpha_M = 2 * math.log(eta / (1 - eta)) / (M2 - M1)
+    beta_M = (M1 + M2) / 2
+    return 1 / (1 + torch.exp(alpha_m * (metric - beta_m))) + 1 / (1 + torch.exp(-alpha_M * (metric - beta_M)))
+
+
+def uncertainty_probe(p, pe_B, scale, center, r, u):
+    """src/category_registration.py:96-107,131-159 for ONE pretrained object: p = OccupancyMap state dict (one model, no class
+    dim), pe_B (1,21,3), center (3,), r scalar, u (10000, 96) the jitter draws of stratified_bins.  Returns termination
+    (10000,96), ray entropies, and 1 - reliability of opacity * exp(-entropy / 2)."""
+    phi = torch.linspace(0, math.pi, 100)
+    theta = torch.linspace(0, 2 * math.pi, 100)
+    phi, theta = torch.meshgrid(phi, theta, indexing="ij")
+    phi, theta = phi.t(), theta.t()
+    x = r * torch.sin(phi) * torch.cos(theta)
+    y = r * torch.sin(phi) * torch.sin(theta)
+    zc = r * torch.cos(phi)
+    rays_o_o = torch.stack([x, y, zc], dim=-1).reshape(-1, 3)
+    viewdir = -rays_o_o / r
+    rays_o = center + rays_o_o
+    z_vals = stratified_bins(0.0, 2 * r, 96, rays_o.shape[0], u)
+    xyz = rays_o[..., None, :] + viewdir[:, None, :] * z_vals[..., None]
+    sigmas, _ = occupancy_map_forward(p, unidirs_embed(xyz[None], pe_B, scale)[0])
+    occ = torch.sigmoid(10 * sigmas.squeeze(-1))
+    term = occupancy_to_termination(occ)
+    ent = torch.sum(-term * torch.log(term + 1e-10), dim=-1)
+    heuristic = term.sum(-1) * torch.exp(-0.5 * ent)
+    return term, ent, 1 - calculate_reliability(heuristic)

@@ -62,6 +62,89 @@ def test_ctypes_table_matches_header():
                 assert ct is ctypes.c_int, (name, decl)
 
 
+def declared_structs():
+    """typedef struct NAME_args { type field; ... } NAME_args;  ->  {NAME: [(field, c type text), ...]}"""
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    out = {}
+    for m in re.finditer(r"typedef\s+struct\s+(cnr_\w+)_args\s*\{(.*?)\}\s*\1_args\s*;", src, flags=re.S):
+        fields = []
+        for decl in m.group(2).split(";"):
+            decl = " ".join(decl.split())
+            if decl:
+                typ, name = decl.rsplit(" ", 1)
+                if name.startswith("*"):
+                    typ, name = typ + "*", name.lstrip("*")
+                fields.append((name, typ))
+        out[m.group(1)] = fields
+    return out
+
+
+def test_argument_blocks_match_the_header():
+    """The versioned argument structs: same fields, order and C types in include/cnr_hip.h and in the ctypes table, and the
+    same size as the C compiler gives the header's typedef."""
+    import subprocess
+    import tempfile
+    import cnr_amd
+    _C = cnr_amd._C
+    structs = declared_structs()
+    assert set(structs) == set(_C.STRUCTS) and len(structs) == 3
+    ctype_of = {"float": ctypes.c_float, "int32_t": ctypes.c_int32, "uint32_t": ctypes.c_uint32, "int64_t": ctypes.c_int64,
+                "uint64_t": ctypes.c_uint64}
+    for name, fields in structs.items():
+        assert fields[0] == ("struct_size", "uint32_t") and fields[1] == ("abi_version", "uint32_t"), name
+        assert [f for f, _ in fields[2:]] == [f for f, _ in _C.STRUCTS[name]], name
+        for (f, typ), (_, ct) in zip(fields[2:], _C.STRUCTS[name]):
+            assert ct is (ctypes.c_void_p if "*" in typ else ctype_of[typ]), (name, f, typ)
+    src = '#include <stdio.h>\n#include "cnr_hip.h"\nint main(void){printf("%zu %zu %zu %d", sizeof(cnr_step_prologue_args), ' \
+          'sizeof(cnr_step_tail_args), sizeof(cnr_field_train_args), CNR_ABI_VERSION);return 0;}'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "s.c"), "w").write(src)
+        subprocess.run(["gcc", "-I", os.path.dirname(HEADER), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")], check=True)
+        a, b, c, ver = (int(v) for v in subprocess.run([os.path.join(d, "s")], capture_output=True, text=True).stdout.split())
+    assert (a, b, c) == tuple(ctypes.sizeof(_C.struct_type(n)) for n in ("cnr_step_prologue", "cnr_step_tail", "cnr_field_train"))
+    assert ver == _C.ABI_VERSION
+
+
+def test_argument_blocks_of_another_revision_are_refused(lib):
+    """struct_size / abi_version that do not match this library: CNR_E_ARG before anything else is read."""
+    import cnr_amd
+    _C = cnr_amd._C
+    for name in _C.STRUCTS:
+        fn = getattr(lib, name)
+        fn.argtypes, fn.restype = [ctypes.c_void_p, ctypes.c_void_p], ctypes.c_int
+        st = _C.struct_type(name)()
+        st.struct_size, st.abi_version = ctypes.sizeof(st) - 8, _C.ABI_VERSION
+        assert fn(ctypes.byref(st), None) == -1, name
+        st.struct_size, st.abi_version = ctypes.sizeof(st), _C.ABI_VERSION + 1
+        assert fn(ctypes.byref(st), None) == -1, name
+        assert fn(None, None) == -1, name
+        st.struct_size, st.abi_version = ctypes.sizeof(st), _C.ABI_VERSION      # right revision, all-NULL fields: still an error code
+        assert fn(ctypes.byref(st), None) == -1, name
+
+
+def test_binding_refuses_short_misspelt_and_surplus_arguments():
+    """_C.call wants exactly the header's parameter list (round 2 padded missing trailing arguments with NULL / 0);
+    _C.call_struct wants every field of the argument block by name."""
+    import torch
+    import cnr_amd
+    _C = cnr_amd._C
+    with pytest.raises(_C.CnrError, match="arguments for"):
+        _C.call("cnr_pe_fwd", None, None, None, 1, 10)                     # scale and the output left out
+    with pytest.raises(_C.CnrError, match="arguments for"):
+        _C.call("cnr_step_advance", None, 1, 2, 3)
+    with pytest.raises(_C.CnrError, match="versioned argument block"):
+        _C.call("cnr_step_tail", *([None] * 42))
+    good = {n: (None if t is ctypes.c_void_p else 0) for n, t in _C.STRUCTS["cnr_step_tail"]}
+    with pytest.raises(_C.CnrError, match="missing fields \\['code_lr'\\]"):
+        _C.call_struct("cnr_step_tail", **{k: v for k, v in good.items() if k != "code_lr"})
+    with pytest.raises(_C.CnrError, match="unknown fields \\['learning_rate'\\]"):
+        _C.call_struct("cnr_step_tail", learning_rate=1e-3, **good)
+    with pytest.raises(_C.CnrError, match="expected a number"):
+        _C.call_struct("cnr_step_tail", **dict(good, lr=None))
+    with pytest.raises(_C.CnrError):                                          # a host tensor where a device pointer belongs
+        _C.call_struct("cnr_step_tail", **dict(good, grad=torch.zeros(4)))
+
+
 def test_argument_errors_are_return_codes(lib):
     """NULL pointers / bad sizes -> CNR_E_ARG (-1) before anything touches the device."""
     import cnr_amd

@@ -120,7 +120,20 @@ def test_full_size_train_step_against_oracle(cnr, dev, C, R, n1, n2, L):
     print(f"full-size step C{C} R{R} S{n1 + n2} L{L} vs fp32 oracle: cos={cos:.5f} worst={worst:.3f}  " + " ".join(report))
     assert cos > 0.9995
 
-    # ---- the same f16 pipeline restated in torch (device): the kernel must return ITS gradient ------------------------
+    # ---- the plain-f16 pipeline restated in torch (device): the kernel must return ITS gradient.  The restatement rounds
+    # every operand to f16, so it is compared with the trainer's plain-f16 form (precise_geometry=False; same seeds, same
+    # batch, same backward) -- the default's geometry forward is deliberately NOT that arithmetic
+    torch.manual_seed(4321)
+    gen2 = torch.Generator().manual_seed(77)
+    pools2 = [cnr.scene_cateogries.synthetic_pool(4 * R, 4, gen2, "cpu") for _ in range(C)]
+    tr_p = cnr.fused.FusedCategoryTrainer(cfg, C, 4, pools2, R, dev, seed=5, generator=gen2, use_graph=False,
+                                          precise_geometry=False)
+    assert torch.equal(tr_p.theta, theta0)
+    tr_p.step()
+    torch.cuda.synchronize()
+    assert torch.equal(tr_p.bufs["pts"], bd["pts"]) and torch.equal(tr_p.bufs["z"], bd["z"])
+    got_default = got
+    got = {k: v.cpu() for k, v in _grad_tensors(cnr, tr_p, tr_p.grad).items()}
     g = _Batch(cnr, tr, theta0, bd, idx, dev)
     P, Be, she, txe, sig, rgb = _emulated_f16_step(cnr, g, dev)
     le = _torch_loss(sig, rgb, g) + 0.0005 * sum(torch.norm(she[c], dim=-1).sum() + torch.norm(txe[c], dim=-1).sum()
@@ -141,6 +154,7 @@ def test_full_size_train_step_against_oracle(cnr, dev, C, R, n1, n2, L):
             num += float((got[k] - emu[k]).double().pow(2).sum()); den += float(emu[k].double().pow(2).sum())
     print(f"   vs emulated f16 pipeline: trunk={(num / den) ** 0.5:.4f}  " + " ".join(rep2))
     assert (num / den) ** 0.5 < 1e-3
+    got = got_default
 
     # ---- AdamW (step 1): moments of the kernel's own gradient, update against the oracle's optimiser ------------------
     g_flat = tr.grad.cpu()
@@ -180,7 +194,7 @@ def test_latent_bwd_against_autograd(cnr, dev, C, n_obj, L):
     g0 = torch.randn(C, lay.total, generator=gen).to(dev)          # what the field backward left in the buffer
     grad = g0.clone()
     reg = 0.0005
-    _C.call("cnr_latent_bwd", theta, *args, zl, dbr, reg, grad)
+    _C.call("cnr_latent_bwd", theta, *args, zl, dbr, reg, grad, None)
     th = theta.clone().double().requires_grad_()
     v = lay.views(th)
     zs = []
@@ -229,7 +243,7 @@ def test_step_grad_and_tail_reduce_records_and_fixed_point_rows(cnr, dev, C, n_o
     grad = torch.full((C, lay.total), 7.0, device=dev)               # every entry must be overwritten
     dbr_out = torch.empty(C * n_obj, 4, 32, device=dev)
     _C.call("cnr_step_grad", theta, grad, lay.total, lay.B[0], lay.latW[0], lay.latb[0], lay.shape[0], lay.tex[0], L,
-            n_obj, C, zl, dbr_out, reg, ws, nwg, fix)
+            n_obj, C, zl, dbr_out, reg, ws, nwg, fix, None)
     assert rel_l2(dbr_out, rows_q) < 1e-6
     # ---- float64 expectation
     th = theta.clone().double().requires_grad_()
@@ -263,9 +277,13 @@ def test_step_grad_and_tail_reduce_records_and_fixed_point_rows(cnr, dev, C, n_o
     R = 64
     rl_ws = torch.zeros(_C.render_loss_workspace_bytes(C, R), device=dev, dtype=torch.uint8)
     losses, flags = torch.zeros(3, C, device=dev), torch.zeros(C, device=dev, dtype=torch.int32)
-    _C.call("cnr_step_tail", th2[0], th2[1], grad2, m, vv, lay.total, lay.B[0], lay.latW[0], lay.latb[0], lay.shape[0],
-            lay.tex[0], L, n_obj, C, zl, torch.empty_like(dbr_out), reg, 1, 1e-3, 0.9, 0.999, 1e-8, 0.013, state[0], state[1],
-            R, rl_ws, losses, flags, None, 8 * R, None, None, R, ws, nwg, fix, 0)
+    _C.call_struct("cnr_step_tail", theta_in=th2[0], theta_out=th2[1], grad=grad2, exp_avg=m, exp_avg_sq=vv,
+                   class_stride=lay.total, off_B=lay.B[0], off_latW=lay.latW[0], off_latb=lay.latb[0], off_shape=lay.shape[0],
+                   off_tex=lay.tex[0], L=L, n_obj=n_obj, C=C, zl=zl, dbiasrows=torch.empty_like(dbr_out), reg_scale=reg,
+                   do_latent=1, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.013, state_cur=state[0],
+                   state_next=state[1], add_rows=R, rl_workspace=rl_ws, losses=losses, flags=flags, depth=None,
+                   pool_rows=8 * R, perm=None, next_max_bound=None, R=R, records=ws, nwg=nwg, rows_fix=fix, rl_blocks=0,
+                   clamp_flags=None, n_obj_cls=None, code_lr=0.0, code_weight_decay=0.0)
     assert torch.equal(grad2, grad)
     p = theta.clone().requires_grad_()
     p.grad = grad.clone()

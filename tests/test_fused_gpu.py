@@ -102,7 +102,7 @@ def test_fused_forward_full_size(cnr, dev, C, R, S, L, wscale):
     ds, dc, dep1, var1, rgb1, opa1 = f(C, R, S), f(C, R, S, 3), f(C, R), f(C, R), f(C, R, 3), f(C, R)
     lab, dm = torch.ones(C, R, device=dev, dtype=torch.uint8), torch.ones(C, R, device=dev, dtype=torch.uint8)
     _C.call("cnr_field_fwd_render", d(pts), d(B).contiguous(), packed, brows, ray_row, 2.0, d(z), f(C, R).zero_(),
-            f(C, R, 3).zero_(), lab, dm, 5.0, 10.0, 1.0, ds, dc, dep1, var1, rgb1, opa1, C, R, S, 0, ws, ws.numel(), None)
+            f(C, R, 3).zero_(), lab, dm, 5.0, 10.0, 1.0, ds, dc, dep1, var1, rgb1, opa1, C, R, S, 0, ws, ws.numel(), None, None, None)
     errs1 = dict(depth=rel_l2(dep1, depth), rgb=rel_l2(rgb1, rgb), opacity=rel_l2(opa1, opa))
     print("   one-launch forward + render: " + " ".join(f"{k}={v:.2e}" for k, v in errs1.items()))
     for k, v in errs1.items():
@@ -113,7 +113,7 @@ def test_fused_forward_full_size(cnr, dev, C, R, S, L, wscale):
     sig2, col2 = cnr.ops.field_fwd(d(pts), d(B).contiguous(), packed, brows, ray_row, 2.0, packed_lo=lo)
     _, depth2, _, rgb2, opa2 = cnr.ops.CompositeFn.apply(sig2, col2, d(z))
     _C.call("cnr_field_fwd_render", d(pts), d(B).contiguous(), packed, brows, ray_row, 2.0, d(z), f(C, R).zero_(),
-            f(C, R, 3).zero_(), lab, dm, 5.0, 10.0, 1.0, ds, dc, dep1, var1, rgb1, opa1, C, R, S, 0, ws, ws.numel(), lo)
+            f(C, R, 3).zero_(), lab, dm, 5.0, 10.0, 1.0, ds, dc, dep1, var1, rgb1, opa1, C, R, S, 0, ws, ws.numel(), lo, None, None)
     errs2 = dict(occ=rel_l2(torch.sigmoid(sig2), occ), depth=rel_l2(depth2, depth), rgb=rel_l2(rgb2, rgb),
                  opacity=rel_l2(opa2, opa), depth_1launch=rel_l2(dep1, depth), rgb_1launch=rel_l2(rgb1, rgb))
     print("   split-weight forward:        " + " ".join(f"{k}={v:.2e}" for k, v in errs2.items()))
@@ -319,7 +319,7 @@ def test_forward_render_one_launch_equals_two(cnr, dev, C, R, S, L):
     ws = torch.zeros(_C.render_loss_workspace_bytes(C, R), device=dev, dtype=torch.uint8)
     ds0, dc0, d0, v0, r0, o0 = f(C, R, S), f(C, R, S, 3), f(C, R), f(C, R), f(C, R, 3), f(C, R)
     _C.call("cnr_render_loss", sig, rgb, z, gt_d, gt_c, labels, dmask, 5.0, 10.0, 1.0, ds0, dc0, d0, v0, r0, o0, C, R, S,
-            ws, ws.numel())
+            ws, ws.numel(), None, None)
     l0, f0 = f(3, C), torch.empty(C, device=dev, dtype=torch.int32)
     _C.call("cnr_render_loss_finish", ws, l0, f0, C, R, 0)
 
@@ -328,7 +328,7 @@ def test_forward_render_one_launch_equals_two(cnr, dev, C, R, S, L):
     ws1 = torch.zeros(int(_C.load().cnr_field_fwd_render_workspace_bytes(C, R, S)), device=dev, dtype=torch.uint8)
     ds1, dc1, d1, v1, r1, o1 = f(C, R, S), f(C, R, S, 3), f(C, R), f(C, R), f(C, R, 3), f(C, R)
     _C.call("cnr_field_fwd_render", pts, B, packed, brows, ray_row, 2.0, z, gt_d, gt_c, labels, dmask, 5.0, 10.0, 1.0,
-            ds1, dc1, d1, v1, r1, o1, C, R, S, 0, ws1, ws1.numel(), None)
+            ds1, dc1, d1, v1, r1, o1, C, R, S, 0, ws1, ws1.numel(), None, None, None)
     l1, f1 = f(3, C), torch.empty(C, device=dev, dtype=torch.int32)
     _C.call("cnr_render_loss_finish", ws1, l1, f1, C, R, nb)
     assert rel_l2(d1, d0) < 1e-6 and rel_l2(r1, r0) < 1e-6 and rel_l2(o1, o0) < 1e-6 and rel_l2(v1, v0) < 1e-5
@@ -337,7 +337,7 @@ def test_forward_render_one_launch_equals_two(cnr, dev, C, R, S, L):
     # unsupported S is refused, not mis-computed
     with pytest.raises(cnr._C.CnrError):
         _C.call("cnr_field_fwd_render", pts, B, packed, brows, ray_row, 2.0, z, gt_d, gt_c, labels, dmask, 5.0, 10.0, 1.0,
-                ds1, dc1, d1, v1, r1, o1, C, R, 48, 0, ws1, ws1.numel(), None)
+                ds1, dc1, d1, v1, r1, o1, C, R, 48, 0, ws1, ws1.numel(), None, None, None)
 
 
 @pytest.mark.parametrize("C,R,S,n_obj", [(1, 2048, 64, 4), (2, 1000, 96, 4), (1, 8192, 128, 4), (1, 77, 240, 4), (2, 50, 33, 4),

@@ -270,7 +270,7 @@ def test_render_loss_single_launch_equals_three_calls(cnr, dev, C, R, S, empty):
         ds2, dc2 = f(C, R, S), f(C, R, S, 3)
         d2, v2, r2, o2 = f(C, R), f(C, R), f(C, R, 3), f(C, R)
         _C.call("cnr_render_loss", sig, col, z, gt_d, gt_c, labels, dmask, 5.0, 10.0, 0.5, ds2, dc2, d2, v2, r2, o2,
-                C, R, S, ws, ws.numel())
+                C, R, S, ws, ws.numel(), None, None)
         _C.call("cnr_render_loss_finish", ws, l2, f2, C, R, 0)
         outs.append((l2, f2, ds2, dc2, d2, v2, r2, o2))
     l2, f2, ds2, dc2, d2, v2, r2, o2 = outs[0]

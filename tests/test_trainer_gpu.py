@@ -222,16 +222,17 @@ def test_prologue_and_epilogue_launches_equal_their_parts(cnr, dev):
     assert outs[1][6].tolist() == [4 * R, 8, 12]
 
 
-def test_split_weight_trainer_runs_and_tracks_default(cnr, dev):
-    """split_weights=True (forward with f16(W) + f16(W - f16(W))): same trajectory as the default trainer to the f16
-    level (the losses of the first steps agree to 2e-3), graph capture included."""
+def test_plain_f16_trainer_tracks_the_precise_default(cnr, dev):
+    """precise_geometry=False (plain f16 operands in the geometry branch, the round-2 forward) against the default (three
+    products per fragment): same trajectory to the f16 level (the losses of the first steps agree to 2e-3), graph capture
+    included."""
     cfg = cnr.cfg.synthetic_config(device=str(dev), latent_dim=256, n_bins_cam2surface=8, n_bins=56)
     out = []
-    for sw in (False, True):
+    for sw in (True, False):
         gen = torch.Generator().manual_seed(31)
         pools = [cnr.scene_cateogries.synthetic_pool(16 * 256, 4, gen, "cpu")]
         torch.cuda.manual_seed(77)
-        tr = cnr.fused.FusedCategoryTrainer(cfg, 1, 4, pools, 256, dev, seed=3, generator=gen, split_weights=sw)
+        tr = cnr.fused.FusedCategoryTrainer(cfg, 1, 4, pools, 256, dev, seed=3, generator=gen, precise_geometry=sw)
         hist = []
         for _ in range(6):
             tr.step()

@@ -36,6 +36,6 @@ for C, R, S in [(1, 2048, 64), (1, 8192, 128), (8, 4096, 64)]:
 
     def one():
         _C.call("cnr_render_loss", sig, col, z, gt_d, gt_c, labels, dmask, 5.0, 10.0, 0.5, dsig, dcol,
-                depth, var, rgb, opa, C, R, S, ws, ws.numel())
+                depth, var, rgb, opa, C, R, S, ws, ws.numel(), None, None)
         _C.call("cnr_render_loss_finish", ws, losses, flags, C, R, 0)
     print(f"C{C} R{R} S{S}: three calls {t(three):7.1f} us   one launch {t(one):7.1f} us", flush=True)

@@ -22,7 +22,7 @@ for R, S in ((2048, 64), (8192, 128)):
     ws = torch.zeros(int(_C.load().cnr_field_fwd_render_workspace_bytes(C, R, S)), device=dev, dtype=torch.uint8)
     for name, l in (("f16", None), ("split", lo)):
         fn = lambda: _C.call("cnr_field_fwd_render", pts, B, packed, brows, ray_row, 2.0, z, gt_d, gt_c, lab, dm, 5.0, 10.0,
-                             1.0, ds, dc, d1, v1, r1, o1, C, R, S, 0, ws, ws.numel(), l)
+                             1.0, ds, dc, d1, v1, r1, o1, C, R, S, 0, ws, ws.numel(), l, None, None)
         for _ in range(5): fn()
         torch.cuda.synchronize()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -23,10 +23,10 @@ for C, R, S in ((8, 4096, 128), (4, 2048, 64), (1, 8192, 128)):
     sig, rgb = f(C, R, S), f(C, R, S, 3)
     ws2 = torch.zeros(_C.render_loss_workspace_bytes(C, R), device=dev, dtype=torch.uint8)
     one = lambda: _C.call("cnr_field_fwd_render", pts, B, packed, brows, ray_row, 2.0, z, gt_d, gt_c, lab, dm, 5.0, 10.0,
-                          1.0, ds, dc, d1, v1, r1, o1, C, R, S, 0, ws, ws.numel(), None)
+                          1.0, ds, dc, d1, v1, r1, o1, C, R, S, 0, ws, ws.numel(), None, None, None)
     def two():
         _C.call("cnr_field_fwd", pts, B, packed, brows, ray_row, 2.0, sig, rgb, C, R, S, 0, None)
-        _C.call("cnr_render_loss", sig, rgb, z, gt_d, gt_c, lab, dm, 5.0, 10.0, 1.0, ds, dc, d1, v1, r1, o1, C, R, S, ws2, ws2.numel())
+        _C.call("cnr_render_loss", sig, rgb, z, gt_d, gt_c, lab, dm, 5.0, 10.0, 1.0, ds, dc, d1, v1, r1, o1, C, R, S, ws2, ws2.numel(), None, None)
     for name, fn in (("one launch", one), ("two launches", two)):
         for _ in range(3): fn()
         torch.cuda.synchronize()

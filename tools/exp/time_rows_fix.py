@@ -19,10 +19,8 @@ for n_obj in (4, 7, 12):
     Bc = tr.theta[0, lay.B[0]:lay.B[1]]
     clamp = torch.zeros_like(tr.clamp); st = tr.d_state2[tr.parity]
     for name, fix in (("with table", torch.zeros_like(tr.rows_fix)), ("without", None)):
-        run = lambda: _C.call("cnr_field_train", b["pts"], Bc, o["packed"], o["brows"], b["ray_row"], tr.scale, b["z"],
-                              b["gt_depth"], b["gt_rgb"], b["labels"], b["depth_mask"], tr.counts_tab, st, 5.0, 10.0, 1.0,
-                              tr.grad_scale, o["depth"], o["var"], o["rgb"], o["opa"], C, R, S, tr.n_obj, tr.bwd_blocks,
-                              o["bwd_ws"], o["bwd_ws"].numel(), o["rl_ws"], o["rl_ws"].numel(), lay.total, fix, clamp)
+        args = tr._field_train_args(b, o, Bc, st, 1.0, fix, clamp)
+        run = lambda: _C.call_struct("cnr_field_train", **args)
         for _ in range(5): run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
