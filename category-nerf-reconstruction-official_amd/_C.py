@@ -19,6 +19,7 @@ _vp, _i, _i64, _u64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.
 SIGNATURES = {
     "cnr_version": [],
     "cnr_device_info": [_vp, _vp, _vp],
+    "cnr_camera_rays": [_vp, _i, _i, _f, _f, _f, _f, _vp],
     "cnr_sample_maxdepth": [_vp, _vp, _vp, _i64, _vp, _i, _i, _vp],
     "cnr_step_advance": [_vp, _i64, _vp],
     "cnr_sample_rays": [_vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64, _vp, _i64, _vp, _i, _i, _i, _i, _i, _f, _f, _f,

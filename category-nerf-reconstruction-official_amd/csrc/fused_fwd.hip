@@ -162,16 +162,40 @@ namespace {
 // effective bias rows.  Returns the sigma logit BEFORE the x10 (valid in every lane) and leaves the three colour logits in
 // acc[0..2] of lane half 0.  SPLIT: the geometry branch (encoding_xyz .. encoding_shape) as three products per fragment,
 // Wh xh + Wl xh + Wh xl with the residual weight image smem_lo (fused_common.h, NKK_GEO); the colour branch plain f16.
+// (the order of the products below is the order of the one-launch kernel, fused_bwd_pipe8.hip: the two forwards then
+//  agree bit for bit, which tests/test_trainer_gpu.py relies on)
 template <bool SPLIT>
-__device__ __forceinline__ f16v mma3(const unsigned char* smem, const unsigned char* smem_lo, int kk, int lane,
-                                     const h8& xh, const h8& xl, f16v acc) {
-  const h8 wh = lds_frag(smem, kk, lane);
-  acc = MFMA(wh, xh, acc);
+__device__ __forceinline__ f16v pe_products(const unsigned char* smem, const unsigned char* smem_lo, int kk0, int lane,
+                                            const h8 (&E1f)[6], const h8 (&E1l)[6], f16v acc) {
+  h8 w[6];
+#pragma unroll
+  for (int s = 0; s < 6; ++s) w[s] = lds_frag(smem, kk0 + s, lane);
+#pragma unroll
+  for (int s = 0; s < 6; ++s) acc = MFMA(w[s], E1f[s], acc);
   if (SPLIT) {
-    acc = MFMA(lds_frag(smem_lo, kk, lane), xh, acc);
-    acc = MFMA(wh, xl, acc);
+#pragma unroll
+    for (int s = 0; s < 6; ++s) acc = MFMA(w[s], E1l[s], acc);
+#pragma unroll
+    for (int s = 0; s < 6; ++s) acc = MFMA(lds_frag(smem_lo, kk0 + s, lane), E1f[s], acc);
   }
   return acc;
+}
+// a 32-wide hidden layer of the geometry branch: input = the previous layer's accumulators (ReLU), start = bias row
+template <bool SPLIT>
+__device__ __forceinline__ f16v hidden_layer(const unsigned char* smem, const unsigned char* smem_lo, int kk0, int lane,
+                                             const f16v& prev, const f16v& init) {
+  const h8 w0 = lds_frag(smem, kk0, lane), w1 = lds_frag(smem, kk0 + 1, lane);
+  const h8 xa = pack8(prev, 0, true), xb = pack8(prev, 1, true);
+  f16v o = MFMA(w0, xa, init);
+  o = MFMA(w1, xb, o);
+  if (SPLIT) {
+    o = MFMA(lds_frag(smem_lo, kk0, lane), xa, o);
+    o = MFMA(lds_frag(smem_lo, kk0 + 1, lane), xb, o);
+    const h8 la = pack8_lo(prev, 0, true, xa), lb = pack8_lo(prev, 1, true, xb);
+    o = MFMA(w0, la, o);
+    o = MFMA(w1, lb, o);
+  }
+  return o;
 }
 template <bool SPLIT>
 __device__ __forceinline__ float forward_tile(const unsigned char* smem, const unsigned char* smem_lo, const float* cf, const float (&Bh)[33],
@@ -179,38 +203,18 @@ __device__ __forceinline__ float forward_tile(const unsigned char* smem, const u
                                               int h, f16v& acc_out) {
   h8 E1f[6], E2f[3], E1l[6];
   pe_slots<false, SPLIT>(Bh, t0, t1, t2, h, E1f, E2f, E1l);
-  const h8 zl = {};   // (unused operand of the plain form)
-
-  // L0 encoding_xyz
-  f16v acc = acc_init(cf + CF_B_XYZ, h);
-#pragma unroll
-  for (int s = 0; s < 6; ++s) acc = mma3<SPLIT>(smem, smem_lo, KK_XYZ + s, lane, E1f[s], SPLIT ? E1l[s] : zl, acc);
-  h8 H0 = pack8(acc, 0, true), H1 = pack8(acc, 1, true), L0 = zl, L1 = zl;
-  if (SPLIT) { L0 = pack8_lo(acc, 0, true, H0); L1 = pack8_lo(acc, 1, true, H1); }
+  // L0 encoding_xyz, and the e1 part of L2 cat_layer (its own accumulator, started from the cat bias row): the E1 operands die here
+  f16v acc = pe_products<SPLIT>(smem, smem_lo, KK_XYZ, lane, E1f, E1l, acc_init(cf + CF_B_XYZ, h));
+  const f16v catp = pe_products<SPLIT>(smem, smem_lo, KK_CAT + 2, lane, E1f, E1l, acc_init(brow + 1 * 32, h));
   // L1 shape_layer_1 (latent slot 0 folded into the bias row)
-  acc = acc_init(brow + 0 * 32, h);
-  acc = mma3<SPLIT>(smem, smem_lo, KK_S1 + 0, lane, H0, L0, acc);
-  acc = mma3<SPLIT>(smem, smem_lo, KK_S1 + 1, lane, H1, L1, acc);
-  H0 = pack8(acc, 0, true); H1 = pack8(acc, 1, true);
-  if (SPLIT) { L0 = pack8_lo(acc, 0, true, H0); L1 = pack8_lo(acc, 1, true, H1); }
+  acc = hidden_layer<SPLIT>(smem, smem_lo, KK_S1, lane, acc, acc_init(brow + 0 * 32, h));
   // L2 cat_layer: [a1 | e1]
-  acc = acc_init(brow + 1 * 32, h);
-  acc = mma3<SPLIT>(smem, smem_lo, KK_CAT + 0, lane, H0, L0, acc);
-  acc = mma3<SPLIT>(smem, smem_lo, KK_CAT + 1, lane, H1, L1, acc);
-#pragma unroll
-  for (int s = 0; s < 6; ++s) acc = mma3<SPLIT>(smem, smem_lo, KK_CAT + 2 + s, lane, E1f[s], SPLIT ? E1l[s] : zl, acc);
-  H0 = pack8(acc, 0, true); H1 = pack8(acc, 1, true);
-  if (SPLIT) { L0 = pack8_lo(acc, 0, true, H0); L1 = pack8_lo(acc, 1, true, H1); }
+  acc = hidden_layer<SPLIT>(smem, smem_lo, KK_CAT, lane, acc, catp);
   // L3 shape_layer_2
-  acc = acc_init(brow + 2 * 32, h);
-  acc = mma3<SPLIT>(smem, smem_lo, KK_S2 + 0, lane, H0, L0, acc);
-  acc = mma3<SPLIT>(smem, smem_lo, KK_S2 + 1, lane, H1, L1, acc);
-  H0 = pack8(acc, 0, true); H1 = pack8(acc, 1, true);
-  if (SPLIT) { L0 = pack8_lo(acc, 0, true, H0); L1 = pack8_lo(acc, 1, true, H1); }
-  // L4 encoding_shape (no activation)
-  acc = acc_init(cf + CF_B_ES, h);
-  acc = mma3<SPLIT>(smem, smem_lo, KK_ES + 0, lane, H0, L0, acc);
-  acc = mma3<SPLIT>(smem, smem_lo, KK_ES + 1, lane, H1, L1, acc);
+  acc = hidden_layer<SPLIT>(smem, smem_lo, KK_S2, lane, acc, acc_init(brow + 2 * 32, h));
+  // L4 encoding_shape (no activation on its output)
+  acc = hidden_layer<SPLIT>(smem, smem_lo, KK_ES, lane, acc, acc_init(cf + CF_B_ES, h));
+  h8 H0, H1;
   // sigma head in fp32 on the VALU: raw = w_sigma . y4 + b
   float raw;
   {

@@ -165,6 +165,17 @@ class FusedCategoryTrainer:
                          indices=st("indices"))
         self.pool_rows = self.pool["depth"].shape[1]
         assert self.pool_rows >= 2 * self.Rg
+        if self.shard == "class" and self.pg is not None and self.world > 1:
+            # the per-epoch OR of the empty flags is a collective issued at every reshuffle: all ranks must reshuffle in the
+            # same steps, i.e. hold pools of the same length and take the same rays per step -- checked here, where a
+            # mismatch is a message instead of a hang at the first epoch end
+            mine = torch.tensor([self.pool_rows, self.Rg], dtype=torch.int64,
+                                device=self.device if torch.distributed.get_backend(self.pg) == "nccl" else "cpu")
+            every = [torch.zeros_like(mine) for _ in range(self.world)]
+            torch.distributed.all_gather(every, mine, group=self.pg)
+            every = [tuple(int(v) for v in t.tolist()) for t in every]
+            if len(set(every)) != 1:
+                raise ValueError(f"class shards need the same pool length and rays per step on every rank, got (pool_rows, rays) = {every}")
         # device-side step state {pool cursor, rng step, optimiser step}, two copies: step k reads copy k & 1 and its
         # last kernel writes copy (k + 1) & 1 -- no kernel ever writes a state another kernel of the same step reads
         self.d_state2 = torch.zeros(2, 3, device=self.device, dtype=torch.int64)
@@ -600,7 +611,7 @@ class FusedCategoryTrainer:
     def load_state_dicts(self, d, c=0):
         """Inverse of :meth:`state_dicts` for local class ``c``: a checkpoint dict in the reference's key schema
         (src/scene_cateogries.py:548-571: FC_state_dict, PE_state_dict, shape_code_state_dict, texture_code_state_dict)
-        goes into BOTH parameter copies; optimiser moments are reset (the reference does not save them)."""
+        goes into BOTH parameter copies, and the optimiser starts afresh for all classes (see reset_optimizer)."""
         fc = d["FC_state_dict"]
         for th in (self.theta2[0], self.theta2[1]):
             v = self.lay.views(th)
@@ -614,5 +625,13 @@ class FusedCategoryTrainer:
             v["B"][c].copy_(d["PE_state_dict"]["B_layer.weight"])
             v["shape"][c, :self.n_obj_list[c]].copy_(d["shape_code_state_dict"]["weight"])
             v["tex"][c, :self.n_obj_list[c]].copy_(d["texture_code_state_dict"]["weight"])
-        self.exp_avg[c].zero_()
-        self.exp_avg_sq[c].zero_()
+        self.reset_optimizer()
+
+    def reset_optimizer(self):
+        """A fresh AdamW for EVERY class: both moments zero and the device-side optimiser step counter back to 0 (the counter
+        is one per trainer: bias correction with a large step on zeroed moments would shrink the first updates after a resume).
+        The reference saves no optimiser state and builds a new AdamW for all classes when it resumes (train.py:40,66-68);
+        load_state_dicts() therefore calls this -- loading one class restarts the optimiser of all of them."""
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        self.d_state2[:, 2] = 0

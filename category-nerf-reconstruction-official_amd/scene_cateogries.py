@@ -72,12 +72,18 @@ class cameraInfo:
         self.rays_dir_cache = self.get_rays_dirs()
 
     def get_rays_dirs(self, depth_type="z"):
-        dev = self.device
-        dirs = torch.ones((self.width, self.height, 3), device=dev)
-        dirs[:, :, 0] = ((torch.arange(end=self.width, device=dev) - self.cx) / self.fx)[:, None]
-        dirs[:, :, 1] = ((torch.arange(end=self.height, device=dev) - self.cy) / self.fy)
         if depth_type == "euclidean":   # the reference raises here as well (:623-626)
             raise Exception("Get camera rays directions with euclidean depth not yet implemented")
+        if self.device.type == "cuda":  # cnr_camera_rays: correctly rounded division, bit-equal to the reference's CPU tensor
+            from . import _C
+            dirs = torch.empty((self.width, self.height, 3), device=self.device)
+            with torch.cuda.device(self.device):
+                _C.call("cnr_camera_rays", dirs, int(self.width), int(self.height), float(self.fx), float(self.fy),
+                        float(self.cx), float(self.cy))
+            return dirs
+        dirs = torch.ones((self.width, self.height, 3))
+        dirs[:, :, 0] = ((torch.arange(end=self.width) - self.cx) / self.fx)[:, None]
+        dirs[:, :, 1] = ((torch.arange(end=self.height) - self.cy) / self.fy)
         return dirs
 
 

@@ -50,6 +50,11 @@ extern "C" {
 int cnr_version(void);
 int cnr_device_info(int* n_cu, int* lds_bytes, int* gcn_arch_is_gfx950);
 
+/* ---- a1: cameraInfo.get_rays_dirs (src/scene_cateogries.py:613-629) --------------------------------------------------
+ * dirs (W,H,3): dirs[w][h] = ((w - cx) / fx, (h - cy) / fy, 1) -- indexed [w, h] (the reference transposes images at load),
+ * NOT normalised (z-depth convention).  Correctly rounded fp32 subtraction and division: bit-equal to the reference. */
+int cnr_camera_rays(float* dirs, int W, int H, float fx, float fy, float cx, float cy, void* stream);
+
 /* ---- a2-a5: ray transform + depth-guided sampling (src/scene_cateogries.py:24-47, 51-96, 453-546)
  * One pool slice of R rays (per class; C slices batched).  Inputs:
  *   rgbs  (C,R,4) u8  [r,g,b,state]      depth (C,R)      dirs_c (C,R,3)     T (C,R,4,4)

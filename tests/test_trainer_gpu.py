@@ -427,20 +427,24 @@ def test_run_with_multi_step_graphs_equals_single_steps(cnr, dev):
                                                # 8-15 objects per class: two row-sum blocks
                                                (2, 250, 4, 28, 9, 32), (1, 480, 1, 9, 15, 32), (1, 256, 8, 56, 12, 32),
                                                (1, 96, 16, 112, 8, 32)])
-def test_one_launch_step_equals_forward_render_plus_backward(cnr, dev, C, R, n1, n2, n_obj, L):
+@pytest.mark.parametrize("precise", [False, True], ids=["plain_f16", "precise_geometry"])
+def test_one_launch_step_equals_forward_render_plus_backward(cnr, dev, C, R, n1, n2, n_obj, L, precise):
     """cnr_field_train (a8-a15 forward, losses, loss gradient and the field backward in ONE launch, the ray's tiles
     exchanging composite partials between waves) against cnr_field_fwd_render + cnr_field_bwd_pipe: same f16 pipeline,
     same samples -> renders and loss values to fp32 summation order, the complete gradient (trunk, latent layers, B,
     codes) to 1e-4, parameters after AdamW; ragged tile counts (dead tiles in the last workgroup iteration), 5-7
     objects per class (the run-time row-sum stride), 8-15 (two row-sum blocks), S = 32 / 64 / 128 (1, 2, 4 tiles per ray) and rays padded to
-    16 / 32 / 64 / 128 sample slots (dead lanes; two 16-slot rays per tile for S <= 16)."""
+    16 / 32 / 64 / 128 sample slots (dead lanes; two 16-slot rays per tile for S <= 16).
+    plain_f16: both paths run one arithmetic end to end -> the gradient bar is 1e-4.  precise_geometry (the default): the two
+    forwards agree bit for bit, but the two-launch path's backward recomputes its activations with plain f16 operands where the
+    one-launch backward keeps the precise forward's -- the gradients then differ like f16 from fp32 (a few 1e-3)."""
     res = {}
     for name, one in (("two", False), ("one", True)):
         cfg = cnr.cfg.synthetic_config(device=str(dev), latent_dim=L, n_bins_cam2surface=n1, n_bins=n2)
         gen = torch.Generator().manual_seed(5)
         pools = [cnr.scene_cateogries.synthetic_pool(max(4 * R, 8), n_obj, gen, "cpu") for _ in range(C)]
         tr = cnr.fused.FusedCategoryTrainer(cfg, C, n_obj, pools, R, dev, seed=2, generator=gen, use_graph=False,
-                                            one_launch=one)
+                                            one_launch=one, precise_geometry=precise)
         assert bool(tr._ft_blocks) == one
         hist = []
         for _ in range(3):
@@ -457,8 +461,8 @@ def test_one_launch_step_equals_forward_render_plus_backward(cnr, dev, C, R, n1,
     assert rel_l2(a["losses"], b["losses"]) < 5e-5 and torch.equal(a["flags"], b["flags"])   # (v_rcp / v_sqrt in the depth weight)
     # (the one-launch kernel forms its quotients with v_rcp_f32, 1 ulp: d sigma differs in the last bit, which the f16 pack of
     #  the scaled gradients turns into an f16 ulp here and there)
-    assert rel_l2(a["grad"], b["grad"]) < 1e-4, rel_l2(a["grad"], b["grad"])
-    assert rel_l2(a["theta"], b["theta"]) < 1e-3     # first AdamW step: +-lr per entry, the sign of a ~0 gradient entry is noise
+    assert rel_l2(a["grad"], b["grad"]) < (2e-2 if precise else 1e-4), rel_l2(a["grad"], b["grad"])
+    assert rel_l2(a["theta"], b["theta"]) < (4e-3 if precise else 1e-3)     # first AdamW step: +-lr per entry, the sign of a ~0 gradient entry is noise
     for s in range(3):   # still the same training run two steps later (AdamW's sign-like first steps amplify rounding)
         assert torch.isfinite(res["one"][s]["grad"]).all()
         assert rel_l2(res["one"][s]["losses"], res["two"][s]["losses"]) < 2e-2
@@ -512,11 +516,25 @@ def test_classes_with_different_object_counts_and_a_single_object_class(cnr, dev
     tr2 = cnr.fused.FusedCategoryTrainer(cfg, C, n_objs, pools, R, dev, seed=9, generator=torch.Generator().manual_seed(99),
                                          use_graph=False)
     assert not torch.equal(tr2.theta[1], tr.theta[1])
+    for _ in range(5):          # an optimiser with history: moments and a step count of 5
+        tr2.step()
     tr2.load_state_dicts(sd, 1)
     v1, v2 = tr.lay.views(tr.theta), tr2.lay.views(tr2.theta)
     for k in ("trunk", "latW", "latb", "B"):
         assert torch.equal(v1[k][1], v2[k][1]), k
     assert torch.equal(v1["shape"][1, :1], v2["shape"][1, :1]) and torch.equal(v1["tex"][1, :1], v2["tex"][1, :1])
+    # a resume starts a FRESH AdamW (the reference builds a new optimiser and saves no moments): moments zero, step counter 0,
+    # so that the first update after the load is a first AdamW step: |delta| = lr (1 + wd |theta|) wherever the gradient is
+    # not noise -- with the old step count bias correction would have shrunk it by 1 - beta1^6 = 0.47
+    assert float(tr2.exp_avg.abs().max()) == 0.0 and float(tr2.exp_avg_sq.abs().max()) == 0.0
+    assert tr2.d_state2[:, 2].tolist() == [0, 0]
+    before = tr2.theta.clone()
+    tr2.step()
+    torch.cuda.synchronize()
+    g2 = tr2.grad[1]
+    big = g2.abs() > 0.05 * g2.abs().max()
+    delta = (tr2.theta[1] - before[1]).abs()[big]
+    assert float((delta / cfg.learning_rate).min()) > 0.9 and float((delta / cfg.learning_rate).max()) < 1.1
 
 
 @pytest.mark.parametrize("C,R,slices,perm_on", [(1, 2048, 7, True), (3, 100, 5, False), (9, 33, 4, True)])
