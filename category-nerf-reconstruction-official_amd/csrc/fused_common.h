@@ -122,14 +122,22 @@ __device__ __forceinline__ h8 pack8(const f16v& a, int s, bool relu) {
   }
   return r;
 }
+// x - (float)h as ONE v_fma_mix_f32 (f16 source read in place): the -1 is opaque to the optimiser, which otherwise rewrites
+// fma(h, -1, x) into v_cvt_f32_f16 + v_sub_f32
+__device__ __forceinline__ float minus_one() {
+  float m = -1.0f;
+  asm volatile("" : "+s"(m));   // no instruction
+  return m;
+}
 // the residual of pack8: f16(x - f16(x)) for the same 8 accumulator registers, x = max(a, 0) when relu
 __device__ __forceinline__ h8 pack8_lo(const f16v& a, int s, bool relu, const h8& hi) {
   h8 r;
+  const float m1 = minus_one();
 #pragma unroll
   for (int j = 0; j < 8; j += 2) {
     const float x0 = relu ? fmaxf(a[8 * s + j], 0.0f) : a[8 * s + j];
     const float x1 = relu ? fmaxf(a[8 * s + j + 1], 0.0f) : a[8 * s + j + 1];
-    f2 v = {__builtin_fmaf((float)hi[j], -1.0f, x0), __builtin_fmaf((float)hi[j + 1], -1.0f, x1)};   // v_fma_mix_f32
+    f2 v = {__builtin_fmaf((float)hi[j], m1, x0), __builtin_fmaf((float)hi[j + 1], m1, x1)};   // v_fma_mix_f32
     h2 p = __builtin_convertvector(v, h2);
     r[j] = p[0]; r[j + 1] = p[1];
   }
@@ -137,9 +145,10 @@ __device__ __forceinline__ h8 pack8_lo(const f16v& a, int s, bool relu, const h8
 }
 __device__ __forceinline__ h8 pack8f_lo(const float* v, const h8& hi) {
   h8 r;
+  const float m1 = minus_one();
 #pragma unroll
   for (int j = 0; j < 8; j += 2) {
-    f2 x = {__builtin_fmaf((float)hi[j], -1.0f, v[j]), __builtin_fmaf((float)hi[j + 1], -1.0f, v[j + 1])};
+    f2 x = {__builtin_fmaf((float)hi[j], m1, v[j]), __builtin_fmaf((float)hi[j + 1], m1, v[j + 1])};
     h2 p = __builtin_convertvector(x, h2);
     r[j] = p[0]; r[j + 1] = p[1];
   }

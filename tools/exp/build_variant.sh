@@ -1,0 +1,12 @@
+#!/bin/bash
+# tools/exp/libs/libcnr_<name>.so: the library with ONE translation unit rebuilt with extra flags (an A/B arm for
+# tools/exp/ab_step.py: CNR_HIP_LIB=tools/exp/libs/libcnr_<name>.so).  usage: build_variant.sh <name> <file.hip> <flags...>
+set -e
+name=$1; file=$2; shift 2
+cd "$(dirname "$0")/../../category-nerf-reconstruction-official_amd/csrc"
+make -j8 >/dev/null
+mkdir -p ../../tools/exp/libs
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 "$@" -c "$file" -o "../../tools/exp/libs/${name}_${file%.hip}.o"
+objs=$(ls build/*.o | grep -v "build/${file%.hip}.o")
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "../../tools/exp/libs/libcnr_${name}.so" $objs "../../tools/exp/libs/${name}_${file%.hip}.o"
+echo "built tools/exp/libs/libcnr_${name}.so"
