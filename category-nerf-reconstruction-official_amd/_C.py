@@ -72,6 +72,16 @@ SIGNATURES = {
                         _i64, _vp, _vp, _vp],
     "cnr_render_loss_finish": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "cnr_step_epilogue": [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i, _i, _vp],
+    "cnr_bg_pack_bytes": [],
+    "cnr_bg_param_count": [],
+    "cnr_bg_blocks": [_i],
+    "cnr_bg_dw_chunks": [_i, _i],
+    "cnr_bg_record_floats": [],
+    "cnr_bg_pack": [_vp, _vp, _vp],
+    "cnr_bg_forward": [_vp, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp],
+    "cnr_bg_backward": [_vp, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
+    "cnr_bg_dw": [_vp, _vp, _vp, _i, _i, _vp, _vp],
+    "cnr_bg_tail": [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _f, _f, _f, _f, _f, _f, _vp, _i64, _vp],
 }
 # The three launches of the fused trainer's step take ONE versioned struct (include/cnr_hip.h: struct_size and abi_version
 # first, then these fields in this order).  call_struct() wants every field by NAME: a missing, misspelt or surplus argument
@@ -116,7 +126,7 @@ def struct_type(name):
 
 
 _RESTYPE64 = {"cnr_pack_bytes", "cnr_pack_lo_bytes", "cnr_field_bwd_workspace_bytes", "cnr_render_loss_workspace_bytes",
-              "cnr_dense_bwd_workspace_bytes", "cnr_field_fwd_render_workspace_bytes", "cnr_field_train_workspace_bytes", "cnr_pack_fp8_bytes"}
+              "cnr_dense_bwd_workspace_bytes", "cnr_field_fwd_render_workspace_bytes", "cnr_field_train_workspace_bytes", "cnr_pack_fp8_bytes", "cnr_bg_pack_bytes"}
 
 _lib = None
 _double = None

@@ -24,9 +24,14 @@ class BackgroundStep:
         tcfg = copy.copy(cfg)
         tcfg.hidden_feature_size, tcfg.obj_scale, tcfg.training_device = cfg.hidden_feature_size_bg, cfg.bg_scale, str(self.device)
         self.trainer = trainer_mod.Trainer(tcfg, 0, [0])                     # .pe, .fc_occ_map (src/trainer.py:23-25)
-        assert precision in ("fp32", "f16")
-        # "f16": the hidden layers' products on f16 MFMA operands with fp32 accumulation (ops.DenseFn half=True; the x10
-        # occupancy head stays fp32, like the sigma head of the category kernel); "fp32": the exact tier (default)
+        assert precision in ("fp32", "f16", "fused")
+        # "fp32": the exact tier -- one launch per layer (cnr_dense_*: fp32 MFMA) under torch autograd, pinned to the reference's
+        #         bg_*.npz vectors at 2e-5 (the default of this class; the parity tier);
+        # "f16":  the same launches with f16 operands in the hidden layers (ops.DenseFn half=True);
+        # "fused": the throughput tier (csrc/bg_fused.hip): the whole step in seven launches, every activation of a 64-sample
+        #         tile in LDS, f16 MFMA operands with the geometry branch as three products per fragment (the x10 occupancy
+        #         logit, like the category kernel), no autograd, no float atomics.  Hidden size 128 only.
+        self.precision = precision
         self.trainer.fc_occ_map.half = precision == "f16"
         dev = self.device
         self.pool = dict(rgbs=pool["rgbs"].to(dev)[None].contiguous(), depth=pool["depth"].to(dev)[None].contiguous(),
@@ -59,6 +64,8 @@ class BackgroundStep:
         import torch.nn as nn
         self.trainer.fc_occ_map.grad_out = {id(m): (m.weight.grad, m.bias.grad if m.bias is not None else None)
                                             for m in self.trainer.fc_occ_map.modules() if isinstance(m, nn.Linear)}
+        if precision == "fused":
+            self._init_fused(n)
         self.bufs = {}
         self.loss = torch.zeros((), device=dev)
         self.losses = torch.zeros(3, device=dev)
@@ -75,6 +82,8 @@ class BackgroundStep:
 
     def _body(self):
         """sample -> PE -> OccupancyMap -> composite + losses -> backward -> AdamW -> advance (all stream-ordered)."""
+        if self.precision == "fused":
+            return self._body_fused()
         cfg, t = self.cfg, self.trainer
         self.gflat.zero_()
         b = ops.sample_rays(self.pool["rgbs"], self.pool["depth"], self.pool["dirs"], self.pool["T"], self.n1, self.n2,
@@ -89,6 +98,55 @@ class BackgroundStep:
         self.loss.copy_(loss.detach())
         self.losses.copy_(torch.stack([ld["depth"][0], ld["color"][0], ld["opacity"][0]]).detach())
         _C.call("cnr_step_advance", self.d_state, self.R)
+
+    # ---- the fused f16 tier ----------------------------------------------------------------------------------------------------
+    def _init_fused(self, n):
+        import math
+        lib, dev = _C.load(), self.device
+        fc = self.trainer.fc_occ_map
+        assert self.cfg.hidden_feature_size_bg == 128 and n == int(lib.cnr_bg_param_count()), \
+            "the fused background step is built for OccupancyMap(hidden 128) + UniDirsEmbed"
+        # the kernels address the flat buffer by fixed offsets: the modules' registration order must be the header's
+        names = [k for k, _ in fc.named_parameters()]
+        assert names == ["in_layer.0.weight", "in_layer.0.bias", "mid1.0.0.weight", "mid1.0.0.bias", "cat_layer.0.weight",
+                         "cat_layer.0.bias", "mid2.0.0.weight", "mid2.0.0.bias", "out_alpha.weight", "out_alpha.bias",
+                         "color_linear.0.weight", "color_linear.0.bias", "out_color.weight", "out_color.bias"], names
+        assert [tuple(p.shape) for p in self.trainer.pe.parameters()] == [(21, 3)]
+        self.S = self.n1 + self.n2
+        M = self.M = self.R * self.S
+        self.dw_chunk = 256
+        self.nblk, self.nchunk = int(lib.cnr_bg_blocks(M)), int(lib.cnr_bg_dw_chunks(M, self.dw_chunk))
+        self.gscale = float(2 ** round(math.log2(max(self.R, 2))))      # power-of-two loss scale of the f16 gradient chain
+        f = lambda *sh, dt=torch.float32: torch.empty(*sh, device=dev, dtype=dt)
+        self.fb = dict(packed=f(int(lib.cnr_bg_pack_bytes()), dt=torch.uint8), sigma=f(1, self.R, self.S),
+                       rgbs=f(1, self.R, self.S, 3), act=f(5, M, 128, dt=torch.float16), eimg=f(M, 144, dt=torch.float16),
+                       dpre=f(5, M, 128, dt=torch.float16), records=f(self.nblk, int(lib.cnr_bg_record_floats())),
+                       partials=f(self.nchunk, n), dsig=f(1, self.R, self.S), drgb=f(1, self.R, self.S, 3),
+                       depth=f(1, self.R), var=f(1, self.R), rgb=f(1, self.R, 3), opa=f(1, self.R),
+                       rl_ws=torch.zeros(_C.render_loss_workspace_bytes(1, self.R), device=dev, dtype=torch.uint8),
+                       losses=torch.zeros(3, 1, device=dev), flags=torch.zeros(1, device=dev, dtype=torch.int32))
+
+    def _body_fused(self):
+        """sample -> pack -> forward -> composite + losses + their gradient -> backward -> weight gradients -> reduce + AdamW +
+        advance: eight launches, nothing under autograd (train.py:113-121,172-184 for the background)."""
+        cfg, o = self.cfg, self.fb
+        b = ops.sample_rays(self.pool["rgbs"], self.pool["depth"], self.pool["dirs"], self.pool["T"], self.n1, self.n2,
+                            cfg.surface_eps, cfg.stop_eps, min_bound=cfg.min_depth, world_frame=True, seed=self.seed,
+                            d_state=self.d_state, rays=self.R, out=self.bufs, perm=self.perm)
+        scale, M = float(self.trainer.pe._scale), self.M
+        _C.call("cnr_bg_pack", self.flat, o["packed"])
+        _C.call("cnr_bg_forward", b["pts"], self.flat, o["packed"], scale, M, o["sigma"], o["rgbs"], o["act"], o["eimg"])
+        _C.call("cnr_render_loss", o["sigma"], o["rgbs"], b["z"], b["gt_depth"], b["gt_rgb"], b["labels"], b["depth_mask"],
+                5.0, 10.0, self.gscale, o["dsig"], o["drgb"], o["depth"], o["var"], o["rgb"], o["opa"], 1, self.R, self.S,
+                o["rl_ws"], o["rl_ws"].numel(), None, None)
+        _C.call("cnr_render_loss_finish", o["rl_ws"], o["losses"], o["flags"], 1, self.R, 0)
+        _C.call("cnr_bg_backward", b["pts"], self.flat, o["packed"], scale, M, o["dsig"], o["drgb"], o["rgbs"], o["act"],
+                o["dpre"], o["records"], self.d_state, self.R)
+        _C.call("cnr_bg_dw", o["act"], o["dpre"], o["eimg"], M, self.dw_chunk, o["partials"])
+        _C.call("cnr_bg_tail", self.flat, self.gflat, self.exp_avg, self.exp_avg_sq, o["partials"], self.nchunk, o["records"],
+                self.nblk, self.gscale, cfg.learning_rate, 0.9, 0.999, 1e-8, cfg.weight_decay, self.d_state, -1)
+        self.losses.copy_(o["losses"][:, 0])
+        self.loss.copy_(o["losses"][0, 0] + 5.0 * o["losses"][1, 0] + 10.0 * o["losses"][2, 0])
 
     def pre_step(self):
         if self.cursor >= self.pool_rows - self.R:

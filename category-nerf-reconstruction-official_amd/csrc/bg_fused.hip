@@ -1,0 +1,840 @@
+// Fused f16-MFMA train step of the BACKGROUND field: vMAP-style OccupancyMap(hidden 128), src/model.py:86-155, trained every
+// iteration on 1200 world-frame rays x 14 samples (train.py:113-121,172-180).  Round 2 ran its seven Linear layers one launch
+// each under torch autograd (14 x 20.8 us + 7 x 26.6 us + ~40 glue kernels = 0.69 ms); here the step is
+//   cnr_bg_pack      fp32 parameters -> f16 MFMA fragment images (forward hi / geometry-branch residual / transposed)
+//   cnr_bg_forward   per 64-sample tile: PE -> in_layer -> mid1 -> cat_layer -> mid2 -> {out_alpha | color_linear -> out_color}
+//                    with every activation in LDS; writes sigma, rgb and the f16 activations the backward needs
+//   (cnr_render_loss / cnr_render_loss_finish: composite, losses, d sigma, d colour -- the category path's kernels)
+//   cnr_bg_backward  per tile: the data-gradient chain, masks from the stored activations, PE backward; writes the f16
+//                    pre-activation gradients, and the small gradients (out_color, out_alpha, B) as per-workgroup records
+//   cnr_bg_dw        weight / bias gradients of the five 128-wide layers: dW = dPre^T X over all samples, split over sample
+//                    chunks (partials, fixed-order sum)
+//   cnr_bg_tail      partial + record reduction, AdamW in place, step state advance
+// Layout: a workgroup = 4 waves owns a tile of 64 samples; every layer is computed transposed, D = W X^T
+// (v_mfma_f32_32x32x16_f16): wave w owns output features [32 w, 32 w + 32) for both 32-sample halves of the tile; the A
+// operand (weights) comes pre-packed from global / L2 straight into registers, the B operand (activations) from a
+// [sample][feature] f16 image in LDS (16-byte reads, padded rows), the accumulators go back to such an image.
+// Precision: the geometry branch (in_layer, mid1, cat_layer, mid2 -> out_alpha) as three f16 products per fragment,
+// Wh xh + Wl xh + Wh xl (residual weights and residual activation images), the x10 occupancy head as an fp32 dot product
+// of the fp32 accumulators -- the same reasoning as the category kernel (include/cnr_hip.h, cnr_pack_weights_lo); the
+// colour branch and the whole backward use plain f16 operands with a power-of-two loss scale.  Deterministic: no float
+// atomics anywhere (records and partials summed in a fixed order).
+#include "adamw_common.h"
+#include "fused_common.h"
+
+namespace {
+using namespace fz;
+
+constexpr int BH = 128, BE1 = 87, BE2 = 42, BE1P = 96, BE2P = 48, BEP = BE1P + BE2P;   // hidden, PE widths, padded
+// flat parameter buffer (the modules' registration order: src/model.py:100-113, then B_layer of the PE)
+constexpr int O_IN_W = 0, O_IN_B = 11136, O_M1_W = 11264, O_M1_B = 27648, O_CAT_W = 27776, O_CAT_B = 55296,
+              O_M2_W = 55424, O_M2_B = 71808, O_OA_W = 71936, O_OA_B = 72064, O_CL_W = 72065, O_CL_B = 93825,
+              O_OC_W = 93953, O_OC_B = 94337, O_PE_B = 94340, BG_NPARAM = 94403;
+enum BgLayer { L_IN, L_M1, L_CAT, L_M2, L_CL, L_OC, NLAYER };
+// k-steps (16 input features each) per layer: first source (hidden activations / E1 for in_layer), second source (PE part)
+__host__ __device__ constexpr int ks_a(int l) { return l == L_IN ? 6 : 8; }
+__host__ __device__ constexpr int ks_b(int l) { return l == L_CAT ? 6 : l == L_CL ? 3 : 0; }
+__host__ __device__ constexpr int ks(int l) { return ks_a(l) + ks_b(l); }
+// forward fragment index (hi image) of (layer, out block w, k-step s); OC has one out block
+__host__ __device__ constexpr int fwd_base(int l) { return l == L_IN ? 0 : l == L_M1 ? 24 : l == L_CAT ? 56 : l == L_M2 ? 112 : l == L_CL ? 144 : 188; }
+constexpr int NF_FWD = 196, NF_LO = 144;     // residual image: the four geometry layers, same indexing (fwd_base < 144)
+// transposed fragments (data-gradient chain): rows = 32 input features of block ib, K = output features
+__host__ __device__ constexpr int bwd_base(int l) { return l == L_OC ? 0 : l == L_CL ? 4 : l == L_M2 ? 52 : l == L_CAT ? 84 : l == L_M1 ? 140 : 172; }
+__host__ __device__ constexpr int bwd_blocks(int l) { return l == L_OC ? 4 : l == L_CL ? 6 : l == L_CAT ? 7 : l == L_IN ? 3 : 4; }
+constexpr int NF_BWD = 196;
+constexpr int PK_FWD_OFF = 0, PK_LO_OFF = NF_FWD * FRAG_BYTES, PK_BWD_OFF = PK_LO_OFF + NF_LO * FRAG_BYTES,
+              BG_PACK_BYTES = PK_BWD_OFF + NF_BWD * FRAG_BYTES;
+__host__ __device__ constexpr int w_off(int l) { return l == L_IN ? O_IN_W : l == L_M1 ? O_M1_W : l == L_CAT ? O_CAT_W : l == L_M2 ? O_M2_W : l == L_CL ? O_CL_W : O_OC_W; }
+__host__ __device__ constexpr int b_off(int l) { return l == L_IN ? O_IN_B : l == L_M1 ? O_M1_B : l == L_CAT ? O_CAT_B : l == L_M2 ? O_M2_B : l == L_CL ? O_CL_B : O_OC_B; }
+__host__ __device__ constexpr int ld_of(int l) { return l == L_IN ? BE1 : l == L_CAT ? BH + BE1 : l == L_CL ? BH + BE2 : BH; }
+__host__ __device__ constexpr int n_out(int l) { return l == L_OC ? 3 : BH; }
+// column of the layer's weight matrix that extended input index k (16 s + 8 h + j) reads, -1 = padding
+__device__ __forceinline__ int in_col(int l, int k) {
+  if (l == L_IN) return k < BE1 ? k : -1;
+  if (k < BH) return k;
+  const int q = k - BH;
+  if (l == L_CAT) return q < BE1 ? BH + q : -1;
+  if (l == L_CL) return q < BE2 ? BH + q : -1;
+  return -1;
+}
+
+// LDS image strides (bytes): [sample][feature] f16 rows padded so that the 16-byte operand reads of 16 consecutive samples
+// fall on 16 different bank quads
+constexpr int ST_X = 272, ST_E1B = 208, ST_E2B = 112, ST_OC = 48;
+// Samples per workgroup tile of the forward / backward kernels: 32 = one MFMA column block.  M = 16 800 gives 525 tiles at
+// 51 KB (forward) / 45 KB (backward) of LDS: all resident at once, two or three workgroups per CU to cover each other's
+// dependent latency (weight fragments from L2 -> products -> epilogue -> barrier, per layer).  With 64-sample tiles (103 KB, one
+// workgroup per CU) 263 tiles took two rounds on 256 CUs.
+constexpr int TS = 32, NH = TS / 32;
+constexpr int XIMG = TS * ST_X, E1IMG = TS * ST_E1B, E2IMG = TS * ST_E2B;
+
+// ------------------------------------------------------------------------------------------------------------------------
+// pack: one block per fragment
+// ------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bg_pack_kernel(const float* __restrict__ theta, unsigned char* __restrict__ packed) {
+  const int f = blockIdx.x;
+  _Float16* out = reinterpret_cast<_Float16*>(packed + (size_t)f * FRAG_BYTES);
+  int kind, idx;   // 0 hi, 1 lo, 2 transposed
+  if (f < NF_FWD) { kind = 0; idx = f; } else if (f < NF_FWD + NF_LO) { kind = 1; idx = f - NF_FWD; } else { kind = 2; idx = f - NF_FWD - NF_LO; }
+  for (int e = threadIdx.x; e < 512; e += 256) {
+    const int lane = e >> 3, j = e & 7, r = lane & 31, h = lane >> 5;
+    float v = 0.0f;
+    if (kind < 2) {
+      int l = idx < 24 ? L_IN : idx < 56 ? L_M1 : idx < 112 ? L_CAT : idx < 144 ? L_M2 : idx < 188 ? L_CL : L_OC;
+      const int rel = idx - fwd_base(l), w = l == L_OC ? 0 : rel / ks(l), s = l == L_OC ? rel : rel % ks(l);
+      const int o = 32 * w + r, c = in_col(l, 16 * s + 8 * h + j);
+      if (o < n_out(l) && c >= 0) v = theta[w_off(l) + o * ld_of(l) + c];
+      if (kind == 1) v = v - (float)(_Float16)v;
+    } else {
+      int l = idx < 4 ? L_OC : idx < 52 ? L_CL : idx < 84 ? L_M2 : idx < 140 ? L_CAT : idx < 172 ? L_M1 : L_IN;
+      const int rel = idx - bwd_base(l), ib = l == L_OC ? rel : rel / 8, s = l == L_OC ? 0 : rel % 8;
+      // row = input feature 32 ib + r of the layer's extended input; for in_layer the blocks are its E1 inputs
+      const int kin = l == L_IN ? 32 * ib + r : 32 * ib + r;
+      const int c = l == L_IN ? (kin < BE1 ? kin : -1) : in_col(l, kin);
+      const int o = 16 * s + 8 * h + j;
+      if (c >= 0 && o < n_out(l)) v = theta[w_off(l) + o * ld_of(l) + c];
+    }
+    out[lane * 8 + j] = (_Float16)v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// shared device helpers
+// ------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ h8 gfrag(const unsigned char* __restrict__ img, int f, int lane) {
+  return *reinterpret_cast<const h8*>(img + (size_t)f * FRAG_BYTES + lane * 16);
+}
+// B operand of k-step s of a [sample][feature] image: lane (sample, h) reads features 16 s + 8 h .. + 7
+__device__ __forceinline__ h8 xfrag(const unsigned char* img, int stride, int sample, int s, int h) {
+  return *reinterpret_cast<const h8*>(img + sample * stride + (16 * s + 8 * h) * 2);
+}
+// accumulator rows of wave block w as a function of (reg, h): feature = 32 w + acc_row(reg, h)
+// store 16 accumulator values (f16) of one sample into an image: four 8-byte pieces
+__device__ __forceinline__ void store_acc_h(unsigned char* img, int stride, int sample, int w, int h, const f16v& a, bool relu,
+                                            unsigned char* img_lo) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float x[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) x[q] = relu ? fmaxf(a[4 * g + q], 0.0f) : a[4 * g + q];
+    h4 hi = {(_Float16)x[0], (_Float16)x[1], (_Float16)x[2], (_Float16)x[3]};
+    unsigned char* p = img + sample * stride + (32 * w + 8 * g + 4 * h) * 2;
+    *reinterpret_cast<h4*>(p) = hi;
+    if (img_lo) {
+      h4 lo = {(_Float16)(x[0] - (float)hi[0]), (_Float16)(x[1] - (float)hi[1]), (_Float16)(x[2] - (float)hi[2]),
+               (_Float16)(x[3] - (float)hi[3])};
+      *reinterpret_cast<h4*>(img_lo + sample * stride + (32 * w + 8 * g + 4 * h) * 2) = lo;
+    }
+  }
+}
+__device__ __forceinline__ f16v bias_acc(const float* __restrict__ b, int w, int h, int nvalid) {
+  f16v a;
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const int o = 32 * w + acc_row(reg, h);
+    a[reg] = o < nvalid ? b[o] : 0.0f;
+  }
+  return a;
+}
+// copy a [TS][128] f16 image (stride ST_X) to global rows [m0, m0 + TS) of an (M, 128) f16 array, 16 bytes per thread and trip
+__device__ __forceinline__ void image_to_global(const unsigned char* img, _Float16* __restrict__ dst, int m0, int M) {
+  for (int i = threadIdx.x; i < TS * 16; i += 256) {
+    const int row = i >> 4, ch = i & 15;
+    if (m0 + row < M)
+      *reinterpret_cast<f4*>(reinterpret_cast<unsigned char*>(dst + (size_t)(m0 + row) * BH) + ch * 16) =
+          *reinterpret_cast<const f4*>(img + row * ST_X + ch * 16);
+  }
+}
+__device__ __forceinline__ void global_to_image(unsigned char* img, const _Float16* __restrict__ src, int m0, int M) {
+  for (int i = threadIdx.x; i < TS * 16; i += 256) {
+    const int row = i >> 4, ch = i & 15;
+    f4 v = {0.f, 0.f, 0.f, 0.f};
+    if (m0 + row < M)
+      v = *reinterpret_cast<const f4*>(reinterpret_cast<const unsigned char*>(src + (size_t)(m0 + row) * BH) + ch * 16);
+    *reinterpret_cast<f4*>(img + row * ST_X + ch * 16) = v;
+  }
+}
+
+// positional encoding of the tile: thread = (sample c, direction group g); natural feature order e[0..2] = t,
+// e[3 + 21 b + d] = sin(pi 2^b p_d) (src/embedding.py:82-92) into the E1 (features 0..86, hi and residual) and E2 (87..128)
+// images; pads zeroed.  Also the hi features to global rows (M, 144) for the weight-gradient kernel.
+__device__ __forceinline__ void pe_images(const float* __restrict__ pts, const float* __restrict__ Bm, float inv_scale, int m0,
+                                          int M, unsigned char* E1h, unsigned char* E1l, unsigned char* E2h) {
+  constexpr int NG = 256 / TS;     // direction groups
+  const int c = threadIdx.x % TS, g = threadIdx.x / TS;
+  const int m = m0 + c < M ? m0 + c : M - 1;
+  const float t0 = pts[(size_t)m * 3 + 0] * inv_scale, t1 = pts[(size_t)m * 3 + 1] * inv_scale, t2 = pts[(size_t)m * 3 + 2] * inv_scale;
+  _Float16* e1h = reinterpret_cast<_Float16*>(E1h + c * ST_E1B);
+  _Float16* e1l = E1l ? reinterpret_cast<_Float16*>(E1l + c * ST_E1B) : nullptr;
+  _Float16* e2h = reinterpret_cast<_Float16*>(E2h + c * ST_E2B);
+  auto put1 = [&](int f, float v) {
+    const _Float16 hi = (_Float16)v;
+    e1h[f] = hi;
+    if (e1l) e1l[f] = (_Float16)(v - (float)hi);
+  };
+  if (g == 0) {
+    put1(0, t0); put1(1, t1); put1(2, t2);
+    for (int f = BE1; f < BE1P; ++f) put1(f, 0.0f);
+    for (int f = BE2; f < BE2P; ++f) e2h[f] = (_Float16)0;
+  }
+  for (int d = g; d < 21; d += NG) {
+    const float p = Bm[3 * d] * t0 + Bm[3 * d + 1] * t1 + Bm[3 * d + 2] * t2;
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+      const float v = __builtin_amdgcn_sinf(p * (0.5f * (float)(1 << b)));   // sin(pi 2^b p): the hardware sine takes revolutions
+      const int f = 3 + 21 * b + d;
+      if (b < 4) put1(f, v); else e2h[f - BE1] = (_Float16)v;
+    }
+  }
+}
+
+// one k-range of a layer: acc[half] += W[s0 .. s0 + NS) x image columns; GEO: three products with the residual weights / image
+template <int NS, bool GEO>
+__device__ __forceinline__ void mma_range(const unsigned char* __restrict__ pk, int f_hi, int f_lo, const unsigned char* Xh,
+                                          const unsigned char* Xl, int stride, int lane, f16v (&acc)[NH]) {
+  const int c = lane & 31, h = lane >> 5;
+  h8 wh[NS], wl[GEO ? NS : 1];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) wh[s] = gfrag(pk + PK_FWD_OFF, f_hi + s, lane);
+  if constexpr (GEO) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) wl[s] = gfrag(pk + PK_LO_OFF, f_lo + s, lane);
+  }
+#pragma unroll
+  for (int half = 0; half < NH; ++half) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const h8 xh = xfrag(Xh, stride, c + 32 * half, s, h);
+      acc[half] = MFMA(wh[s], xh, acc[half]);
+      if constexpr (GEO) {
+        acc[half] = MFMA(wl[s], xh, acc[half]);
+        acc[half] = MFMA(wh[s], xfrag(Xl, stride, c + 32 * half, s, h), acc[half]);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------------------------------
+struct BgFwdArgs {
+  const float* pts; const float* theta; const unsigned char* packed; float inv_scale; int M;
+  float* sigma; float* rgb;            // (M,), (M,3)
+  _Float16* act;                       // 5 x (M,128): a1 .. a5 (post-ReLU, f16)
+  _Float16* eimg;                      // (M,144): PE features (hi), E1 in columns 0..95, E2 in 96..143
+};
+__device__ __forceinline__ void store_tile(unsigned char* img, unsigned char* img_lo, int c, int w, int h, const f16v (&acc)[NH], bool relu) {
+#pragma unroll
+  for (int half = 0; half < NH; ++half) store_acc_h(img, ST_X, c + 32 * half, w, h, acc[half], relu, img_lo);
+}
+__device__ __forceinline__ void init_tile(f16v (&acc)[NH], const float* __restrict__ b, int w, int h, int nvalid) {
+  const f16v v = bias_acc(b, w, h, nvalid);
+#pragma unroll
+  for (int half = 0; half < NH; ++half) acc[half] = v;
+}
+
+__global__ __launch_bounds__(256, 2) void bg_fwd_kernel(BgFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* E1h = smem;
+  unsigned char* E1l = E1h + E1IMG;
+  unsigned char* E2h = E1l + E1IMG;
+  unsigned char* Xh0 = E2h + E2IMG;
+  unsigned char* Xl0 = Xh0 + XIMG;
+  unsigned char* Xh1 = Xl0 + XIMG;
+  unsigned char* Xl1 = Xh1 + XIMG;
+  float* sigp = reinterpret_cast<float*>(Xl1 + XIMG);   // [4][TS]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.x * TS, M = a.M;
+  const float* th = a.theta;
+  pe_images(a.pts, th + O_PE_B, a.inv_scale, m0, M, E1h, E1l, E2h);
+  __syncthreads();
+  // PE features (hi) -> global for the weight-gradient kernel: rows of 288 bytes = 18 x 16
+  for (int i = threadIdx.x; i < TS * 18; i += 256) {
+    const int row = i / 18, ch = i % 18;
+    if (m0 + row < M) {
+      const f4 v = ch < 12 ? *reinterpret_cast<const f4*>(E1h + row * ST_E1B + ch * 16)
+                           : *reinterpret_cast<const f4*>(E2h + row * ST_E2B + (ch - 12) * 16);
+      *reinterpret_cast<f4*>(reinterpret_cast<unsigned char*>(a.eimg + (size_t)(m0 + row) * BEP) + ch * 16) = v;
+    }
+  }
+  f16v acc[NH];
+  const size_t MH = (size_t)M * BH;
+  // ---- in_layer: E1 -> a1 -----------------------------------------------------------------------------------------
+  init_tile(acc, th + O_IN_B, w, h, BH);
+  mma_range<6, true>(a.packed, fwd_base(L_IN) + 6 * w, fwd_base(L_IN) + 6 * w, E1h, E1l, ST_E1B, lane, acc);
+  store_tile(Xh0, Xl0, c, w, h, acc, true);
+  __syncthreads();
+  image_to_global(Xh0, a.act + 0 * MH, m0, M);
+  // ---- mid1: a1 -> a2 -------------------------------------------------------------------------------------------------
+  init_tile(acc, th + O_M1_B, w, h, BH);
+  mma_range<8, true>(a.packed, fwd_base(L_M1) + 8 * w, fwd_base(L_M1) + 8 * w, Xh0, Xl0, ST_X, lane, acc);
+  store_tile(Xh1, Xl1, c, w, h, acc, true);
+  __syncthreads();
+  image_to_global(Xh1, a.act + 1 * MH, m0, M);
+  // ---- cat_layer: [a2 | e1] -> a3 (image 0 = a1 was last read before the barrier above) ------------------------------
+  init_tile(acc, th + O_CAT_B, w, h, BH);
+  mma_range<8, true>(a.packed, fwd_base(L_CAT) + 14 * w, fwd_base(L_CAT) + 14 * w, Xh1, Xl1, ST_X, lane, acc);
+  mma_range<6, true>(a.packed, fwd_base(L_CAT) + 14 * w + 8, fwd_base(L_CAT) + 14 * w + 8, E1h, E1l, ST_E1B, lane, acc);
+  store_tile(Xh0, Xl0, c, w, h, acc, true);
+  __syncthreads();
+  image_to_global(Xh0, a.act + 2 * MH, m0, M);
+  // ---- mid2: a3 -> a4, and the x10 occupancy head as an fp32 dot product of the fp32 activations -----------------------
+  init_tile(acc, th + O_M2_B, w, h, BH);
+  mma_range<8, true>(a.packed, fwd_base(L_M2) + 8 * w, fwd_base(L_M2) + 8 * w, Xh0, Xl0, ST_X, lane, acc);
+  {
+    float wa[16];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) wa[reg] = th[O_OA_W + 32 * w + acc_row(reg, h)];
+#pragma unroll
+    for (int half = 0; half < NH; ++half) {
+      float part = 0.0f;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) part = fmaf(wa[reg], fmaxf(acc[half][reg], 0.0f), part);
+      part += __shfl_xor(part, 32, 64);
+      if (h == 0) sigp[w * TS + c + 32 * half] = part;
+    }
+  }
+  store_tile(Xh1, nullptr, c, w, h, acc, true);   // image 1 = a2: last read by cat_layer, a barrier ago
+  __syncthreads();
+  image_to_global(Xh1, a.act + 3 * MH, m0, M);
+  if (threadIdx.x < TS && m0 + threadIdx.x < M) {
+    const int s = threadIdx.x;   // alpha = raw * 10 (src/model.py:142)
+    a.sigma[m0 + s] = 10.0f * (((sigp[s] + sigp[TS + s]) + (sigp[2 * TS + s] + sigp[3 * TS + s])) + th[O_OA_B]);
+  }
+  // ---- color_linear: [a4 | e2] -> a5 (colour branch: plain f16) --------------------------------------------------------
+  init_tile(acc, th + O_CL_B, w, h, BH);
+  mma_range<8, false>(a.packed, fwd_base(L_CL) + 11 * w, 0, Xh1, nullptr, ST_X, lane, acc);
+  mma_range<3, false>(a.packed, fwd_base(L_CL) + 11 * w + 8, 0, E2h, nullptr, ST_E2B, lane, acc);
+  store_tile(Xh0, nullptr, c, w, h, acc, true);   // image 0 = a3: last read by mid2
+  __syncthreads();
+  image_to_global(Xh0, a.act + 4 * MH, m0, M);
+  // ---- out_color (3 outputs): wave 0, rows 0..2 = registers 0..2 of lane half 0 ------------------------------------------
+  if (w == 0) {
+    init_tile(acc, th + O_OC_B, 0, h, 3);
+    mma_range<8, false>(a.packed, fwd_base(L_OC), 0, Xh0, nullptr, ST_X, lane, acc);
+    if (h == 0) {
+#pragma unroll
+      for (int half = 0; half < NH; ++half) {
+        const int m = m0 + c + 32 * half;
+        if (m < M) {
+          float* o = a.rgb + (size_t)m * 3;
+          o[0] = 1.0f / (1.0f + __expf(-acc[half][0])); o[1] = 1.0f / (1.0f + __expf(-acc[half][1]));
+          o[2] = 1.0f / (1.0f + __expf(-acc[half][2]));
+        }
+      }
+    }
+  }
+}
+constexpr int BG_FWD_LDS = 2 * E1IMG + E2IMG + 4 * XIMG + 4 * TS * 4;
+
+// ------------------------------------------------------------------------------------------------------------------------
+// backward (data-gradient chain)
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr int BG_REC = 640;   // per-workgroup record (floats): dW out_color 384 | db out_color 3 (+1) | dW out_alpha 128 | db out_alpha 1 (+3) | dB 63 (+..)
+constexpr int R_OCW = 0, R_OCB = 384, R_OAW = 388, R_OAB = 516, R_PEB = 520;
+struct BgBwdArgs {
+  const float* pts; const float* theta; const unsigned char* packed; float inv_scale; int M;
+  const float* d_sigma; const float* d_rgb; const float* rgb;       // upstream gradients (already x grad_scale), forward colours
+  const _Float16* act;                 // 5 x (M,128)
+  _Float16* dpre;                      // 5 x (M,128): scaled pre-activation gradients of in_layer, mid1, cat, mid2, color_linear
+  float* records;                      // (blocks, BG_REC)
+  int64_t* d_state; int64_t add_rows;  // d_state != NULL: block 0 advances the step state (see cnr_bg_backward)
+};
+
+// acc[half] = sum over the 8 k-steps (128 output features) of W^T block `fb` times the dPre image
+__device__ __forceinline__ void bwd_block(const unsigned char* __restrict__ pk, int fb, const unsigned char* D, int lane, f16v (&acc)[NH]) {
+  const int c = lane & 31, h = lane >> 5;
+  h8 wt[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) wt[s] = gfrag(pk + PK_BWD_OFF, fb + s, lane);
+#pragma unroll
+  for (int half = 0; half < NH; ++half)
+#pragma unroll
+    for (int s = 0; s < 8; ++s) acc[half] = MFMA(wt[s], xfrag(D, ST_X, c + 32 * half, s, h), acc[half]);
+}
+// dPre = d act * (act > 0): the activation image gives this lane's 16 features in the accumulator layout
+__device__ __forceinline__ void mask_store(unsigned char* Dimg, const unsigned char* Aimg, int sample, int w, int h, const f16v& a) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const h4 act = *reinterpret_cast<const h4*>(Aimg + sample * ST_X + (32 * w + 8 * g + 4 * h) * 2);
+    h4 d;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) d[q] = act[q] > (_Float16)0 ? (_Float16)a[4 * g + q] : (_Float16)0;
+    *reinterpret_cast<h4*>(Dimg + sample * ST_X + (32 * w + 8 * g + 4 * h) * 2) = d;
+  }
+}
+__device__ __forceinline__ void mask_tile(unsigned char* Dimg, const unsigned char* Aimg, int c, int w, int h, const f16v (&acc)[NH]) {
+#pragma unroll
+  for (int half = 0; half < NH; ++half) mask_store(Dimg, Aimg, c + 32 * half, w, h, acc[half]);
+}
+__device__ __forceinline__ void zero_tile(f16v (&acc)[NH]) {
+#pragma unroll
+  for (int half = 0; half < NH; ++half)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[half][i] = 0.0f;
+}
+
+__global__ __launch_bounds__(256, 2) void bg_bwd_kernel(BgBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* D0 = smem;
+  unsigned char* D1 = D0 + XIMG;
+  unsigned char* Aim = D1 + XIMG;
+  float* DE1 = reinterpret_cast<float*>(Aim + XIMG);        // [TS][96] d e1 (fp32, scaled)
+  float* DE2 = DE1 + TS * BE1P;                              // [TS][48]
+  unsigned char* OCimg = reinterpret_cast<unsigned char*>(DE2 + TS * BE2P);   // [TS][16] f16 (+ pad): dPre of out_color in columns 0..2
+  float* dsg = reinterpret_cast<float*>(OCimg + TS * ST_OC);                   // [TS] 10 x scaled d sigma
+  float* tpos = dsg + TS;                                                      // [TS][3] t = x / scale
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.x * TS, M = a.M;
+  const float* th = a.theta;
+  const size_t MH = (size_t)M * BH;
+  float* rec = a.records + (size_t)blockIdx.x * BG_REC;
+  // the step state moves here: the sampler (which reads the cursor) ran earlier in the step, the optimiser launch (which reads
+  // the step count) comes later -- no launch of its own for three integer adds
+  if (a.d_state && blockIdx.x == 0 && threadIdx.x == 0) { a.d_state[0] += a.add_rows; a.d_state[1] += 1; a.d_state[2] += 1; }
+  // ---- upstream: dPre of out_color = d rgb * rgb (1 - rgb); 10 x d sigma; sample positions ------------------------------
+  if (threadIdx.x < TS) {
+    const int s = threadIdx.x, m = m0 + s;
+    const bool ok = m < M;
+    _Float16* o = reinterpret_cast<_Float16*>(OCimg + s * ST_OC);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      float v = 0.0f;
+      if (ok && j < 3) { const float r = a.rgb[(size_t)m * 3 + j]; v = a.d_rgb[(size_t)m * 3 + j] * r * (1.0f - r); }
+      o[j] = (_Float16)v;
+    }
+    // the f16 chain needs |10 d sigma| within range: clipped like the category kernel's (include/cnr_hip.h, clamp_flags)
+    dsg[s] = ok ? fminf(fmaxf(a.d_sigma[m], -8192.0f), 8192.0f) * 10.0f : 0.0f;
+    const int mc = ok ? m : M - 1;
+    tpos[3 * s + 0] = a.pts[(size_t)mc * 3 + 0] * a.inv_scale; tpos[3 * s + 1] = a.pts[(size_t)mc * 3 + 1] * a.inv_scale;
+    tpos[3 * s + 2] = a.pts[(size_t)mc * 3 + 2] * a.inv_scale;
+  }
+  global_to_image(Aim, a.act + 4 * MH, m0, M);   // a5
+  __syncthreads();
+  // ---- out_color: weight / bias gradient on the VALU (3 x 128 + 3), d a5 on the matrix core -----------------------------
+  {
+    const int f = threadIdx.x & 127, jj = threadIdx.x >> 7;   // outputs j = jj and jj + 2
+    float s0 = 0.0f, s1 = 0.0f;
+    for (int s = 0; s < TS; ++s) {
+      const float x = (float)reinterpret_cast<const _Float16*>(Aim + s * ST_X)[f];
+      const _Float16* o = reinterpret_cast<const _Float16*>(OCimg + s * ST_OC);
+      s0 = fmaf((float)o[jj], x, s0);
+      if (jj == 0) s1 = fmaf((float)o[2], x, s1);
+    }
+    rec[R_OCW + jj * BH + f] = s0;
+    if (jj == 0) rec[R_OCW + 2 * BH + f] = s1;
+    if (threadIdx.x < 3) {
+      float sb = 0.0f;
+      for (int s = 0; s < TS; ++s) sb += (float)reinterpret_cast<const _Float16*>(OCimg + s * ST_OC)[threadIdx.x];
+      rec[R_OCB + threadIdx.x] = sb;
+    }
+  }
+  f16v acc[NH], ae[NH];
+  zero_tile(acc);
+  {
+    const h8 wt = gfrag(a.packed + PK_BWD_OFF, bwd_base(L_OC) + w, lane);
+#pragma unroll
+    for (int half = 0; half < NH; ++half) {
+      const h8 x = *reinterpret_cast<const h8*>(OCimg + (c + 32 * half) * ST_OC + 8 * h * 2);
+      acc[half] = MFMA(wt, x, acc[half]);
+    }
+  }
+  mask_tile(D0, Aim, c, w, h, acc);      // dPre5
+  __syncthreads();
+  image_to_global(D0, a.dpre + 4 * MH, m0, M);
+  // ---- color_linear^T: d a4 (colour part) + d e2 ; + out_alpha ------------------------------------------------------------
+  zero_tile(acc);
+  bwd_block(a.packed, bwd_base(L_CL) + 8 * w, D0, lane, acc);
+  if (w < 2) {
+    zero_tile(ae);
+    bwd_block(a.packed, bwd_base(L_CL) + 8 * (4 + w), D0, lane, ae);
+#pragma unroll
+    for (int half = 0; half < NH; ++half)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int q = 32 * w + acc_row(reg, h);
+        if (q < BE2P) DE2[(c + 32 * half) * BE2P + q] = ae[half][reg];
+      }
+  }
+  global_to_image(Aim, a.act + 3 * MH, m0, M);   // a4 (the a5 image was last read before the barrier above)
+  __syncthreads();
+  {
+    // out_alpha: dW = sum_s (10 d sigma_s) a4[s][f], db = sum_s 10 d sigma_s ; d a4 += w_alpha 10 d sigma
+    if (threadIdx.x < 128) {
+      float sw = 0.0f;
+      for (int s = 0; s < TS; ++s) sw = fmaf(dsg[s], (float)reinterpret_cast<const _Float16*>(Aim + s * ST_X)[threadIdx.x], sw);
+      rec[R_OAW + threadIdx.x] = sw;
+    } else if (threadIdx.x == 128) {
+      float sb = 0.0f;
+      for (int s = 0; s < TS; ++s) sb += dsg[s];
+      rec[R_OAB] = sb;
+    }
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const float wa = th[O_OA_W + 32 * w + acc_row(reg, h)];
+#pragma unroll
+      for (int half = 0; half < NH; ++half) acc[half][reg] = fmaf(wa, dsg[c + 32 * half], acc[half][reg]);
+    }
+  }
+  mask_tile(D1, Aim, c, w, h, acc);      // dPre4
+  __syncthreads();
+  image_to_global(D1, a.dpre + 3 * MH, m0, M);
+  // ---- mid2^T -> dPre3 ---------------------------------------------------------------------------------------------------
+  zero_tile(acc);
+  bwd_block(a.packed, bwd_base(L_M2) + 8 * w, D1, lane, acc);
+  global_to_image(Aim, a.act + 2 * MH, m0, M);   // a3 (the a4 image was last read before the barrier above)
+  __syncthreads();
+  mask_tile(D0, Aim, c, w, h, acc);
+  __syncthreads();
+  image_to_global(D0, a.dpre + 2 * MH, m0, M);
+  // ---- cat_layer^T -> d a2, d e1 -------------------------------------------------------------------------------------------
+  zero_tile(acc);
+  bwd_block(a.packed, bwd_base(L_CAT) + 8 * w, D0, lane, acc);
+  if (w < 3) {
+    zero_tile(ae);
+    bwd_block(a.packed, bwd_base(L_CAT) + 8 * (4 + w), D0, lane, ae);
+  }
+  global_to_image(Aim, a.act + 1 * MH, m0, M);   // a2
+  __syncthreads();
+  mask_tile(D1, Aim, c, w, h, acc);      // dPre2
+  __syncthreads();
+  image_to_global(D1, a.dpre + 1 * MH, m0, M);
+  // ---- mid1^T -> dPre1 -----------------------------------------------------------------------------------------------------
+  zero_tile(acc);
+  bwd_block(a.packed, bwd_base(L_M1) + 8 * w, D1, lane, acc);
+  global_to_image(Aim, a.act + 0 * MH, m0, M);   // a1
+  __syncthreads();
+  mask_tile(D0, Aim, c, w, h, acc);
+  __syncthreads();
+  image_to_global(D0, a.dpre + 0 * MH, m0, M);
+  // ---- in_layer^T -> d e1 (on top of cat_layer's) --------------------------------------------------------------------------
+  if (w < 3) {
+    bwd_block(a.packed, bwd_base(L_IN) + 8 * w, D0, lane, ae);
+#pragma unroll
+    for (int half = 0; half < NH; ++half)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg)
+        DE1[(c + 32 * half) * BE1P + 32 * w + acc_row(reg, h)] = ae[half][reg];
+  }
+  __syncthreads();
+  // ---- PE backward -> d B_layer.weight: a wave takes 64 / TS directions at a time; lane = (direction slot, sample) ---------
+  {
+    constexpr int DPW = 64 / TS;                       // directions per wave and trip
+    const int s = lane % TS, dsel = lane / TS;
+    const bool ok = m0 + s < M;
+    const float t0 = tpos[3 * s], t1 = tpos[3 * s + 1], t2 = tpos[3 * s + 2];
+    for (int d0 = w * DPW; d0 < 21; d0 += 4 * DPW) {
+      const int d = d0 + dsel, dc = d < 21 ? d : 20;
+      const float p = th[O_PE_B + 3 * dc] * t0 + th[O_PE_B + 3 * dc + 1] * t1 + th[O_PE_B + 3 * dc + 2] * t2;
+      float gp = 0.0f;
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        const int f = 3 + 21 * b + dc;
+        const float de = b < 4 ? DE1[s * BE1P + f] : DE2[s * BE2P + (f - BE1)];
+        gp = fmaf(de * __builtin_amdgcn_cosf(p * (0.5f * (float)(1 << b))), 3.14159265358979f * (float)(1 << b), gp);
+      }
+      if (!ok || d >= 21) gp = 0.0f;
+      float g0 = gp * t0, g1 = gp * t1, g2 = gp * t2;
+#pragma unroll
+      for (int o = TS / 2; o > 0; o >>= 1) { g0 += __shfl_xor(g0, o, 64); g1 += __shfl_xor(g1, o, 64); g2 += __shfl_xor(g2, o, 64); }
+      if (s == 0 && d < 21) { rec[R_PEB + 3 * d] = g0; rec[R_PEB + 3 * d + 1] = g1; rec[R_PEB + 3 * d + 2] = g2; }
+    }
+  }
+}
+constexpr int BG_BWD_LDS = 3 * XIMG + TS * (BE1P + BE2P) * 4 + TS * ST_OC + TS * 4 + TS * 12 + 64;
+
+// ------------------------------------------------------------------------------------------------------------------------
+// weight gradients of the five 128-wide layers: dW[n][k] = sum_m dPre[m][n] X[m][k], db[n] = sum_m dPre[m][n]
+// grid (20, chunks): block = (layer, 32-output block n) x sample chunk.  The workgroup stages 64-sample tiles of dPre[:, n block]
+// and of the layer's input rows in LDS (double-buffered: the next tile's global loads are in flight under the products of the
+// current one); a [sample][feature] tile gives both MFMA operands through transposing reads (ds_read_b64_tr_b16).  The four
+// waves split the layer's 32-wide INPUT blocks (+ one "ones" block whose column 0 is the bias gradient), so every wave keeps
+// its own accumulators for the whole chunk and writes them out itself -- no reduction inside the workgroup.
+// ------------------------------------------------------------------------------------------------------------------------
+typedef short s4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ h8 tr_frag_b(const unsigned char* img, int stride, int col0, int s, int lane) {
+  const int i = lane & 15, g16 = lane >> 4, q = i >> 2, p = i & 3, hh = g16 >> 1;
+  const unsigned char* ad = img + (16 * s + 8 * hh + q) * stride + (col0 + 16 * (g16 & 1) + 4 * p) * 2;
+  typedef __attribute__((address_space(3))) s4v* lds_s4;
+  const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(ad));
+  const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(ad + 4 * stride));
+  h8 r;
+  r.lo = __builtin_bit_cast(h4, lo);
+  r.hi = __builtin_bit_cast(h4, hi);
+  return r;
+}
+struct BgDwArgs {
+  const _Float16* act; const _Float16* dpre; const _Float16* eimg; int M; int chunk;   // chunk: samples per block (multiple of 64)
+  float* partials;                                                                       // (chunks, BG_NPARAM)
+};
+constexpr int DW_XST = 464;          // X tile row stride (bytes): up to 224 features + pad (29 x 16)
+constexpr int DW_DST = 80;           // dPre tile row stride: 32 features + pad
+constexpr int DW_BUF = 64 * DW_XST + 64 * DW_DST;
+template <int LAYER>
+__device__ __forceinline__ void dw_layer(const BgDwArgs& a, int nb, unsigned char* smem) {
+  constexpr int KB = LAYER == L_IN ? 3 : LAYER == L_CAT ? 7 : LAYER == L_CL ? 6 : 4;    // 32-wide input blocks
+  constexpr int NA = LAYER == L_IN ? 0 : 4;                                                // of which from the hidden activation
+  constexpr int AIDX = LAYER == L_M1 ? 0 : LAYER == L_CAT ? 1 : LAYER == L_M2 ? 2 : 3;   // which activation array feeds it
+  constexpr int DIDX = LAYER == L_IN ? 0 : LAYER == L_M1 ? 1 : LAYER == L_CAT ? 2 : LAYER == L_M2 ? 3 : 4;
+  constexpr int ECOL = LAYER == L_CL ? BE1P : 0, EW = LAYER == L_CL ? BE2P : BE1P;          // PE columns of the (M,144) image
+  constexpr int XCH = NA * 4 + (KB > NA ? EW / 8 : 0);                                    // 16-byte pieces per X row (a 32-feature block = 4)
+  constexpr int XPT = (64 * XCH + 255) / 256;                                            // X pieces per thread and tile
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const size_t MH = (size_t)a.M * BH;
+  // this wave's blocks: wv and wv + 4 of [0, KB] (block KB = the bias block)
+  const bool has1 = wv + 4 <= KB;
+  f16v acc0, acc1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
+  h8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = (lane & 31) == 0 ? (_Float16)1 : (_Float16)0;   // column 0 of the bias block = sum over samples
+  const int mc0 = blockIdx.y * a.chunk, mc1 = mc0 + a.chunk < a.M ? mc0 + a.chunk : a.M;
+  f4 dreg, xreg[XPT];
+  auto load_tile = [&](int m0) {
+    {
+      const int row = threadIdx.x >> 2, ch = threadIdx.x & 3;
+      dreg = f4{0.f, 0.f, 0.f, 0.f};
+      if (m0 + row < mc1)
+        dreg = *reinterpret_cast<const f4*>(reinterpret_cast<const unsigned char*>(a.dpre + DIDX * MH + (size_t)(m0 + row) * BH + 32 * nb) + ch * 16);
+    }
+#pragma unroll
+    for (int e = 0; e < XPT; ++e) {
+      const int i = e * 256 + threadIdx.x, row = i / XCH, ch = i % XCH;
+      f4 v = {0.f, 0.f, 0.f, 0.f};
+      if (i < 64 * XCH && m0 + row < mc1) {
+        if (ch < NA * 4)
+          v = *reinterpret_cast<const f4*>(reinterpret_cast<const unsigned char*>(a.act + AIDX * MH + (size_t)(m0 + row) * BH) + ch * 16);
+        else
+          v = *reinterpret_cast<const f4*>(reinterpret_cast<const unsigned char*>(a.eimg + (size_t)(m0 + row) * BEP + ECOL) + (ch - NA * 4) * 16);
+      }
+      xreg[e] = v;
+    }
+  };
+  auto store_tile_lds = [&](unsigned char* buf) {
+    unsigned char* Xt = buf;
+    unsigned char* Dt = buf + 64 * DW_XST;
+    *reinterpret_cast<f4*>(Dt + (threadIdx.x >> 2) * DW_DST + (threadIdx.x & 3) * 16) = dreg;
+#pragma unroll
+    for (int e = 0; e < XPT; ++e) {
+      const int i = e * 256 + threadIdx.x, row = i / XCH, ch = i % XCH;
+      if (i < 64 * XCH) *reinterpret_cast<f4*>(Xt + row * DW_XST + ch * 16) = xreg[e];
+    }
+    if constexpr (LAYER == L_CL) {   // the second PE block is half empty (48 columns): columns 48..63 of it are zero
+      if (threadIdx.x < 128) *reinterpret_cast<f4*>(Xt + (threadIdx.x >> 1) * DW_XST + NA * 64 + 96 + (threadIdx.x & 1) * 16) = f4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  int buf = 0;
+  if (mc0 < mc1) { load_tile(mc0); store_tile_lds(smem); }
+  __syncthreads();
+  for (int m0 = mc0; m0 < mc1; m0 += 64) {
+    const bool more = m0 + 64 < mc1;
+    if (more) load_tile(m0 + 64);                      // global loads of the next tile under this tile's products
+    const unsigned char* Xt = smem + buf * DW_BUF;
+    const unsigned char* Dt = Xt + 64 * DW_XST;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {      // 16 samples per k-step
+      const h8 df = tr_frag_b(Dt, DW_DST, 0, s, lane);
+      if (wv < KB) acc0 = MFMA(df, tr_frag_b(Xt, DW_XST, 32 * wv, s, lane), acc0);
+      else acc0 = MFMA(df, ones, acc0);                                      // (KB = 3: wave 3 holds the bias block)
+      if (has1) {
+        if (wv + 4 < KB) acc1 = MFMA(df, tr_frag_b(Xt, DW_XST, 32 * (wv + 4), s, lane), acc1);
+        else acc1 = MFMA(df, ones, acc1);
+      }
+    }
+    if (more) store_tile_lds(smem + (buf ^ 1) * DW_BUF);
+    __syncthreads();
+    buf ^= 1;
+  }
+  // ---- out: accumulator rows = outputs n, lanes = input columns --------------------------------------------------------------
+  float* part = a.partials + (size_t)blockIdx.y * BG_NPARAM;
+  const int kcol = lane & 31, hh = lane >> 5;
+  constexpr int WOFF = w_off(LAYER), BOFF = b_off(LAYER), LD = ld_of(LAYER);
+  auto write_block = [&](int k, const f16v& acc) {
+    if (k == KB) {
+      if (kcol == 0) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) part[BOFF + 32 * nb + acc_row(reg, hh)] = acc[reg];
+      }
+      return;
+    }
+    int wcol;
+    if (k < NA) wcol = 32 * k + kcol;
+    else {
+      const int q = 32 * (k - NA) + kcol;
+      const int ew = LAYER == L_CL ? BE2 : BE1;
+      wcol = q < ew ? (LAYER == L_IN ? q : BH + q) : -1;
+    }
+    if (wcol >= 0) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) part[WOFF + (32 * nb + acc_row(reg, hh)) * LD + wcol] = acc[reg];
+    }
+  };
+  if (wv <= KB) write_block(wv, acc0);
+  if (has1) write_block(wv + 4, acc1);
+}
+__global__ __launch_bounds__(256, 2) void bg_dw_kernel(BgDwArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int layer = blockIdx.x >> 2, nb = blockIdx.x & 3;
+  switch (layer) {
+    case 0: dw_layer<L_IN>(a, nb, smem); break;
+    case 1: dw_layer<L_M1>(a, nb, smem); break;
+    case 2: dw_layer<L_CAT>(a, nb, smem); break;
+    case 3: dw_layer<L_M2>(a, nb, smem); break;
+    default: dw_layer<L_CL>(a, nb, smem); break;
+  }
+}
+constexpr int BG_DW_LDS = 2 * DW_BUF;
+
+// ------------------------------------------------------------------------------------------------------------------------
+// tail: fixed-order sum of the partials (big layers) and records (small ones), 1 / grad_scale, AdamW in place, step state
+// ------------------------------------------------------------------------------------------------------------------------
+struct BgTailArgs {
+  float* theta; float* grad; float* m; float* v; const float* partials; int chunks; const float* records; int nrec;
+  float inv_gscale, lr, b1, b2, eps, wd; int64_t* d_state; int64_t add_rows;
+};
+__device__ __forceinline__ int rec_slot(int i) {   // record entry of small parameter i, -1 = a big-layer parameter
+  if (i >= O_OA_W && i < O_OA_W + BH) return R_OAW + (i - O_OA_W);
+  if (i == O_OA_B) return R_OAB;
+  if (i >= O_OC_W && i < O_OC_W + 3 * BH) return R_OCW + (i - O_OC_W);
+  if (i >= O_OC_B && i < O_OC_B + 3) return R_OCB + (i - O_OC_B);
+  if (i >= O_PE_B) return R_PEB + (i - O_PE_B);
+  return -1;
+}
+// blocks [0, NBIG): one parameter per thread, its partials summed over the chunks; blocks [NBIG, NBIG + BG_REC / 64): 64 record
+// entries each, the workgroups' records split over the four waves (eight loads in flight each), combined in wave order
+__device__ __forceinline__ int rec_param(int e) {   // parameter of record entry e, -1 = padding
+  if (e < R_OCW + 3 * BH) return O_OC_W + (e - R_OCW);
+  if (e >= R_OCB && e < R_OCB + 3) return O_OC_B + (e - R_OCB);
+  if (e >= R_OAW && e < R_OAW + BH) return O_OA_W + (e - R_OAW);
+  if (e == R_OAB) return O_OA_B;
+  if (e >= R_PEB && e < R_PEB + 63) return O_PE_B + (e - R_PEB);
+  return -1;
+}
+constexpr int TAIL_NBIG = (BG_NPARAM + 255) / 256;
+__global__ __launch_bounds__(256) void bg_tail_kernel(BgTailArgs a) {
+  __shared__ float part[4][64];
+  const int64_t t = a.d_state[2] + (a.add_rows >= 0 ? 1 : 0);   // add_rows < 0: the state was advanced earlier in the step
+  cnr::AdamArgs ad{a.theta, a.grad, a.m, a.v, BG_NPARAM, a.lr, a.b1, a.b2, a.eps, a.wd, 1.0f};
+  float step_size, inv_bc2;
+  cnr::adam_coefficients(ad, t, step_size, inv_bc2);
+  int i = -1;
+  float g = 0.0f;
+  if ((int)blockIdx.x < TAIL_NBIG) {
+    i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= BG_NPARAM || rec_slot(i) >= 0) i = -1;
+    if (i >= 0) {
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      int c = 0;
+      for (; c + 4 <= a.chunks; c += 4) {
+        s0 += a.partials[(size_t)(c + 0) * BG_NPARAM + i]; s1 += a.partials[(size_t)(c + 1) * BG_NPARAM + i];
+        s2 += a.partials[(size_t)(c + 2) * BG_NPARAM + i]; s3 += a.partials[(size_t)(c + 3) * BG_NPARAM + i];
+      }
+      for (; c < a.chunks; ++c) s0 += a.partials[(size_t)c * BG_NPARAM + i];
+      g = (s0 + s1) + (s2 + s3);
+    }
+  } else {
+    const int e = ((int)blockIdx.x - TAIL_NBIG) * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    const int per = (a.nrec + 3) / 4, r0 = q * per, r1 = r0 + per < a.nrec ? r0 + per : a.nrec;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = r0;
+    for (; r + 4 <= r1; r += 4) {
+      s0 += a.records[(size_t)(r + 0) * BG_REC + e]; s1 += a.records[(size_t)(r + 1) * BG_REC + e];
+      s2 += a.records[(size_t)(r + 2) * BG_REC + e]; s3 += a.records[(size_t)(r + 3) * BG_REC + e];
+    }
+    for (; r < r1; ++r) s0 += a.records[(size_t)r * BG_REC + e];
+    part[q][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (q == 0) {
+      i = rec_param(e);
+      g = (part[0][e & 63] + part[1][e & 63]) + (part[2][e & 63] + part[3][e & 63]);
+    }
+  }
+  if (i >= 0) {
+    g *= a.inv_gscale;
+    a.grad[i] = g;
+    float p = a.theta[i] * (1.0f - a.lr * a.wd);
+    const float mi = a.m[i] + (g - a.m[i]) * (1.0f - a.b1);
+    const float vi = a.v[i] * a.b2 + (1.0f - a.b2) * g * g;
+    p -= step_size * (mi / (sqrtf(vi) * inv_bc2 + a.eps));
+    a.theta[i] = p; a.m[i] = mi; a.v[i] = vi;
+  }
+}
+__global__ void bg_advance_kernel(int64_t* d_state, int64_t add_rows) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) { d_state[0] += add_rows; d_state[1] += 1; d_state[2] += 1; }
+}
+}  // namespace
+
+// ========================================================================================================================
+// C-ABI
+// ========================================================================================================================
+extern "C" int64_t cnr_bg_pack_bytes(void) { return (int64_t)BG_PACK_BYTES; }
+extern "C" int cnr_bg_param_count(void) { return BG_NPARAM; }
+extern "C" int cnr_bg_blocks(int M) { return M > 0 ? (M + TS - 1) / TS : 0; }
+extern "C" int cnr_bg_dw_chunks(int M, int chunk) { return (M > 0 && chunk > 0) ? (M + chunk - 1) / chunk : 0; }
+extern "C" int cnr_bg_record_floats(void) { return BG_REC; }
+
+extern "C" int cnr_bg_pack(const float* theta, void* packed, void* stream) {
+  if (!theta || !packed) return CNR_E_ARG;
+  if (((uintptr_t)packed & 15) != 0) return CNR_E_ALIGN;
+  hipLaunchKernelGGL(bg_pack_kernel, dim3(NF_FWD + NF_LO + NF_BWD), dim3(256), 0, (hipStream_t)stream, theta, (unsigned char*)packed);
+  CNR_LAUNCH_CHECK();
+  return CNR_OK;
+}
+
+extern "C" int cnr_bg_forward(const float* pts, const float* theta, const void* packed, float scale, int M, float* sigma,
+                              float* rgb, void* act, void* eimg, void* stream) {
+  if (!pts || !theta || !packed || !sigma || !rgb || !act || !eimg || M <= 0 || !(scale > 0.f)) return CNR_E_ARG;
+  if (((uintptr_t)packed & 15) != 0 || ((uintptr_t)act & 15) != 0 || ((uintptr_t)eimg & 15) != 0) return CNR_E_ALIGN;
+  static cnr::DeviceOnce once;
+  const int er = cnr::set_max_dynamic_lds(once, (const void*)bg_fwd_kernel, BG_FWD_LDS);
+  if (er) return er;
+  BgFwdArgs a{pts, theta, (const unsigned char*)packed, 1.0f / scale, M, sigma, rgb, (_Float16*)act, (_Float16*)eimg};
+  hipLaunchKernelGGL(bg_fwd_kernel, dim3((unsigned)cnr_bg_blocks(M)), dim3(256), BG_FWD_LDS, (hipStream_t)stream, a);
+  CNR_LAUNCH_CHECK();
+  return CNR_OK;
+}
+
+extern "C" int cnr_bg_backward(const float* pts, const float* theta, const void* packed, float scale, int M,
+                               const float* d_sigma, const float* d_rgb, const float* rgb, const void* act, void* dpre,
+                               float* records, int64_t* d_state, int64_t add_rows, void* stream) {
+  if (!pts || !theta || !packed || !d_sigma || !d_rgb || !rgb || !act || !dpre || !records || M <= 0 || !(scale > 0.f))
+    return CNR_E_ARG;
+  if (((uintptr_t)packed & 15) != 0 || ((uintptr_t)act & 15) != 0 || ((uintptr_t)dpre & 15) != 0) return CNR_E_ALIGN;
+  static cnr::DeviceOnce once;
+  const int er = cnr::set_max_dynamic_lds(once, (const void*)bg_bwd_kernel, BG_BWD_LDS);
+  if (er) return er;
+  BgBwdArgs a{pts, theta, (const unsigned char*)packed, 1.0f / scale, M, d_sigma, d_rgb, rgb, (const _Float16*)act,
+              (_Float16*)dpre, records, d_state, add_rows};
+  hipLaunchKernelGGL(bg_bwd_kernel, dim3((unsigned)cnr_bg_blocks(M)), dim3(256), BG_BWD_LDS, (hipStream_t)stream, a);
+  CNR_LAUNCH_CHECK();
+  return CNR_OK;
+}
+
+extern "C" int cnr_bg_dw(const void* act, const void* dpre, const void* eimg, int M, int chunk, float* partials, void* stream) {
+  if (!act || !dpre || !eimg || !partials || M <= 0 || chunk <= 0 || (chunk & 63) != 0) return CNR_E_ARG;
+  if (((uintptr_t)act & 15) != 0 || ((uintptr_t)dpre & 15) != 0 || ((uintptr_t)eimg & 15) != 0) return CNR_E_ALIGN;
+  static cnr::DeviceOnce once;
+  const int er = cnr::set_max_dynamic_lds(once, (const void*)bg_dw_kernel, BG_DW_LDS);
+  if (er) return er;
+  BgDwArgs a{(const _Float16*)act, (const _Float16*)dpre, (const _Float16*)eimg, M, chunk, partials};
+  hipLaunchKernelGGL(bg_dw_kernel, dim3(20, (unsigned)cnr_bg_dw_chunks(M, chunk)), dim3(256), BG_DW_LDS, (hipStream_t)stream, a);
+  CNR_LAUNCH_CHECK();
+  return CNR_OK;
+}
+
+extern "C" int cnr_bg_tail(float* theta, float* grad, float* exp_avg, float* exp_avg_sq, const float* partials, int chunks,
+                           const float* records, int nrec, float grad_scale, float lr, float beta1, float beta2, float eps,
+                           float weight_decay, int64_t* d_state, int64_t add_rows, void* stream) {
+  if (!theta || !grad || !exp_avg || !exp_avg_sq || !partials || !records || chunks <= 0 || nrec <= 0 || !d_state ||
+      !(grad_scale > 0.f) || !(lr > 0.f) || BG_REC % 64 != 0)
+    return CNR_E_ARG;
+  BgTailArgs a{theta, grad, exp_avg, exp_avg_sq, partials, chunks, records, nrec, 1.0f / grad_scale, lr, beta1, beta2, eps,
+               weight_decay, d_state, add_rows};
+  // (the step count is read by every block: the state moves in a second, one-thread launch behind them -- or, add_rows < 0,
+  //  it was moved by cnr_bg_backward already, the launch between the sampler, which reads the cursor, and this one)
+  hipLaunchKernelGGL(bg_tail_kernel, dim3(TAIL_NBIG + BG_REC / 64), dim3(256), 0, (hipStream_t)stream, a);
+  if (add_rows >= 0) hipLaunchKernelGGL(bg_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_state, add_rows);
+  CNR_LAUNCH_CHECK();
+  return CNR_OK;
+}

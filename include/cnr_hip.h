@@ -567,6 +567,41 @@ typedef struct cnr_field_train_args {
 } cnr_field_train_args;
 int cnr_field_train(const cnr_field_train_args* args, void* stream);
 
+/* ---- the background field's train step on f16 MFMA, fused (csrc/bg_fused.hip) ----------------------------
+ * OccupancyMap(hidden 128), src/model.py:86-155, called every iteration at train.py:113-121,172-180 on R x S world-frame
+ * samples (1200 x 14).  theta: the flat fp32 parameter buffer in the modules' registration order,
+ *   in_layer.0 W (128,87) b | mid1.0.0 W (128,128) b | cat_layer.0 W (128,215) b | mid2.0.0 W (128,128) b | out_alpha W (1,128) b |
+ *   color_linear.0 W (128,170) b | out_color W (3,128) b | B_layer.weight (21,3)          = cnr_bg_param_count() = 94 403 floats.
+ * One step = cnr_bg_pack -> cnr_bg_forward -> cnr_render_loss (+ _finish) -> cnr_bg_backward -> cnr_bg_dw -> cnr_bg_tail, M = R S:
+ *   pack:     theta -> (cnr_bg_pack_bytes()) f16 MFMA fragments: forward, geometry-branch residual, transposed.
+ *   forward:  pts (M,3) -> sigma (M,) = 10 raw, rgb (M,3); act (5,M,128) f16 = post-ReLU outputs of in_layer, mid1, cat_layer,
+ *             mid2, color_linear; eimg (M,144) f16 = PE features (E1 in columns 0..95, E2 in 96..143).  Geometry branch
+ *             (in_layer .. mid2 -> out_alpha) as three f16 products per fragment, fp32 occupancy head; colour branch plain f16.
+ *   backward: d_sigma (M,), d_rgb (M,3) (already multiplied by the loss scale) -> dpre (5,M,128) f16 pre-activation gradients,
+ *             records (cnr_bg_blocks(M), cnr_bg_record_floats()): per-workgroup gradients of out_color, out_alpha, B_layer.
+ *   dw:       weight / bias gradients of the five 128-wide layers over sample chunks of `chunk` (a multiple of 64) samples
+ *             -> partials (cnr_bg_dw_chunks(M, chunk), cnr_bg_param_count()).
+ *   tail:     fixed-order sums of partials and records, x 1 / grad_scale -> grad; AdamW in place (step = d_state[2] + 1);
+ *             d_state += (add_rows, 1, 1).  With d_state given to cnr_bg_backward (it then advances the state: the sampler, which
+ *             reads the cursor, ran before it, the optimiser, which reads the step count, runs after it) pass add_rows = -1
+ *             here: the step count is then d_state[2] as it stands and no state launch follows.
+ * No float atomics: two runs give the same bits. */
+int64_t cnr_bg_pack_bytes(void);
+int cnr_bg_param_count(void);
+int cnr_bg_blocks(int M);
+int cnr_bg_dw_chunks(int M, int chunk);
+int cnr_bg_record_floats(void);
+int cnr_bg_pack(const float* theta, void* packed, void* stream);
+int cnr_bg_forward(const float* pts, const float* theta, const void* packed, float scale, int M, float* sigma, float* rgb,
+                   void* act, void* eimg, void* stream);
+int cnr_bg_backward(const float* pts, const float* theta, const void* packed, float scale, int M, const float* d_sigma,
+                    const float* d_rgb, const float* rgb, const void* act, void* dpre, float* records, int64_t* d_state,
+                    int64_t add_rows, void* stream);
+int cnr_bg_dw(const void* act, const void* dpre, const void* eimg, int M, int chunk, float* partials, void* stream);
+int cnr_bg_tail(float* theta, float* grad, float* exp_avg, float* exp_avg_sq, const float* partials, int chunks,
+                const float* records, int nrec, float grad_scale, float lr, float beta1, float beta2, float eps,
+                float weight_decay, int64_t* d_state, int64_t add_rows, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,142 @@
+"""GPU: the fused f16 background step (csrc/bg_fused.hip: cnr_bg_pack / _forward / _backward / _dw / _tail around
+cnr_render_loss) against the vectors the REFERENCE produced for the background branch (tests/golden/bg_*_h128.npz: one
+train.py:113-121,172-184 step of OccupancyMap(128) + UniDirsEmbed -- samples, outputs, losses, every gradient, the AdamW
+update), and BackgroundStep(precision="fused") against the exact-fp32 tier over several steps.
+
+Bars: the occupancy logit comes out of the precise geometry branch (three f16 products per fragment + fp32 head): 2e-5 like
+the fp32 tier; colours carry f16 operands: 1e-3 (north_star's bar); gradients are an f16 chain with fp32 accumulation: each
+tensor within a few per cent of the reference's and cosine > 0.999 overall, like the category kernel's."""
+import pytest
+import torch
+
+from conftest import Golden, bg_golden_names, rel_l2
+
+pytestmark = pytest.mark.gpu
+NAMES = ["in_layer.0.weight", "in_layer.0.bias", "mid1.0.0.weight", "mid1.0.0.bias", "cat_layer.0.weight", "cat_layer.0.bias",
+         "mid2.0.0.weight", "mid2.0.0.bias", "out_alpha.weight", "out_alpha.bias", "color_linear.0.weight",
+         "color_linear.0.bias", "out_color.weight", "out_color.bias"]
+
+
+def _flat(g, prefix):
+    return torch.cat([g.t(prefix + n).reshape(-1) for n in NAMES] + [g.t({"mlp.": "B", "grad.": "grad_B", "new.": "new_B"}[prefix]).reshape(-1)])
+
+
+@pytest.mark.parametrize("name", [n for n in bg_golden_names() if n.endswith("h128")])
+def test_fused_background_step_against_the_reference_vectors(dev, name):
+    import cnr_amd as cnr
+    _C = cnr._C
+    lib = _C.load()
+    g = Golden(name, dev)
+    R, S = g.R, g.S
+    M = R * S
+    theta = _flat(g, "mlp.").contiguous()
+    n = theta.numel()
+    assert n == int(lib.cnr_bg_param_count())
+    f = lambda *sh, dt=torch.float32: torch.zeros(*sh, device=dev, dtype=dt)
+    packed = f(int(lib.cnr_bg_pack_bytes()), dt=torch.uint8)
+    sigma, rgbs = f(1, R, S), f(1, R, S, 3)
+    act, eimg, dpre = f(5, M, 128, dt=torch.float16), f(M, 144, dt=torch.float16), f(5, M, 128, dt=torch.float16)
+    nblk, chunk = int(lib.cnr_bg_blocks(M)), 256
+    nch = int(lib.cnr_bg_dw_chunks(M, chunk))
+    records, partials = f(nblk, int(lib.cnr_bg_record_floats())), f(nch, n)
+    pts = g.t("pts").contiguous()
+    _C.call("cnr_bg_pack", theta, packed)
+    _C.call("cnr_bg_forward", pts, theta, packed, g.scale, M, sigma, rgbs, act, eimg)
+    torch.cuda.synchronize()
+    e_sig, e_rgb = rel_l2(sigma, g.t("sigmas").squeeze(-1)), rel_l2(rgbs, g.t("rgbs"))
+    print(f"fused background forward {name}: sigma {e_sig:.2e} rgb {e_rgb:.2e}")
+    assert e_sig < 2e-5 and e_rgb < 1e-3
+    # activations and PE image are what the backward consumes: a1 against torch
+    e1 = torch.cat([pts.view(M, 3) / g.scale, torch.sin(torch.pi * (2.0 ** torch.arange(6, device=dev))[:, None] *
+                                                          ((pts.view(M, 3) / g.scale) @ g.t("B")[0].T)[:, None, :]).reshape(M, -1)], -1)
+    assert rel_l2(eimg[:, :87].float(), e1[:, :87]) < 1e-3 and rel_l2(eimg[:, 96:138].float(), e1[:, 87:]) < 1e-3
+    assert float(eimg[:, 87:96].abs().max()) == 0 and float(eimg[:, 138:].abs().max()) == 0
+    a1 = torch.relu(e1[:, :87] @ g.t("mlp.in_layer.0.weight").T + g.t("mlp.in_layer.0.bias"))
+    assert rel_l2(act[0].float(), a1) < 1e-3
+    # ---- composite + losses + their gradient, then the backward ---------------------------------------------------------
+    gscale = 256.0
+    ws = torch.zeros(_C.render_loss_workspace_bytes(1, R), device=dev, dtype=torch.uint8)
+    dsig, drgb = f(1, R, S), f(1, R, S, 3)
+    depth, var, rgb, opa = f(1, R), f(1, R), f(1, R, 3), f(1, R)
+    losses, flags = f(3, 1), f(1, dt=torch.int32)
+    _C.call("cnr_render_loss", sigma, rgbs, g.t("z").contiguous(), g.t("gt_depth").contiguous(), g.t("gt_rgb").contiguous(),
+            g.t("labels").contiguous(), g.t("depth_mask").to(torch.uint8).contiguous(), 5.0, 10.0, gscale, dsig, drgb, depth, var,
+            rgb, opa, 1, R, S, ws, ws.numel(), None, None)
+    _C.call("cnr_render_loss_finish", ws, losses, flags, 1, R, 0)
+    for k, key in enumerate(("loss_depth", "loss_color", "loss_opacity")):
+        assert rel_l2(losses[k], g.t(key)) < 1e-3, key
+    _C.call("cnr_bg_backward", pts, theta, packed, g.scale, M, dsig, drgb, rgbs, act, dpre, records, None, 0)
+    _C.call("cnr_bg_dw", act, dpre, eimg, M, chunk, partials)
+    # the weight-gradient kernel on its own: dW = dPre^T X, db = column sums, from the very f16 arrays it reads
+    torch.cuda.synchronize()
+    psum = partials.sum(0)
+    xs = dict(in_layer=eimg[:, :87], mid1=act[0], cat_layer=torch.cat([act[1], eimg[:, :87]], 1), mid2=act[2],
+              color_linear=torch.cat([act[3], eimg[:, 96:138]], 1))
+    off = 0
+    for li, (lname, x) in enumerate(xs.items()):
+        k = x.shape[1]
+        dwr = dpre[li].float().T @ x.float()
+        dbr = dpre[li].float().sum(0)
+        if lname == "color_linear":
+            off = 72065
+        assert rel_l2(psum[off:off + 128 * k].view(128, k), dwr) < 1e-5, lname
+        assert rel_l2(psum[off + 128 * k:off + 128 * k + 128], dbr) < 1e-5, lname
+        off += 128 * k + 128
+    th2, grad, m, v = theta.clone(), f(n), f(n), f(n)
+    state = torch.zeros(3, device=dev, dtype=torch.int64)
+    _C.call("cnr_bg_tail", th2, grad, m, v, partials, nch, records, nblk, gscale, 1e-3, 0.9, 0.999, 1e-8, 0.013, state, R)
+    torch.cuda.synchronize()
+    assert state.tolist() == [R, 1, 1]
+    ref = _flat(g, "grad.")
+    off, rep, worst = 0, [], 0.0
+    for nme in NAMES + ["B"]:
+        k = g.t("mlp." + nme).numel() if nme != "B" else 63
+        e = rel_l2(grad[off:off + k], ref[off:off + k])
+        rep.append(f"{nme}={e:.3f}")
+        worst = max(worst, e)
+        off += k
+    cos = float((grad.double() @ ref.double()) / (grad.double().norm() * ref.double().norm()))
+    print(f"fused background gradient {name}: cos {cos:.6f} worst {worst:.3f}  " + " ".join(rep))
+    assert cos > 0.999 and worst < 0.06
+    # AdamW (first step: -lr sign(g) where g is not noise)
+    new_ref = _flat(g, "new.")
+    clear = ref.abs() > 0.02 * ref.abs().max()
+    assert rel_l2((th2 - theta)[clear], (new_ref - theta)[clear]) < 0.02
+    # the step is a fixed-order computation: a second run gives the same bits
+    th3, grad3 = theta.clone(), f(n)
+    st3 = torch.zeros(3, device=dev, dtype=torch.int64)
+    _C.call("cnr_bg_backward", pts, theta, packed, g.scale, M, dsig, drgb, rgbs, act, dpre, records, st3, R)   # the state moves here ...
+    _C.call("cnr_bg_dw", act, dpre, eimg, M, chunk, partials)
+    _C.call("cnr_bg_tail", th3, grad3, f(n), f(n), partials, nch, records, nblk, gscale, 1e-3, 0.9, 0.999, 1e-8, 0.013,
+            st3, -1)                                                                                          # ... and the tail reads it as it stands
+    assert torch.equal(grad3, grad) and torch.equal(th3, th2) and st3.tolist() == [R, 1, 1]
+
+
+def test_fused_background_trainer_tracks_the_fp32_tier(dev):
+    """BackgroundStep(precision="fused") against precision="fp32" from the same initial parameters on the same sampled batches
+    (device cursor + in-kernel Philox: identical), 12 steps across a reshuffle, graph replay included."""
+    import cnr_amd as cnr
+
+    def make(prec):
+        cfg = cnr.cfg.synthetic_config(device=str(dev), latent_dim=32, n_bins_cam2surface=4, n_bins=9)
+        cfg.hidden_feature_size_bg, cfg.n_bins_cam2surface_bg = 128, 5
+        torch.manual_seed(3)
+        pool = cnr.scene_cateogries.synthetic_pool(6 * 300, 1, torch.Generator().manual_seed(12), "cpu")
+        return cnr.background.BackgroundStep(cfg, pool, 300, dev, seed=5, precision=prec)
+    a, b = make("fused"), make("fp32")
+    assert torch.equal(a.flat, b.flat)
+    for it in range(12):
+        a.step()
+        b.step()
+        torch.cuda.synchronize()
+        assert torch.equal(a.bufs["z"], b.bufs["z"]), it
+        assert rel_l2(a.losses, b.losses) < (2e-3 if it == 0 else 5e-2), (it, a.losses, b.losses)
+    assert a.graph is not None and int(a.d_state[2]) == 12 and int(a.d_state[0]) == a.cursor
+    assert torch.isfinite(a.flat).all()
+    # both moved away from the start by the same amount and in the same direction
+    start = make("fp32").flat
+    da, db = a.flat - start, b.flat - start
+    cos = float((da.double() @ db.double()) / (da.double().norm() * db.double().norm()))
+    print("fused vs fp32 background trainer after 12 steps: cosine of the parameter displacement", round(cos, 4),
+          "rel", round(rel_l2(a.flat, b.flat), 5))
+    assert cos > 0.9 and rel_l2(a.flat, b.flat) < 5e-3
