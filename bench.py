@@ -487,8 +487,8 @@ def main():
                                                         "steps": 2000, "ms_per_step": d2 / 2000 * 1e3, "rays_per_s": R2 * 2000 / d2}}
         except Exception as e:
             out["extra_legs"] = {"real_config_480x10": f"failed: {e}"}
-        # the WHOLE iteration of train.py:113-184: background (1200 rays x 14 samples, OccupancyMap(128), exact-fp32 kernels
-        # under autograd) + the benchmarked category step, captured as one hipGraph per state parity
+        # the WHOLE iteration of train.py:113-184: background (1200 rays x 14 samples, OccupancyMap(128), the fused f16 step) + the
+        # benchmarked category step, captured as one hipGraph per state parity
         try:
             cfg3 = cnr_amd.cfg.synthetic_config(device=str(dev), latent_dim=L, n_bins_cam2surface=n1, n_bins=n2)
             cfg3.n_bins_cam2surface_bg = 5
@@ -496,7 +496,8 @@ def main():
             pools3 = [cnr_amd.scene_cateogries.synthetic_pool(64 * R, n_obj, g3, "cpu")]
             tr3 = cnr_amd.fused.FusedCategoryTrainer(cfg3, 1, n_obj, pools3, R, dev, seed=2, generator=g3)
             cfg_bg = cnr_amd.cfg.synthetic_config(device=str(dev), latent_dim=L, n_bins_cam2surface=n1, n_bins=9)
-            bg = cnr_amd.background.BackgroundStep(cfg_bg, cnr_amd.scene_cateogries.synthetic_pool(64 * 1200, 1, g3, "cpu"), 1200, dev)
+            bg = cnr_amd.background.BackgroundStep(cfg_bg, cnr_amd.scene_cateogries.synthetic_pool(64 * 1200, 1, g3, "cpu"), 1200, dev,
+                                                   precision="fused")
             full = cnr_amd.background.FullStepTrainer(tr3, bg)
             for _ in range(10):
                 full.step()
@@ -507,8 +508,8 @@ def main():
             torch.cuda.synchronize()
             d3 = time.perf_counter() - t0
             out["extra_legs"]["full_iteration_bg_plus_category"] = {
-                "workload": f"background 1200 rays x 14 samples (OccupancyMap(128), fp32) + 1 category x {R} rays x {S} samples, one "
-                            "hipGraph per state parity", "steps": 500, "ms_per_step": d3 / 500 * 1e3,
+                "workload": f"background 1200 rays x 14 samples (OccupancyMap(128), fused f16 step: csrc/bg_fused.hip) + 1 category x {R} "
+                            f"rays x {S} samples, one hipGraph per state parity", "steps": 500, "ms_per_step": d3 / 500 * 1e3,
                 "category_rays_per_s": R * 500 / d3, "all_rays_per_s": (R + 1200) * 500 / d3}
         except Exception as e:
             out["extra_legs"]["full_iteration_bg_plus_category"] = f"failed: {e}"

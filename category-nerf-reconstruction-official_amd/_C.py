@@ -23,7 +23,7 @@ SIGNATURES = {
     "cnr_sample_maxdepth": [_vp, _vp, _vp, _i64, _vp, _i, _i, _vp],
     "cnr_step_advance": [_vp, _i64, _vp],
     "cnr_sample_rays": [_vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64, _vp, _i64, _vp, _i, _i, _i, _i, _i, _f, _f, _f,
-                        _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp],
+                        _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp],
     "cnr_latent_fwd": [_vp, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _vp, _vp, _vp],
     "cnr_latent_bwd": [_vp, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp],
     "cnr_pe_fwd": [_vp, _vp, _vp, _i, _i64, _f, _vp],
@@ -81,7 +81,7 @@ SIGNATURES = {
     "cnr_bg_forward": [_vp, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp],
     "cnr_bg_backward": [_vp, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "cnr_bg_dw": [_vp, _vp, _vp, _i, _i, _vp, _vp],
-    "cnr_bg_tail": [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _f, _f, _f, _f, _f, _f, _vp, _i64, _vp],
+    "cnr_bg_tail": [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _f, _f, _f, _f, _f, _f, _vp, _i64, _vp, _vp, _i, _vp, _vp, _vp],
 }
 # The three launches of the fused trainer's step take ONE versioned struct (include/cnr_hip.h: struct_size and abi_version
 # first, then these fields in this order).  call_struct() wants every field by NAME: a missing, misspelt or surplus argument

@@ -67,18 +67,22 @@ class BackgroundStep:
         if precision == "fused":
             self._init_fused(n)
         self.bufs = {}
-        self.loss = torch.zeros((), device=dev)
-        self.losses = torch.zeros(3, device=dev)
+        if precision != "fused":
+            self.loss = torch.zeros((), device=dev)
+            self.losses = torch.zeros(3, device=dev)
         self.cursor = 0
         self.steps_done = 0
         self.graph = None
         self._reshuffle()
 
     def _reshuffle(self):
-        """src/scene_cateogries.py:439-449 as a new permutation; cursor back to 0."""
+        """src/scene_cateogries.py:439-449 as a new permutation; cursor back to 0.  Fused tier: the max depth of every slice of
+        the epoch in one launch (cnr_slice_maxdepth; src/scene_cateogries.py:486 needs it per batch), so that no step computes it."""
         self.perm[0].copy_(torch.randperm(self.pool_rows, device=self.device, generator=self._perm_gen))
         self.d_state[0:1].copy_(self._zero)
         self.cursor = 0
+        if self.precision == "fused":
+            _C.call("cnr_slice_maxdepth", self.pool["depth"], self.perm, self.pool_rows, 1, self.R, self.n_slices, self.slice_max)
 
     def _body(self):
         """sample -> PE -> OccupancyMap -> composite + losses -> backward -> AdamW -> advance (all stream-ordered)."""
@@ -114,9 +118,14 @@ class BackgroundStep:
         assert [tuple(p.shape) for p in self.trainer.pe.parameters()] == [(21, 3)]
         self.S = self.n1 + self.n2
         M = self.M = self.R * self.S
-        self.dw_chunk = 256
+        # samples per weight-gradient workgroup: 384 -> 5 layers x 44 chunks = 220 workgroups, one round on 256 CUs (measured 17.5 us;
+        # 256: 20.2, 512: 21.2)
+        self.dw_chunk = int(__import__('os').environ.get('CNR_BG_DW_CHUNK', '384'))
         self.nblk, self.nchunk = int(lib.cnr_bg_blocks(M)), int(lib.cnr_bg_dw_chunks(M, self.dw_chunk))
         self.gscale = float(2 ** round(math.log2(max(self.R, 2))))      # power-of-two loss scale of the f16 gradient chain
+        self.n_slices = self.pool_rows // self.R
+        self.slice_max = torch.zeros(1, self.n_slices, device=dev)
+        self._packed_for = None          # version of self.flat the fragment images were packed from
         f = lambda *sh, dt=torch.float32: torch.empty(*sh, device=dev, dtype=dt)
         self.fb = dict(packed=f(int(lib.cnr_bg_pack_bytes()), dt=torch.uint8), sigma=f(1, self.R, self.S),
                        rgbs=f(1, self.R, self.S, 3), act=f(5, M, 128, dt=torch.float16), eimg=f(M, 144, dt=torch.float16),
@@ -126,35 +135,66 @@ class BackgroundStep:
                        rl_ws=torch.zeros(_C.render_loss_workspace_bytes(1, self.R), device=dev, dtype=torch.uint8),
                        losses=torch.zeros(3, 1, device=dev), flags=torch.zeros(1, device=dev, dtype=torch.int32))
 
+    @property
+    def losses(self):
+        """(3,) depth / colour / opacity terms of the last step (src/loss.py:18-74)"""
+        return self.fb["losses"][:, 0] if self.precision == "fused" else self._losses
+
+    @losses.setter
+    def losses(self, v):
+        self._losses = v
+
+    @property
+    def loss(self):
+        """the step's scalar loss: depth + 5 colour + 10 opacity (formed on demand in the fused tier: nobody reads it per step)"""
+        if self.precision == "fused":
+            l = self.fb["losses"][:, 0]
+            return l[0] + 5.0 * l[1] + 10.0 * l[2]
+        return self._loss
+
+    @loss.setter
+    def loss(self, v):
+        self._loss = v
+
     def _body_fused(self):
         """sample -> pack -> forward -> composite + losses + their gradient -> backward -> weight gradients -> reduce + AdamW +
         advance: eight launches, nothing under autograd (train.py:113-121,172-184 for the background)."""
         cfg, o = self.cfg, self.fb
         b = ops.sample_rays(self.pool["rgbs"], self.pool["depth"], self.pool["dirs"], self.pool["T"], self.n1, self.n2,
                             cfg.surface_eps, cfg.stop_eps, min_bound=cfg.min_depth, world_frame=True, seed=self.seed,
-                            d_state=self.d_state, rays=self.R, out=self.bufs, perm=self.perm)
+                            d_state=self.d_state, rays=self.R, out=self.bufs, perm=self.perm, max_bound=self.slice_max,
+                            max_bound_slices=self.n_slices)
         scale, M = float(self.trainer.pe._scale), self.M
-        _C.call("cnr_bg_pack", self.flat, o["packed"])
         _C.call("cnr_bg_forward", b["pts"], self.flat, o["packed"], scale, M, o["sigma"], o["rgbs"], o["act"], o["eimg"])
         _C.call("cnr_render_loss", o["sigma"], o["rgbs"], b["z"], b["gt_depth"], b["gt_rgb"], b["labels"], b["depth_mask"],
                 5.0, 10.0, self.gscale, o["dsig"], o["drgb"], o["depth"], o["var"], o["rgb"], o["opa"], 1, self.R, self.S,
                 o["rl_ws"], o["rl_ws"].numel(), None, None)
-        _C.call("cnr_render_loss_finish", o["rl_ws"], o["losses"], o["flags"], 1, self.R, 0)
         _C.call("cnr_bg_backward", b["pts"], self.flat, o["packed"], scale, M, o["dsig"], o["drgb"], o["rgbs"], o["act"],
                 o["dpre"], o["records"], self.d_state, self.R)
         _C.call("cnr_bg_dw", o["act"], o["dpre"], o["eimg"], M, self.dw_chunk, o["partials"])
         _C.call("cnr_bg_tail", self.flat, self.gflat, self.exp_avg, self.exp_avg_sq, o["partials"], self.nchunk, o["records"],
-                self.nblk, self.gscale, cfg.learning_rate, 0.9, 0.999, 1e-8, cfg.weight_decay, self.d_state, -1)
-        self.losses.copy_(o["losses"][:, 0])
-        self.loss.copy_(o["losses"][0, 0] + 5.0 * o["losses"][1, 0] + 10.0 * o["losses"][2, 0])
+                self.nblk, self.gscale, cfg.learning_rate, 0.9, 0.999, 1e-8, cfg.weight_decay, self.d_state, -1, o["packed"],
+                o["rl_ws"], self.R, o["losses"], o["flags"])
+        # (self.losses / self.loss are views of / derived from o["losses"]: see the properties -- no torch kernel in the step)
+
+    def repack(self):
+        """Fused tier: rebuild the f16 fragment images from ``self.flat`` (cnr_bg_pack).  Needed once before the first step and
+        after any outside change of the parameters (load_state_dict, a copy into ``flat``): inside the training loop every
+        weight's fragments are refreshed by the optimiser launch that updates it."""
+        _C.call("cnr_bg_pack", self.flat, self.fb["packed"])
+        self._packed_for = self.flat._version
 
     def pre_step(self):
+        if self.precision == "fused" and (self._packed_for is None or self._packed_for != self.flat._version):
+            self.repack()
         if self.cursor >= self.pool_rows - self.R:
             self._reshuffle()
 
     def post_step(self):
         self.cursor += self.R
         self.steps_done += 1
+        if self.precision == "fused":
+            self._packed_for = self.flat._version     # (the step's own update: kernels do not bump torch's version counter)
 
     def step(self, use_graph=True):
         """One background step; after three eager steps it is captured and replayed."""

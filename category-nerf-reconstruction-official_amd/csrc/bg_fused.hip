@@ -21,6 +21,7 @@
 // atomics anywhere (records and partials summed in a fixed order).
 #include "adamw_common.h"
 #include "fused_common.h"
+#include "render_common.h"
 
 namespace {
 using namespace fz;
@@ -188,31 +189,37 @@ __device__ __forceinline__ void pe_images(const float* __restrict__ pts, const f
   }
 }
 
-// one k-range of a layer: acc[half] += W[s0 .. s0 + NS) x image columns; GEO: three products with the residual weights / image
+// The weight fragments of a k-range (hi, and for the geometry branch the residual) as a register set, loaded from global / L2 right
+// in front of their use.  (Loading them a layer ahead was measured: 256 instead of 82 registers, two instead of three workgroups
+// per CU, forward 25.5 instead of 20.5 us -- the neighbours on the CU hide the round trip better than a prefetch does.)
 template <int NS, bool GEO>
-__device__ __forceinline__ void mma_range(const unsigned char* __restrict__ pk, int f_hi, int f_lo, const unsigned char* Xh,
-                                          const unsigned char* Xl, int stride, int lane, f16v (&acc)[NH]) {
-  const int c = lane & 31, h = lane >> 5;
+struct Frags {
   h8 wh[NS], wl[GEO ? NS : 1];
+  __device__ __forceinline__ void load(const unsigned char* __restrict__ pk, int f0, int lane) {
 #pragma unroll
-  for (int s = 0; s < NS; ++s) wh[s] = gfrag(pk + PK_FWD_OFF, f_hi + s, lane);
-  if constexpr (GEO) {
+    for (int s = 0; s < NS; ++s) wh[s] = gfrag(pk + PK_FWD_OFF, f0 + s, lane);
+    if constexpr (GEO) {
 #pragma unroll
-    for (int s = 0; s < NS; ++s) wl[s] = gfrag(pk + PK_LO_OFF, f_lo + s, lane);
+      for (int s = 0; s < NS; ++s) wl[s] = gfrag(pk + PK_LO_OFF, f0 + s, lane);
+    }
   }
+  // acc[half] += W x image columns; GEO: three products with the residual weights / image
+  __device__ __forceinline__ void mma(const unsigned char* Xh, const unsigned char* Xl, int stride, int lane, f16v (&acc)[NH]) const {
+    const int c = lane & 31, h = lane >> 5;
 #pragma unroll
-  for (int half = 0; half < NH; ++half) {
+    for (int half = 0; half < NH; ++half) {
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      const h8 xh = xfrag(Xh, stride, c + 32 * half, s, h);
-      acc[half] = MFMA(wh[s], xh, acc[half]);
-      if constexpr (GEO) {
-        acc[half] = MFMA(wl[s], xh, acc[half]);
-        acc[half] = MFMA(wh[s], xfrag(Xl, stride, c + 32 * half, s, h), acc[half]);
+      for (int s = 0; s < NS; ++s) {
+        const h8 xh = xfrag(Xh, stride, c + 32 * half, s, h);
+        acc[half] = MFMA(wh[s], xh, acc[half]);
+        if constexpr (GEO) {
+          acc[half] = MFMA(wl[s], xh, acc[half]);
+          acc[half] = MFMA(wh[s], xfrag(Xl, stride, c + 32 * half, s, h), acc[half]);
+        }
       }
     }
   }
-}
+};
 
 // ------------------------------------------------------------------------------------------------------------------------
 // forward
@@ -261,26 +268,36 @@ __global__ __launch_bounds__(256, 2) void bg_fwd_kernel(BgFwdArgs a) {
   const size_t MH = (size_t)M * BH;
   // ---- in_layer: E1 -> a1 -----------------------------------------------------------------------------------------
   init_tile(acc, th + O_IN_B, w, h, BH);
-  mma_range<6, true>(a.packed, fwd_base(L_IN) + 6 * w, fwd_base(L_IN) + 6 * w, E1h, E1l, ST_E1B, lane, acc);
+  Frags<6, true> f_in;
+  f_in.load(a.packed, fwd_base(L_IN) + 6 * w, lane);            // in flight under the positional encoding
+  f_in.mma(E1h, E1l, ST_E1B, lane, acc);
   store_tile(Xh0, Xl0, c, w, h, acc, true);
   __syncthreads();
   image_to_global(Xh0, a.act + 0 * MH, m0, M);
   // ---- mid1: a1 -> a2 -------------------------------------------------------------------------------------------------
   init_tile(acc, th + O_M1_B, w, h, BH);
-  mma_range<8, true>(a.packed, fwd_base(L_M1) + 8 * w, fwd_base(L_M1) + 8 * w, Xh0, Xl0, ST_X, lane, acc);
+  Frags<8, true> f_m1;
+  f_m1.load(a.packed, fwd_base(L_M1) + 8 * w, lane);
+  f_m1.mma(Xh0, Xl0, ST_X, lane, acc);
   store_tile(Xh1, Xl1, c, w, h, acc, true);
   __syncthreads();
   image_to_global(Xh1, a.act + 1 * MH, m0, M);
   // ---- cat_layer: [a2 | e1] -> a3 (image 0 = a1 was last read before the barrier above) ------------------------------
   init_tile(acc, th + O_CAT_B, w, h, BH);
-  mma_range<8, true>(a.packed, fwd_base(L_CAT) + 14 * w, fwd_base(L_CAT) + 14 * w, Xh1, Xl1, ST_X, lane, acc);
-  mma_range<6, true>(a.packed, fwd_base(L_CAT) + 14 * w + 8, fwd_base(L_CAT) + 14 * w + 8, E1h, E1l, ST_E1B, lane, acc);
+  Frags<8, true> f_ca;
+  Frags<6, true> f_ce;
+  f_ca.load(a.packed, fwd_base(L_CAT) + 14 * w, lane);
+  f_ce.load(a.packed, fwd_base(L_CAT) + 14 * w + 8, lane);
+  f_ca.mma(Xh1, Xl1, ST_X, lane, acc);
+  f_ce.mma(E1h, E1l, ST_E1B, lane, acc);
   store_tile(Xh0, Xl0, c, w, h, acc, true);
   __syncthreads();
   image_to_global(Xh0, a.act + 2 * MH, m0, M);
   // ---- mid2: a3 -> a4, and the x10 occupancy head as an fp32 dot product of the fp32 activations -----------------------
   init_tile(acc, th + O_M2_B, w, h, BH);
-  mma_range<8, true>(a.packed, fwd_base(L_M2) + 8 * w, fwd_base(L_M2) + 8 * w, Xh0, Xl0, ST_X, lane, acc);
+  Frags<8, true> f_m2;
+  f_m2.load(a.packed, fwd_base(L_M2) + 8 * w, lane);
+  f_m2.mma(Xh0, Xl0, ST_X, lane, acc);
   {
     float wa[16];
 #pragma unroll
@@ -303,15 +320,21 @@ __global__ __launch_bounds__(256, 2) void bg_fwd_kernel(BgFwdArgs a) {
   }
   // ---- color_linear: [a4 | e2] -> a5 (colour branch: plain f16) --------------------------------------------------------
   init_tile(acc, th + O_CL_B, w, h, BH);
-  mma_range<8, false>(a.packed, fwd_base(L_CL) + 11 * w, 0, Xh1, nullptr, ST_X, lane, acc);
-  mma_range<3, false>(a.packed, fwd_base(L_CL) + 11 * w + 8, 0, E2h, nullptr, ST_E2B, lane, acc);
+  Frags<8, false> f_cl;
+  Frags<3, false> f_c2;
+  f_cl.load(a.packed, fwd_base(L_CL) + 11 * w, lane);
+  f_c2.load(a.packed, fwd_base(L_CL) + 11 * w + 8, lane);
+  f_cl.mma(Xh1, nullptr, ST_X, lane, acc);
+  f_c2.mma(E2h, nullptr, ST_E2B, lane, acc);
   store_tile(Xh0, nullptr, c, w, h, acc, true);   // image 0 = a3: last read by mid2
   __syncthreads();
   image_to_global(Xh0, a.act + 4 * MH, m0, M);
   // ---- out_color (3 outputs): wave 0, rows 0..2 = registers 0..2 of lane half 0 ------------------------------------------
   if (w == 0) {
     init_tile(acc, th + O_OC_B, 0, h, 3);
-    mma_range<8, false>(a.packed, fwd_base(L_OC), 0, Xh0, nullptr, ST_X, lane, acc);
+    Frags<8, false> f_oc;
+    f_oc.load(a.packed, fwd_base(L_OC), lane);
+    f_oc.mma(Xh0, nullptr, ST_X, lane, acc);
     if (h == 0) {
 #pragma unroll
       for (int half = 0; half < NH; ++half) {
@@ -341,17 +364,21 @@ struct BgBwdArgs {
   int64_t* d_state; int64_t add_rows;  // d_state != NULL: block 0 advances the step state (see cnr_bg_backward)
 };
 
-// acc[half] = sum over the 8 k-steps (128 output features) of W^T block `fb` times the dPre image
-__device__ __forceinline__ void bwd_block(const unsigned char* __restrict__ pk, int fb, const unsigned char* D, int lane, f16v (&acc)[NH]) {
-  const int c = lane & 31, h = lane >> 5;
+// the 8 k-steps (128 output features) of W^T block `fb`; acc[half] += W^T x dPre image
+struct BFrags {
   h8 wt[8];
+  __device__ __forceinline__ void load(const unsigned char* __restrict__ pk, int fb, int lane) {
 #pragma unroll
-  for (int s = 0; s < 8; ++s) wt[s] = gfrag(pk + PK_BWD_OFF, fb + s, lane);
+    for (int s = 0; s < 8; ++s) wt[s] = gfrag(pk + PK_BWD_OFF, fb + s, lane);
+  }
+  __device__ __forceinline__ void mma(const unsigned char* D, int lane, f16v (&acc)[NH]) const {
+    const int c = lane & 31, h = lane >> 5;
 #pragma unroll
-  for (int half = 0; half < NH; ++half)
+    for (int half = 0; half < NH; ++half)
 #pragma unroll
-    for (int s = 0; s < 8; ++s) acc[half] = MFMA(wt[s], xfrag(D, ST_X, c + 32 * half, s, h), acc[half]);
-}
+      for (int s = 0; s < 8; ++s) acc[half] = MFMA(wt[s], xfrag(D, ST_X, c + 32 * half, s, h), acc[half]);
+  }
+};
 // dPre = d act * (act > 0): the activation image gives this lane's 16 features in the accumulator layout
 __device__ __forceinline__ void mask_store(unsigned char* Dimg, const unsigned char* Aimg, int sample, int w, int h, const f16v& a) {
 #pragma unroll
@@ -409,6 +436,7 @@ __global__ __launch_bounds__(256, 2) void bg_bwd_kernel(BgBwdArgs a) {
     tpos[3 * s + 0] = a.pts[(size_t)mc * 3 + 0] * a.inv_scale; tpos[3 * s + 1] = a.pts[(size_t)mc * 3 + 1] * a.inv_scale;
     tpos[3 * s + 2] = a.pts[(size_t)mc * 3 + 2] * a.inv_scale;
   }
+  BFrags bf;
   global_to_image(Aim, a.act + 4 * MH, m0, M);   // a5
   __syncthreads();
   // ---- out_color: weight / bias gradient on the VALU (3 x 128 + 3), d a5 on the matrix core -----------------------------
@@ -444,10 +472,12 @@ __global__ __launch_bounds__(256, 2) void bg_bwd_kernel(BgBwdArgs a) {
   image_to_global(D0, a.dpre + 4 * MH, m0, M);
   // ---- color_linear^T: d a4 (colour part) + d e2 ; + out_alpha ------------------------------------------------------------
   zero_tile(acc);
-  bwd_block(a.packed, bwd_base(L_CL) + 8 * w, D0, lane, acc);
+  bf.load(a.packed, bwd_base(L_CL) + 8 * w, lane);
+  bf.mma(D0, lane, acc);
   if (w < 2) {
     zero_tile(ae);
-    bwd_block(a.packed, bwd_base(L_CL) + 8 * (4 + w), D0, lane, ae);
+    bf.load(a.packed, bwd_base(L_CL) + 8 * (4 + w), lane);
+    bf.mma(D0, lane, ae);
 #pragma unroll
     for (int half = 0; half < NH; ++half)
 #pragma unroll
@@ -481,7 +511,8 @@ __global__ __launch_bounds__(256, 2) void bg_bwd_kernel(BgBwdArgs a) {
   image_to_global(D1, a.dpre + 3 * MH, m0, M);
   // ---- mid2^T -> dPre3 ---------------------------------------------------------------------------------------------------
   zero_tile(acc);
-  bwd_block(a.packed, bwd_base(L_M2) + 8 * w, D1, lane, acc);
+  bf.load(a.packed, bwd_base(L_M2) + 8 * w, lane);
+  bf.mma(D1, lane, acc);
   global_to_image(Aim, a.act + 2 * MH, m0, M);   // a3 (the a4 image was last read before the barrier above)
   __syncthreads();
   mask_tile(D0, Aim, c, w, h, acc);
@@ -489,10 +520,12 @@ __global__ __launch_bounds__(256, 2) void bg_bwd_kernel(BgBwdArgs a) {
   image_to_global(D0, a.dpre + 2 * MH, m0, M);
   // ---- cat_layer^T -> d a2, d e1 -------------------------------------------------------------------------------------------
   zero_tile(acc);
-  bwd_block(a.packed, bwd_base(L_CAT) + 8 * w, D0, lane, acc);
+  bf.load(a.packed, bwd_base(L_CAT) + 8 * w, lane);
+  bf.mma(D0, lane, acc);
   if (w < 3) {
     zero_tile(ae);
-    bwd_block(a.packed, bwd_base(L_CAT) + 8 * (4 + w), D0, lane, ae);
+    bf.load(a.packed, bwd_base(L_CAT) + 8 * (4 + w), lane);
+    bf.mma(D0, lane, ae);
   }
   global_to_image(Aim, a.act + 1 * MH, m0, M);   // a2
   __syncthreads();
@@ -501,7 +534,8 @@ __global__ __launch_bounds__(256, 2) void bg_bwd_kernel(BgBwdArgs a) {
   image_to_global(D1, a.dpre + 1 * MH, m0, M);
   // ---- mid1^T -> dPre1 -----------------------------------------------------------------------------------------------------
   zero_tile(acc);
-  bwd_block(a.packed, bwd_base(L_M1) + 8 * w, D1, lane, acc);
+  bf.load(a.packed, bwd_base(L_M1) + 8 * w, lane);
+  bf.mma(D1, lane, acc);
   global_to_image(Aim, a.act + 0 * MH, m0, M);   // a1
   __syncthreads();
   mask_tile(D0, Aim, c, w, h, acc);
@@ -509,7 +543,8 @@ __global__ __launch_bounds__(256, 2) void bg_bwd_kernel(BgBwdArgs a) {
   image_to_global(D0, a.dpre + 0 * MH, m0, M);
   // ---- in_layer^T -> d e1 (on top of cat_layer's) --------------------------------------------------------------------------
   if (w < 3) {
-    bwd_block(a.packed, bwd_base(L_IN) + 8 * w, D0, lane, ae);
+    bf.load(a.packed, bwd_base(L_IN) + 8 * w, lane);
+    bf.mma(D0, lane, ae);
 #pragma unroll
     for (int half = 0; half < NH; ++half)
 #pragma unroll
@@ -545,11 +580,12 @@ constexpr int BG_BWD_LDS = 3 * XIMG + TS * (BE1P + BE2P) * 4 + TS * ST_OC + TS *
 
 // ------------------------------------------------------------------------------------------------------------------------
 // weight gradients of the five 128-wide layers: dW[n][k] = sum_m dPre[m][n] X[m][k], db[n] = sum_m dPre[m][n]
-// grid (20, chunks): block = (layer, 32-output block n) x sample chunk.  The workgroup stages 64-sample tiles of dPre[:, n block]
-// and of the layer's input rows in LDS (double-buffered: the next tile's global loads are in flight under the products of the
-// current one); a [sample][feature] tile gives both MFMA operands through transposing reads (ds_read_b64_tr_b16).  The four
-// waves split the layer's 32-wide INPUT blocks (+ one "ones" block whose column 0 is the bias gradient), so every wave keeps
-// its own accumulators for the whole chunk and writes them out itself -- no reduction inside the workgroup.
+// grid (5, chunks): block = layer x sample chunk.  The workgroup stages 64-sample tiles of dPre (all 128 outputs) and of the
+// layer's input rows in LDS (the next tile's global loads are in flight under the products of the current one); a
+// [sample][feature] tile gives both MFMA operands through transposing reads (ds_read_b64_tr_b16).  Wave w owns output block
+// [32 w, 32 w + 32) with ALL of the layer's 32-wide input blocks (+ one "ones" block whose column 0 is the bias gradient):
+// up to eight accumulators, kept for the whole chunk and written out by the wave itself -- every input row is read from
+// memory once per chunk (a block per (layer, output block) read it four times: the kernel was bound by those reads).
 // ------------------------------------------------------------------------------------------------------------------------
 typedef short s4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ h8 tr_frag_b(const unsigned char* img, int stride, int col0, int s, int lane) {
@@ -567,11 +603,13 @@ struct BgDwArgs {
   const _Float16* act; const _Float16* dpre; const _Float16* eimg; int M; int chunk;   // chunk: samples per block (multiple of 64)
   float* partials;                                                                       // (chunks, BG_NPARAM)
 };
-constexpr int DW_XST = 464;          // X tile row stride (bytes): up to 224 features + pad (29 x 16)
-constexpr int DW_DST = 80;           // dPre tile row stride: 32 features + pad
+// tile row strides (bytes), = 48 and 16 mod 64 dwords: the four rows a transposing read's 32 lanes touch (64 bytes each) then
+// sit in four different quarters of the 64 banks (272 / 464 bytes put them 4 / 52 dwords apart: 2- to 4-way conflicts)
+constexpr int DW_XST = 448;          // X tile: up to 224 features
+constexpr int DW_DST = 320;          // dPre tile: 128 features + pad
 constexpr int DW_BUF = 64 * DW_XST + 64 * DW_DST;
 template <int LAYER>
-__device__ __forceinline__ void dw_layer(const BgDwArgs& a, int nb, unsigned char* smem) {
+__device__ __forceinline__ void dw_layer(const BgDwArgs& a, unsigned char* smem) {
   constexpr int KB = LAYER == L_IN ? 3 : LAYER == L_CAT ? 7 : LAYER == L_CL ? 6 : 4;    // 32-wide input blocks
   constexpr int NA = LAYER == L_IN ? 0 : 4;                                                // of which from the hidden activation
   constexpr int AIDX = LAYER == L_M1 ? 0 : LAYER == L_CAT ? 1 : LAYER == L_M2 ? 2 : 3;   // which activation array feeds it
@@ -581,22 +619,23 @@ __device__ __forceinline__ void dw_layer(const BgDwArgs& a, int nb, unsigned cha
   constexpr int XPT = (64 * XCH + 255) / 256;                                            // X pieces per thread and tile
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const size_t MH = (size_t)a.M * BH;
-  // this wave's blocks: wv and wv + 4 of [0, KB] (block KB = the bias block)
-  const bool has1 = wv + 4 <= KB;
-  f16v acc0, acc1;
+  f16v acc[KB + 1];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
+  for (int k = 0; k <= KB; ++k)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[k][i] = 0.0f;
   h8 ones;
 #pragma unroll
   for (int j = 0; j < 8; ++j) ones[j] = (lane & 31) == 0 ? (_Float16)1 : (_Float16)0;   // column 0 of the bias block = sum over samples
   const int mc0 = blockIdx.y * a.chunk, mc1 = mc0 + a.chunk < a.M ? mc0 + a.chunk : a.M;
-  f4 dreg, xreg[XPT];
+  f4 dreg[4], xreg[XPT];
   auto load_tile = [&](int m0) {
-    {
-      const int row = threadIdx.x >> 2, ch = threadIdx.x & 3;
-      dreg = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = e * 256 + threadIdx.x, row = i >> 4, ch = i & 15;
+      dreg[e] = f4{0.f, 0.f, 0.f, 0.f};
       if (m0 + row < mc1)
-        dreg = *reinterpret_cast<const f4*>(reinterpret_cast<const unsigned char*>(a.dpre + DIDX * MH + (size_t)(m0 + row) * BH + 32 * nb) + ch * 16);
+        dreg[e] = *reinterpret_cast<const f4*>(reinterpret_cast<const unsigned char*>(a.dpre + DIDX * MH + (size_t)(m0 + row) * BH) + ch * 16);
     }
 #pragma unroll
     for (int e = 0; e < XPT; ++e) {
@@ -614,7 +653,11 @@ __device__ __forceinline__ void dw_layer(const BgDwArgs& a, int nb, unsigned cha
   auto store_tile_lds = [&](unsigned char* buf) {
     unsigned char* Xt = buf;
     unsigned char* Dt = buf + 64 * DW_XST;
-    *reinterpret_cast<f4*>(Dt + (threadIdx.x >> 2) * DW_DST + (threadIdx.x & 3) * 16) = dreg;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = e * 256 + threadIdx.x;
+      *reinterpret_cast<f4*>(Dt + (i >> 4) * DW_DST + (i & 15) * 16) = dreg[e];
+    }
 #pragma unroll
     for (int e = 0; e < XPT; ++e) {
       const int i = e * 256 + threadIdx.x, row = i / XCH, ch = i % XCH;
@@ -634,30 +677,21 @@ __device__ __forceinline__ void dw_layer(const BgDwArgs& a, int nb, unsigned cha
     const unsigned char* Dt = Xt + 64 * DW_XST;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {      // 16 samples per k-step
-      const h8 df = tr_frag_b(Dt, DW_DST, 0, s, lane);
-      if (wv < KB) acc0 = MFMA(df, tr_frag_b(Xt, DW_XST, 32 * wv, s, lane), acc0);
-      else acc0 = MFMA(df, ones, acc0);                                      // (KB = 3: wave 3 holds the bias block)
-      if (has1) {
-        if (wv + 4 < KB) acc1 = MFMA(df, tr_frag_b(Xt, DW_XST, 32 * (wv + 4), s, lane), acc1);
-        else acc1 = MFMA(df, ones, acc1);
-      }
+      const h8 df = tr_frag_b(Dt, DW_DST, 32 * wv, s, lane);
+#pragma unroll
+      for (int k = 0; k < KB; ++k) acc[k] = MFMA(df, tr_frag_b(Xt, DW_XST, 32 * k, s, lane), acc[k]);
+      acc[KB] = MFMA(df, ones, acc[KB]);
     }
     if (more) store_tile_lds(smem + (buf ^ 1) * DW_BUF);
     __syncthreads();
     buf ^= 1;
   }
-  // ---- out: accumulator rows = outputs n, lanes = input columns --------------------------------------------------------------
+  // ---- out: accumulator rows = outputs n of block wv, lanes = input columns -----------------------------------------------
   float* part = a.partials + (size_t)blockIdx.y * BG_NPARAM;
   const int kcol = lane & 31, hh = lane >> 5;
   constexpr int WOFF = w_off(LAYER), BOFF = b_off(LAYER), LD = ld_of(LAYER);
-  auto write_block = [&](int k, const f16v& acc) {
-    if (k == KB) {
-      if (kcol == 0) {
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) part[BOFF + 32 * nb + acc_row(reg, hh)] = acc[reg];
-      }
-      return;
-    }
+  for (int k = 0; k < KB; ++k) {
     int wcol;
     if (k < NA) wcol = 32 * k + kcol;
     else {
@@ -667,21 +701,22 @@ __device__ __forceinline__ void dw_layer(const BgDwArgs& a, int nb, unsigned cha
     }
     if (wcol >= 0) {
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg) part[WOFF + (32 * nb + acc_row(reg, hh)) * LD + wcol] = acc[reg];
+      for (int reg = 0; reg < 16; ++reg) part[WOFF + (32 * wv + acc_row(reg, hh)) * LD + wcol] = acc[k][reg];
     }
-  };
-  if (wv <= KB) write_block(wv, acc0);
-  if (has1) write_block(wv + 4, acc1);
+  }
+  if (kcol == 0) {
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) part[BOFF + 32 * wv + acc_row(reg, hh)] = acc[KB][reg];
+  }
 }
-__global__ __launch_bounds__(256, 2) void bg_dw_kernel(BgDwArgs a) {
+__global__ __launch_bounds__(256, 1) void bg_dw_kernel(BgDwArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int layer = blockIdx.x >> 2, nb = blockIdx.x & 3;
-  switch (layer) {
-    case 0: dw_layer<L_IN>(a, nb, smem); break;
-    case 1: dw_layer<L_M1>(a, nb, smem); break;
-    case 2: dw_layer<L_CAT>(a, nb, smem); break;
-    case 3: dw_layer<L_M2>(a, nb, smem); break;
-    default: dw_layer<L_CL>(a, nb, smem); break;
+  switch (blockIdx.x) {
+    case 0: dw_layer<L_CAT>(a, smem); break;       // heaviest layer first in the dispatch order
+    case 1: dw_layer<L_CL>(a, smem); break;
+    case 2: dw_layer<L_M1>(a, smem); break;
+    case 3: dw_layer<L_M2>(a, smem); break;
+    default: dw_layer<L_IN>(a, smem); break;
   }
 }
 constexpr int BG_DW_LDS = 2 * DW_BUF;
@@ -692,7 +727,39 @@ constexpr int BG_DW_LDS = 2 * DW_BUF;
 struct BgTailArgs {
   float* theta; float* grad; float* m; float* v; const float* partials; int chunks; const float* records; int nrec;
   float inv_gscale, lr, b1, b2, eps, wd; int64_t* d_state; int64_t add_rows;
+  unsigned char* packed;               // != NULL: the thread that updates a weight also refreshes its f16 fragment slots
+  const float* rl_partials; int rl_nb; float* losses; int32_t* flags;   // != NULL: one more block forms the step's loss values
 };
+// Where weight (layer l, output o, input column c) sits in the packed images: the forward fragment (and, geometry layers, its
+// residual twin at the same index) and the transposed fragment.  The inverse of bg_pack_kernel's maps: with `packed` given to
+// the tail, a parameter's fragments are refreshed by the thread that applies its AdamW update and the next step needs no pack
+// launch (padding slots keep the zeros of the first cnr_bg_pack).
+__device__ __forceinline__ void refresh_slots(unsigned char* packed, int l, int o, int c, float v) {
+  const _Float16 hi = (_Float16)v;
+  {
+    const int wb = l == L_OC ? 0 : o >> 5, r = o & 31, s = c >> 4, h = (c >> 3) & 1, j = c & 7;
+    const int f = fwd_base(l) + wb * ks(l) + s, e = (r + 32 * h) * 8 + j;
+    reinterpret_cast<_Float16*>(packed + PK_FWD_OFF + (size_t)f * FRAG_BYTES)[e] = hi;
+    if (l <= L_M2) reinterpret_cast<_Float16*>(packed + PK_LO_OFF + (size_t)f * FRAG_BYTES)[e] = (_Float16)(v - (float)hi);
+  }
+  {
+    const int ib = c >> 5, r = c & 31, s = l == L_OC ? 0 : o >> 4, h = (o >> 3) & 1, j = o & 7;
+    const int f = bwd_base(l) + (l == L_OC ? ib : ib * 8 + s), e = (r + 32 * h) * 8 + j;
+    reinterpret_cast<_Float16*>(packed + PK_BWD_OFF + (size_t)f * FRAG_BYTES)[e] = hi;
+  }
+}
+__device__ __forceinline__ void refresh_param(unsigned char* packed, int i, float v) {
+  int l = -1;
+  if (i < O_IN_B) l = L_IN;
+  else if (i >= O_M1_W && i < O_M1_B) l = L_M1;
+  else if (i >= O_CAT_W && i < O_CAT_B) l = L_CAT;
+  else if (i >= O_M2_W && i < O_M2_B) l = L_M2;
+  else if (i >= O_CL_W && i < O_CL_B) l = L_CL;
+  else if (i >= O_OC_W && i < O_OC_B) l = L_OC;
+  if (l < 0) return;                    // biases, out_alpha and B_layer are read from theta in fp32
+  const int rel = i - w_off(l), ld = ld_of(l);
+  refresh_slots(packed, l, rel / ld, rel % ld, v);
+}
 __device__ __forceinline__ int rec_slot(int i) {   // record entry of small parameter i, -1 = a big-layer parameter
   if (i >= O_OA_W && i < O_OA_W + BH) return R_OAW + (i - O_OA_W);
   if (i == O_OA_B) return R_OAB;
@@ -701,8 +768,8 @@ __device__ __forceinline__ int rec_slot(int i) {   // record entry of small para
   if (i >= O_PE_B) return R_PEB + (i - O_PE_B);
   return -1;
 }
-// blocks [0, NBIG): one parameter per thread, its partials summed over the chunks; blocks [NBIG, NBIG + BG_REC / 64): 64 record
-// entries each, the workgroups' records split over the four waves (eight loads in flight each), combined in wave order
+// blocks [0, NBIG): one parameter per thread, its partials summed over the chunks; blocks [NBIG, NBIG + BG_REC / 16): 16 record
+// entries each, the workgroups' records split over 16 thread groups (eight loads in flight each), combined in group order
 __device__ __forceinline__ int rec_param(int e) {   // parameter of record entry e, -1 = padding
   if (e < R_OCW + 3 * BH) return O_OC_W + (e - R_OCW);
   if (e >= R_OCB && e < R_OCB + 3) return O_OC_B + (e - R_OCB);
@@ -713,7 +780,7 @@ __device__ __forceinline__ int rec_param(int e) {   // parameter of record entry
 }
 constexpr int TAIL_NBIG = (BG_NPARAM + 255) / 256;
 __global__ __launch_bounds__(256) void bg_tail_kernel(BgTailArgs a) {
-  __shared__ float part[4][64];
+  __shared__ float part[16][16];
   const int64_t t = a.d_state[2] + (a.add_rows >= 0 ? 1 : 0);   // add_rows < 0: the state was advanced earlier in the step
   cnr::AdamArgs ad{a.theta, a.grad, a.m, a.v, BG_NPARAM, a.lr, a.b1, a.b2, a.eps, a.wd, 1.0f};
   float step_size, inv_bc2;
@@ -724,30 +791,41 @@ __global__ __launch_bounds__(256) void bg_tail_kernel(BgTailArgs a) {
     i = blockIdx.x * 256 + threadIdx.x;
     if (i >= BG_NPARAM || rec_slot(i) >= 0) i = -1;
     if (i >= 0) {
-      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      float sv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       int c = 0;
-      for (; c + 4 <= a.chunks; c += 4) {
-        s0 += a.partials[(size_t)(c + 0) * BG_NPARAM + i]; s1 += a.partials[(size_t)(c + 1) * BG_NPARAM + i];
-        s2 += a.partials[(size_t)(c + 2) * BG_NPARAM + i]; s3 += a.partials[(size_t)(c + 3) * BG_NPARAM + i];
+      for (; c + 8 <= a.chunks; c += 8) {       // eight loads in flight (the sum is a memory round trip per trip)
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = a.partials[(size_t)(c + u) * BG_NPARAM + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sv[u] += v[u];
       }
-      for (; c < a.chunks; ++c) s0 += a.partials[(size_t)c * BG_NPARAM + i];
-      g = (s0 + s1) + (s2 + s3);
+      for (; c < a.chunks; ++c) sv[0] += a.partials[(size_t)c * BG_NPARAM + i];
+      g = ((sv[0] + sv[1]) + (sv[2] + sv[3])) + ((sv[4] + sv[5]) + (sv[6] + sv[7]));
     }
   } else {
-    const int e = ((int)blockIdx.x - TAIL_NBIG) * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
-    const int per = (a.nrec + 3) / 4, r0 = q * per, r1 = r0 + per < a.nrec ? r0 + per : a.nrec;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    // 16 record entries x 16 groups of records per block: ~nrec / 16 loads per thread, eight in flight
+    const int el = threadIdx.x & 15, q = threadIdx.x >> 4;
+    const int e = ((int)blockIdx.x - TAIL_NBIG) * 16 + el;
+    const int per = (a.nrec + 15) / 16, r0 = q * per, r1 = r0 + per < a.nrec ? r0 + per : a.nrec;
+    float sv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int r = r0;
-    for (; r + 4 <= r1; r += 4) {
-      s0 += a.records[(size_t)(r + 0) * BG_REC + e]; s1 += a.records[(size_t)(r + 1) * BG_REC + e];
-      s2 += a.records[(size_t)(r + 2) * BG_REC + e]; s3 += a.records[(size_t)(r + 3) * BG_REC + e];
+    for (; r + 8 <= r1; r += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = a.records[(size_t)(r + u) * BG_REC + e];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) sv[u] += v[u];
     }
-    for (; r < r1; ++r) s0 += a.records[(size_t)r * BG_REC + e];
-    part[q][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+    for (; r < r1; ++r) sv[0] += a.records[(size_t)r * BG_REC + e];
+    part[q][el] = ((sv[0] + sv[1]) + (sv[2] + sv[3])) + ((sv[4] + sv[5]) + (sv[6] + sv[7]));
     __syncthreads();
     if (q == 0) {
       i = rec_param(e);
-      g = (part[0][e & 63] + part[1][e & 63]) + (part[2][e & 63] + part[3][e & 63]);
+      float t = 0.0f;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) t += part[u][el];
+      g = t;
     }
   }
   if (i >= 0) {
@@ -758,7 +836,11 @@ __global__ __launch_bounds__(256) void bg_tail_kernel(BgTailArgs a) {
     const float vi = a.v[i] * a.b2 + (1.0f - a.b2) * g * g;
     p -= step_size * (mi / (sqrtf(vi) * inv_bc2 + a.eps));
     a.theta[i] = p; a.m[i] = mi; a.v[i] = vi;
+    if (a.packed) refresh_param(a.packed, i, p);
   }
+  // the step's loss values out of the render kernel's per-block partials (cnr_render_loss_finish's job, one block of this launch)
+  if (a.rl_partials && blockIdx.x == gridDim.x - 1 && threadIdx.x < 64)
+    cnr_rl::finish_class(a.rl_partials, a.rl_nb, a.losses, a.flags, 1, 0, threadIdx.x);
 }
 __global__ void bg_advance_kernel(int64_t* d_state, int64_t add_rows) {
   if (threadIdx.x == 0 && blockIdx.x == 0) { d_state[0] += add_rows; d_state[1] += 1; d_state[2] += 1; }
@@ -818,22 +900,26 @@ extern "C" int cnr_bg_dw(const void* act, const void* dpre, const void* eimg, in
   const int er = cnr::set_max_dynamic_lds(once, (const void*)bg_dw_kernel, BG_DW_LDS);
   if (er) return er;
   BgDwArgs a{(const _Float16*)act, (const _Float16*)dpre, (const _Float16*)eimg, M, chunk, partials};
-  hipLaunchKernelGGL(bg_dw_kernel, dim3(20, (unsigned)cnr_bg_dw_chunks(M, chunk)), dim3(256), BG_DW_LDS, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(bg_dw_kernel, dim3(5, (unsigned)cnr_bg_dw_chunks(M, chunk)), dim3(256), BG_DW_LDS, (hipStream_t)stream, a);
   CNR_LAUNCH_CHECK();
   return CNR_OK;
 }
 
 extern "C" int cnr_bg_tail(float* theta, float* grad, float* exp_avg, float* exp_avg_sq, const float* partials, int chunks,
                            const float* records, int nrec, float grad_scale, float lr, float beta1, float beta2, float eps,
-                           float weight_decay, int64_t* d_state, int64_t add_rows, void* stream) {
+                           float weight_decay, int64_t* d_state, int64_t add_rows, void* packed, const void* rl_workspace,
+                           int R, float* losses, int32_t* flags, void* stream) {
+  if (rl_workspace && (!losses || !flags || R <= 0)) return CNR_E_ARG;
+  if (((uintptr_t)packed & 15) != 0) return CNR_E_ALIGN;
   if (!theta || !grad || !exp_avg || !exp_avg_sq || !partials || !records || chunks <= 0 || nrec <= 0 || !d_state ||
       !(grad_scale > 0.f) || !(lr > 0.f) || BG_REC % 64 != 0)
     return CNR_E_ARG;
   BgTailArgs a{theta, grad, exp_avg, exp_avg_sq, partials, chunks, records, nrec, 1.0f / grad_scale, lr, beta1, beta2, eps,
-               weight_decay, d_state, add_rows};
+               weight_decay, d_state, add_rows, (unsigned char*)packed, (const float*)rl_workspace, 0, losses, flags};
+  if (rl_workspace) { const int rpb = cnr_rl::rl_rays_per_block(1, R); a.rl_nb = (R + rpb - 1) / rpb; }
   // (the step count is read by every block: the state moves in a second, one-thread launch behind them -- or, add_rows < 0,
   //  it was moved by cnr_bg_backward already, the launch between the sampler, which reads the cursor, and this one)
-  hipLaunchKernelGGL(bg_tail_kernel, dim3(TAIL_NBIG + BG_REC / 64), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(bg_tail_kernel, dim3(TAIL_NBIG + BG_REC / 16), dim3(256), 0, (hipStream_t)stream, a);
   if (add_rows >= 0) hipLaunchKernelGGL(bg_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_state, add_rows);
   CNR_LAUNCH_CHECK();
   return CNR_OK;

@@ -137,8 +137,9 @@ extern "C" int cnr_sample_rays(const uint8_t* rgbs, const float* depth, const fl
                                float eps, float stop_eps, float min_bound, float* z, float* pts,
                                float* origins, float* dirs_o, float* gt_rgb, float* gt_depth,
                                uint8_t* depth_mask, uint8_t* labels, const int64_t* pool_indices, int n_obj,
-                               int* ray_row, const int* perm, void* stream) {
+                               int* ray_row, const int* perm, int max_bound_slices, void* stream) {
   if (!rgbs || !depth || !dirs_c || !T || !z || !pts || !gt_rgb || !depth_mask || !labels) return CNR_E_ARG;
+  if (max_bound_slices < 0 || (max_bound_slices > 1 && (pool_rows <= 0 || !d_state || !max_bound))) return CNR_E_ARG;
   if (C <= 0 || R <= 0 || n1 < 0 || n2 <= 0) return CNR_E_ARG;
   if (n2 > 128) return CNR_E_SHAPE;
   if ((u == nullptr) != (g == nullptr)) return CNR_E_ARG;
@@ -150,7 +151,7 @@ extern "C" int cnr_sample_rays(const uint8_t* rgbs, const float* depth, const fl
   const int64_t blocks = (rays + waves_per_block - 1) / waves_per_block;
   cnr_sample::SampleArgs args{rgbs, depth, dirs_c, T, u, g, seed, offset, d_state, pool_rows, max_bound, world_frame,
                               C, R, n1, n2, eps, stop_eps, min_bound, z, pts, origins, dirs_o, gt_rgb, gt_depth,
-                              depth_mask, labels, pool_indices, n_obj, ray_row, perm, 0, 0, 0, 0, 0};
+                              depth_mask, labels, pool_indices, n_obj, ray_row, perm, max_bound_slices, 0, 0, 0, 0};
   hipLaunchKernelGGL(sample_kernel, dim3((unsigned)blocks), dim3(64 * waves_per_block), 0, (hipStream_t)stream, args);
   CNR_LAUNCH_CHECK();
   return CNR_OK;

@@ -234,7 +234,7 @@ class RenderLossFn(Function):
 def sample_rays(rgbs, depth, dirs_c, T, n1, n2, eps, stop_eps, min_bound=0.0, world_frame=False,
                 u=None, g=None, seed=0, offset=0, want_rays=False, d_state=None, rays=None, out=None,
                 max_bound=None,
-                pool_indices=None, n_obj=0, perm=None):
+                pool_indices=None, n_obj=0, perm=None, max_bound_slices=0):
     """Class-batched pool slice (C,R,...) -> dict(z, pts, gt_rgb, gt_depth, depth_mask, labels[, origins, dirs_o]).
     u/g given -> parity mode (identical draws); else in-kernel Philox(seed, offset).
     d_state (int64[3] device) + rays=R: the inputs are whole (C,pool_rows,...) pools and the slice starts at
@@ -265,7 +265,7 @@ def sample_rays(rgbs, depth, dirs_c, T, n1, n2, eps, stop_eps, min_bound=0.0, wo
     _C.call("cnr_sample_rays", rgbs.contiguous(), depth.contiguous(), dirs_c.contiguous(), T.contiguous(),
             cont(u), cont(g), int(seed), int(offset), d_state, pool_rows, mb, int(bool(world_frame)), C, R, n1, n2,
             float(eps), float(stop_eps), float(min_bound), z, pts, org, dro, gt, gd, dm, lab,
-            pool_indices, int(n_obj), rr, perm)
+            pool_indices, int(n_obj), rr, perm, int(max_bound_slices))
     return o
 
 

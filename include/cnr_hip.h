@@ -70,6 +70,8 @@ int cnr_camera_rays(float* dirs, int W, int H, float fx, float fy, float cx, flo
  *   NULL), depth_mask (C,R) u8, labels (C,R) u8; ray_row (C,R) i32 = pool_indices[slice] + c * n_obj, the row of
  *   each ray in class-major (C*n_obj, ...) code / bias-row tables (NULL to skip; pool_indices is (C,R) or,
  *   with pool_rows > 0, the (C,pool_rows) int64 base). */
+/* cnr_sample_rays, max_bound_slices = k > 1: max_bound is a (C, k) table over the epoch's slices (cnr_slice_maxdepth), indexed on
+ * the device by d_state[0] / R -- no per-step maximum launch; 0 or 1: one value per class for this step's slice. */
 int cnr_sample_maxdepth(const float* depth, float* max_bound, const int64_t* d_state, int64_t pool_rows,
                         const int* perm, int C, int R, void* stream);
 int cnr_sample_rays(const uint8_t* rgbs, const float* depth, const float* dirs_c, const float* T,
@@ -79,7 +81,8 @@ int cnr_sample_rays(const uint8_t* rgbs, const float* depth, const float* dirs_c
                     float eps, float stop_eps, float min_bound,
                     float* z, float* pts, float* origins, float* dirs_o,
                     float* gt_rgb, float* gt_depth, uint8_t* depth_mask, uint8_t* labels,
-                    const int64_t* pool_indices, int n_obj, int* ray_row, const int* perm, void* stream);
+                    const int64_t* pool_indices, int n_obj, int* ray_row, const int* perm, int max_bound_slices,
+                    void* stream);
 /* Device-resident step state int64[3] = {pool cursor (rows), rng step, optimiser step}.  With pool_rows > 0
  * the four pool pointers above are the BASES of (C, pool_rows, ...) pools and the slice starts at row
  * d_state[0] (src/scene_cateogries.py:422-431's i_batch); the Philox offset advances by d_state[1].
@@ -585,6 +588,9 @@ int cnr_field_train(const cnr_field_train_args* args, void* stream);
  *             d_state += (add_rows, 1, 1).  With d_state given to cnr_bg_backward (it then advances the state: the sampler, which
  *             reads the cursor, ran before it, the optimiser, which reads the step count, runs after it) pass add_rows = -1
  *             here: the step count is then d_state[2] as it stands and no state launch follows.
+ *             packed != NULL: every weight's f16 fragment slots are refreshed by the thread that updates it (the next step then
+ *             needs no cnr_bg_pack; call cnr_bg_pack once before the first step and after any outside change of theta);
+ *             rl_workspace != NULL: cnr_render_loss's workspace for R rays -> losses (3,1), flags (1) (= cnr_render_loss_finish).
  * No float atomics: two runs give the same bits. */
 int64_t cnr_bg_pack_bytes(void);
 int cnr_bg_param_count(void);
@@ -600,7 +606,8 @@ int cnr_bg_backward(const float* pts, const float* theta, const void* packed, fl
 int cnr_bg_dw(const void* act, const void* dpre, const void* eimg, int M, int chunk, float* partials, void* stream);
 int cnr_bg_tail(float* theta, float* grad, float* exp_avg, float* exp_avg_sq, const float* partials, int chunks,
                 const float* records, int nrec, float grad_scale, float lr, float beta1, float beta2, float eps,
-                float weight_decay, int64_t* d_state, int64_t add_rows, void* stream);
+                float weight_decay, int64_t* d_state, int64_t add_rows, void* packed, const void* rl_workspace, int R,
+                float* losses, int32_t* flags, void* stream);
 
 #ifdef __cplusplus
 }

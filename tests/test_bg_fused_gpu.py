@@ -84,7 +84,16 @@ def test_fused_background_step_against_the_reference_vectors(dev, name):
         off += 128 * k + 128
     th2, grad, m, v = theta.clone(), f(n), f(n), f(n)
     state = torch.zeros(3, device=dev, dtype=torch.int64)
-    _C.call("cnr_bg_tail", th2, grad, m, v, partials, nch, records, nblk, gscale, 1e-3, 0.9, 0.999, 1e-8, 0.013, state, R)
+    packed2 = packed.clone()
+    losses_t, flags_t = f(3, 1), f(1, dt=torch.int32)
+    _C.call("cnr_bg_tail", th2, grad, m, v, partials, nch, records, nblk, gscale, 1e-3, 0.9, 0.999, 1e-8, 0.013, state, R, packed2,
+            ws, R, losses_t, flags_t)
+    # the tail refreshed the fragments of every weight it updated: identical to a fresh pack of the new parameters; and its loss
+    # block is cnr_render_loss_finish
+    fresh = torch.zeros_like(packed)
+    _C.call("cnr_bg_pack", th2, fresh)
+    assert torch.equal(packed2, fresh)
+    assert torch.equal(losses_t, losses) and torch.equal(flags_t, flags)
     torch.cuda.synchronize()
     assert state.tolist() == [R, 1, 1]
     ref = _flat(g, "grad.")
@@ -108,7 +117,7 @@ def test_fused_background_step_against_the_reference_vectors(dev, name):
     _C.call("cnr_bg_backward", pts, theta, packed, g.scale, M, dsig, drgb, rgbs, act, dpre, records, st3, R)   # the state moves here ...
     _C.call("cnr_bg_dw", act, dpre, eimg, M, chunk, partials)
     _C.call("cnr_bg_tail", th3, grad3, f(n), f(n), partials, nch, records, nblk, gscale, 1e-3, 0.9, 0.999, 1e-8, 0.013,
-            st3, -1)                                                                                          # ... and the tail reads it as it stands
+            st3, -1, None, None, 0, None, None)                                                                                          # ... and the tail reads it as it stands
     assert torch.equal(grad3, grad) and torch.equal(th3, th2) and st3.tolist() == [R, 1, 1]
 
 
