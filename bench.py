@@ -426,7 +426,7 @@ def main():
     # HBM bytes of that call from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc passes,
     # gfx950 corrections per MI355X_MICROARCH.md): measured offline on this shape, kept in profiles/
     traffic = None
-    for tname in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for tname in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", tname)
         if dom == bwd_name and (C, R, S) == (1, 2048, 64) and os.path.exists(tpath):
             traffic = json.load(open(tpath)).get(bwd_name + "_call_hbm_bytes")

@@ -797,6 +797,7 @@ __global__ __launch_bounds__(256) void bg_tail_kernel(BgTailArgs a) {
         float v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) v[u] = a.partials[(size_t)(c + u) * BG_NPARAM + i];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < 8; ++u) sv[u] += v[u];
       }
@@ -814,6 +815,7 @@ __global__ __launch_bounds__(256) void bg_tail_kernel(BgTailArgs a) {
       float v[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) v[u] = a.records[(size_t)(r + u) * BG_REC + e];
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < 8; ++u) sv[u] += v[u];
     }

@@ -37,13 +37,24 @@ __device__ __forceinline__ float record_range_sum(const float* __restrict__ r, i
 #pragma unroll
   for (int u = 0; u < U; ++u) a[u] = 0.0f;
   int w = w0;
+  // (loads into their own registers, a scheduling barrier, then the adds: written as a[u] += r[..] the compiler is free to
+  //  serialise load -> wait -> add per record, and without the SLP vectoriser it does: 19 instead of 5 us per reduction)
   for (; w + U - 1 < w1; w += U) {
+    float v[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) a[u] += r[(size_t)(w + u) * REC_FLOATS];
+    for (int u = 0; u < U; ++u) v[u] = r[(size_t)(w + u) * REC_FLOATS];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) a[u] += v[u];
   }
+  {
+    float v[U];
 #pragma unroll
-  for (int u = 0; u < U; ++u)   // the rest (< U records), still issued together
-    if (w + u < w1) a[u] += r[(size_t)(w + u) * REC_FLOATS];
+    for (int u = 0; u < U; ++u) v[u] = (w + u < w1) ? r[(size_t)(w + u) * REC_FLOATS] : 0.0f;   // the rest (< U records), issued together
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) a[u] += v[u];
+  }
 #pragma unroll
   for (int st = U / 2; st >= 1; st >>= 1) {
 #pragma unroll
