@@ -1,4 +1,4 @@
-// Shared pieces of the fused backward kernels (fused_bwd.hip: two-launch block split; fused_bwd_pipe.hip:
+// Shared pieces of the fused backward kernels (fused_bwd.hip: two-launch block split; fused_bwd_pipe8.hip:
 // chain / dW wave pipeline): LDS image formats, transposing operand reads, the dW block -> parameter map, the
 // per-workgroup record format and its fixed-order reduction.
 #pragma once
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void reduce_records_kernel(const float* __rest
   }
 }
 
-// ---- shared by the pipelined kernels (fused_bwd_pipe.hip, fused_bwd_pipe8.hip) ------------------------------------
+// ---- the pipelined kernel's helpers (fused_bwd_pipe8.hip) ----------------------------------------------------------
 template <int V> using IC = std::integral_constant<int, V>;
 enum Step { ST_R2, ST_R0, ST_T1, ST_VD, ST_ES, ST_S2, ST_CAT, ST_S1, ST_XYZ, NSTEPS };
 

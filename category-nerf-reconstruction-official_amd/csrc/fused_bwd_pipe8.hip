@@ -1,6 +1,6 @@
 // Fused field backward, 8-wave pipeline: workgroup = 4 chain waves + 4 dW waves, one of each per SIMD (TWO waves per SIMD:
 // a chain wave's dependent latency -- MFMA result -> mask / pack -> image store -> barrier -- is covered by its SIMD
-// partner instead of idling the SIMD as in fused_bwd_pipe.hip's 3 + 1 form).
+// partner instead of idling the SIMD as in round 1's 3 + 1 form, one wave per SIMD).
 // What it takes to fit eight waves into one CU:
 //   * 256 registers per wave: the 16 accumulator blocks are spread over the four dW waves (<= 5 each); a chain wave
 //     keeps a0 .. a7 in registers until their step stages them as the layer input (no parked images);
@@ -141,22 +141,46 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
   // role branches: the chain waves first put their own first global requests in flight (first tile's inputs, step state),
   // whose round trips then run under this copy instead of after it (~2 us of every workgroup at 2048 x 64)
   auto copy_operands = [&]() {
-    const unsigned char* src = packed + (size_t)c * PK_BYTES;
-    for (int i = threadIdx.x * 16; i < PK_BYTES; i += NTHR * 16)
-      *reinterpret_cast<f4*>(smem + i) = *reinterpret_cast<const f4*>(src + i);
+    // 61 KB (+ 20 KB of residual fragments) per workgroup: EVERY 16-byte load of a thread is issued before its first LDS store
+    // (one memory round trip; written as a load -> store loop the copy was eight dependent round trips: 7.5 k cycles of every
+    // workgroup, stamped)
+    constexpr int NV = (PK_BYTES / 16 + NTHR - 1) / NTHR, NVL = GEO ? (PK_LO_BYTES / 16 + NTHR - 1) / NTHR : 0;
+    const f4* src = reinterpret_cast<const f4*>(packed + (size_t)c * PK_BYTES);
+    f4 v[NV], vl[NVL > 0 ? NVL : 1];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int i = threadIdx.x + k * NTHR;
+      v[k] = i < PK_BYTES / 16 ? src[i] : f4{0.f, 0.f, 0.f, 0.f};
+    }
+    if constexpr (GEO) {   // residual fragments of the geometry branch behind the packed image
+      const f4* lsrc = reinterpret_cast<const f4*>(packed_lo + (size_t)c * PK_LO_BYTES);
+#pragma unroll
+      for (int k = 0; k < NVL; ++k) {
+        const int i = threadIdx.x + k * NTHR;
+        vl[k] = i < PK_LO_BYTES / 16 ? lsrc[i] : f4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
     float* Bl = reinterpret_cast<float*>(smem + L8_BL);
     for (int i = threadIdx.x; i < 66; i += NTHR) {
       const int hh = i / 33, k = i % 33, d = k / 3;
       Bl[i] = (hh == 1 && d == 10) ? 0.0f : Bdir[(size_t)c * B_stride + (11 * hh + d) * 3 + (k % 3)];
     }
-    if constexpr (GEO) {   // residual fragments of the geometry branch behind the packed image
-      const unsigned char* lsrc = packed_lo + (size_t)c * PK_LO_BYTES;
-      for (int i = threadIdx.x * 16; i < PK_LO_BYTES; i += NTHR * 16)
-        *reinterpret_cast<f4*>(smem + l8_lo() + i) = *reinterpret_cast<const f4*>(lsrc + i);
-    }
     if constexpr (BROWS_LDS) {
       float* br = reinterpret_cast<float*>(smem + L8_BR);  // host guarantees 1 <= rows_per_class <= RS_ROWS
       for (int i = threadIdx.x; i < rows_per_class * 128; i += NTHR) br[i] = biasrows[(size_t)c * rows_per_class * 128 + i];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int i = threadIdx.x + k * NTHR;
+      if (i < PK_BYTES / 16) reinterpret_cast<f4*>(smem)[i] = v[k];
+    }
+    if constexpr (GEO) {
+#pragma unroll
+      for (int k = 0; k < NVL; ++k) {
+        const int i = threadIdx.x + k * NTHR;
+        if (i < PK_LO_BYTES / 16) reinterpret_cast<f4*>(smem + l8_lo())[i] = vl[k];
+      }
     }
     __syncthreads();
     P8PHASE(1);
@@ -1012,7 +1036,7 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
 }
 }  // namespace
 
-// launched by cnr_field_bwd_pipe (fused_bwd_pipe.hip) for chain_waves = 4: same argument checks, same records
+// launched by cnr_field_bwd_pipe (below) and cnr_field_train: same records
 template <int WIDE, int KR, bool TWO = false, bool PAD = false, bool GEO = false>
 static int launch_p8(const float* pts, const float* B, const void* packed, const void* packed_lo, const float* biasrows,
                      const int* ray_row, float scale, const float* d_sigma, const float* d_rgb, float grad_scale, int C,
@@ -1031,7 +1055,7 @@ static int launch_p8(const float* pts, const float* B, const void* packed, const
   return CNR_OK;
 }
 
-extern "C" int cnr_field_bwd_pipe8_launch(const float* pts, const float* B, const void* packed, const float* biasrows,
+static int cnr_field_bwd_pipe8_launch(const float* pts, const float* B, const void* packed, const float* biasrows,
                                           const int* ray_row, float scale, const float* d_sigma, const float* d_rgb,
                                           float grad_scale, int C, int R, int S, int rows_per_class, int blocks,
                                           void* workspace, int64_t B_stride, long long* rows_fix, int* clamp_flags,
@@ -1045,6 +1069,53 @@ extern "C" int cnr_field_bwd_pipe8_launch(const float* pts, const float* B, cons
                            rows_per_class, blocks, workspace, B_stride, rows_fix, clamp_flags, none, stream);
   return launch_p8<0, 0>(pts, B, packed, nullptr, biasrows, ray_row, scale, d_sigma, d_rgb, grad_scale, C, R, S,
                          rows_per_class, blocks, workspace, B_stride, rows_fix, clamp_flags, none, stream);
+}
+
+// ---- cnr_field_bwd_pipe: the stand-alone backward (cnr_field_bwd's contract) on the 8-wave kernel + the record reduction ----
+// (chain_waves is kept in the signature: 4 = this kernel, the only pipelined form; the 4-wave forms with 2 / 3 chain waves of
+//  rounds 1-2 are gone.  No ray_row, or more than 15 rows per class: the block-split kernels of fused_bwd.hip.)
+extern "C" int cnr_field_bwd_pipe_blocks(int R, int S, int chain_waves, int max_blocks) {
+  if (R <= 0 || S <= 0 || chain_waves != 4) return 0;
+  const int64_t ntiles = ((int64_t)R * S + 31) / 32;
+  int64_t blocks = (ntiles + chain_waves - 1) / chain_waves;
+  const int64_t cap = max_blocks > 0 ? max_blocks : 256;
+  return (int)(blocks > cap ? cap : blocks);
+}
+
+extern "C" int cnr_field_bwd_pipe(const float* pts, const float* B, const void* packed, const float* biasrows,
+                                  const int* ray_row, float scale, const float* d_sigma, const float* d_rgb,
+                                  float grad_scale, float* dtrunk, float* dB, float* dbiasrows, int C, int R, int S,
+                                  int rows_per_class, int max_blocks, int chain_waves, void* workspace,
+                                  int64_t workspace_bytes, int64_t B_stride, int64_t dtrunk_stride, int64_t dB_stride,
+                                  long long* rows_fix, int skip_reduce, int* clamp_flags, void* stream) {
+  if (!pts || !B || !packed || !biasrows || !d_sigma || !d_rgb || !dtrunk || !dB || !dbiasrows || !workspace)
+    return CNR_E_ARG;
+  if (C <= 0 || R <= 0 || S <= 0 || !(scale > 0.f) || !(grad_scale > 0.f)) return CNR_E_ARG;
+  if (chain_waves != 4) return CNR_E_ARG;
+  // the pipeline keeps per-object row sums in its row-sum accumulator blocks: class-major rows, at most ROWS_MAX = 15 per
+  // class.  Everything else (one row per ray, more objects) takes the block-split kernels.
+  if (ray_row == nullptr || rows_per_class < 1 || rows_per_class > cnr_rec::ROWS_MAX) {
+    if (rows_fix || skip_reduce) return CNR_E_ARG;   // those two need the pipelined kernel's per-object rows
+    return cnr_field_bwd(pts, B, packed, biasrows, ray_row, scale, d_sigma, d_rgb, grad_scale, dtrunk, dB, dbiasrows, C,
+                         R, S, rows_per_class, max_blocks, workspace, workspace_bytes, B_stride, dtrunk_stride, dB_stride,
+                         stream);
+  }
+  if (S > 240) return CNR_E_SHAPE;
+  if (((uintptr_t)packed & 15) != 0 || ((uintptr_t)biasrows & 15) != 0 || ((uintptr_t)workspace & 15) != 0)
+    return CNR_E_ALIGN;
+  const int64_t N = (int64_t)R * S;
+  if (N > (int64_t)0x7fffff00) return CNR_E_SHAPE;  // tile and sample indices are 32-bit inside the kernel
+  const int blocks = cnr_field_bwd_pipe_blocks(R, S, 4, max_blocks);
+  if (workspace_bytes < (int64_t)C * blocks * REC_FLOATS * (int64_t)sizeof(float)) return CNR_E_ARG;
+  const int rc = cnr_field_bwd_pipe8_launch(pts, B, packed, biasrows, ray_row, scale, d_sigma, d_rgb, grad_scale, C, R, S,
+                                            rows_per_class, blocks, workspace, B_stride, rows_fix, clamp_flags, stream);
+  if (rc != CNR_OK) return rc;
+  if (skip_reduce) return CNR_OK;   // the caller reduces the records itself (cnr_step_tail / cnr_step_grad)
+  hipLaunchKernelGGL(reduce_records_kernel, dim3(REC_FLOATS / 64, (unsigned)C), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)workspace, blocks, dtrunk, dB, dbiasrows, rows_per_class,
+                     dtrunk_stride > 0 ? dtrunk_stride : (int64_t)TRUNK, dB_stride > 0 ? dB_stride : (int64_t)63);
+  CNR_LAUNCH_CHECK();
+  return CNR_OK;
 }
 
 // ---- the ONE-launch step body: a8-a15 forward, losses, and the whole backward (see TrainArgs) ------------------------

@@ -144,7 +144,7 @@ class FusedCategoryTrainer:
         # the latent backward: with AdamW and the epilogue when no gradient exchange follows (cnr_step_tail: single GPU,
         # class sharding), gradient only when rays are sharded (cnr_step_grad: the all-reduce comes between gradient and
         # optimiser)
-        self.use_records = n_obj <= (15 if ops.FIELD_BWD_VARIANT == "pipe4" else 4) and ops.FIELD_BWD_VARIANT.startswith("pipe")
+        self.use_records = n_obj <= 15 and ops.FIELD_BWD_VARIANT == "pipe4"
         self.grad_exchange = self.shard == "ray" and self.world > 1
         self.fused_tail = not self.grad_exchange and self.use_records
         fix_off = (n_th + n_db + 3) // 4 * 4                      # 16-byte aligned
@@ -215,7 +215,7 @@ class FusedCategoryTrainer:
         self._out_slot = None       # capture of a multi-step graph: which history slot the step being recorded writes
         self._last_multi = 0        # steps in the last launch that left their values in the history slots
         self.dbias = self._gbuf[n_th:n_th + n_db].view(n_cls * n_obj, 4, 32)
-        self._nwg = int(_C.load().cnr_field_bwd_pipe_blocks(self.R, self.S, int(ops.FIELD_BWD_VARIANT[-1]), self.bwd_blocks)) \
+        self._nwg = int(_C.load().cnr_field_bwd_pipe_blocks(self.R, self.S, 4, self.bwd_blocks)) \
             if self.use_records else 0
         # Precise geometry branch (default ON): the layers between the sample and the x10 occupancy logit as three f16
         # products per fragment, Wh xh + Wl xh + Wh xl (include/cnr_hip.h, cnr_pack_weights_lo).  Plain f16 operands hold

@@ -380,9 +380,10 @@ class DenseFn(Function):
         return (dx.reshape(ctx.xshape) if dx is not None else None), dW, db, None, None, None
 
 
-# cnr_field_bwd variants: "split" = two block-split launches (csrc/fused_bwd.hip), "pipe2"/"pipe3" = the single
-# pipelined launch with 2 / 3 chain waves + 2 / 1 weight-gradient waves per workgroup (csrc/fused_bwd_pipe.hip),
-# "pipe4" = 4 + 4 waves, two per SIMD (csrc/fused_bwd_pipe8.hip).  Same results contract.
+# cnr_field_bwd variants: "pipe4" = the pipelined launch, 4 chain + 4 weight-gradient waves per workgroup, two per SIMD
+# (csrc/fused_bwd_pipe8.hip; records, bitwise repeatable, up to 15 objects per class); "split" = two block-split launches
+# (csrc/fused_bwd.hip: the fallback for per-ray rows or more objects).  Same results contract.  (The 4-wave pipelines
+# "pipe2" / "pipe3" of rounds 1-2 are gone.)
 FIELD_BWD_VARIANT = os.environ.get("CNR_FIELD_BWD", "pipe4")
 
 
@@ -395,7 +396,7 @@ def field_bwd(pts, B, packed, biasrows, ray_row, scale, d_sig, d_rgb, grad_scale
         _C.call("cnr_field_bwd", pts, B, packed, biasrows, ray_row, scale, d_sig, d_rgb, grad_scale, dtrunk, dB,
                 dbiasrows, C, R, S, rows_per_class, max_blocks, workspace, workspace.numel(), int(B_stride),
                 int(dtrunk_stride), int(dB_stride))
-    elif v in ("pipe2", "pipe3", "pipe4"):
+    elif v == "pipe4":
         _C.call("cnr_field_bwd_pipe", pts, B, packed, biasrows, ray_row, scale, d_sig, d_rgb, grad_scale, dtrunk,
                 dB, dbiasrows, C, R, S, rows_per_class, max_blocks, int(v[-1]), workspace, workspace.numel(), int(B_stride),
                 int(dtrunk_stride), int(dB_stride), rows_fix, int(bool(skip_reduce)), clamp_flags)

@@ -478,15 +478,13 @@ int cnr_step_grad(const float* theta, float* grad, int64_t class_stride, int64_t
                   float* dbiasrows, float reg_scale, const void* records, int nwg, const long long* rows_fix,
                   const int* n_obj_cls, void* stream);
 
-/* Same contract and results as cnr_field_bwd, ONE field kernel + the record reduction: each workgroup is
- * `chain_waves` waves that run forward recompute + data-gradient chain + PE backward for one 32-sample tile each,
- * plus the waves that own the weight-gradient accumulators and consume the chain waves' per-layer images behind a
- * workgroup barrier.  chain_waves = 2 or 3: four waves per workgroup, 4 - chain_waves of them on the weight
- * gradients (csrc/fused_bwd_pipe.hip); chain_waves = 4: eight waves, 4 + 4, two per SIMD (csrc/fused_bwd_pipe8.hip,
- * the fastest form and the trainer's default).  max_blocks / workspace as above.
- * Class-major rows: up to 4 per class (chain_waves 2, 3) or 15 per class (chain_waves 4) stay on this path -- their
- * bias-row sums travel in the records (and in rows_fix); anything else (no ray_row, more rows) is handed to
- * cnr_field_bwd (rows_fix / skip_reduce must then be NULL / 0). */
+/* Same contract and results as cnr_field_bwd, ONE field kernel + the record reduction: a workgroup is four chain waves that
+ * run forward recompute + data-gradient chain + PE backward for one 32-sample tile each, plus four waves that own the
+ * weight-gradient accumulators and consume the chain waves' per-layer images behind a workgroup barrier -- eight waves, two
+ * per SIMD (csrc/fused_bwd_pipe8.hip).  chain_waves must be 4 (the 4-wave pipelines with 2 / 3 chain waves of rounds 1-2 are
+ * gone; the parameter stays in the signature).  max_blocks / workspace as above.
+ * Class-major rows, up to 15 per class, stay on this path -- their bias-row sums travel in the records (and in rows_fix);
+ * anything else (no ray_row, more rows) is handed to cnr_field_bwd (rows_fix / skip_reduce must then be NULL / 0). */
 /* rows_fix (optional): per-object bias-row sums also accumulated as 2^-40 fixed point into this (8, C, n_obj, 4, 32)
  * int64 table (8 copies, a workgroup uses copy index & 7, to shorten the same-address atomic queues; caller zeroes it); skip_reduce != 0: stop after the field kernel, the caller reduces the nwg =
  * cnr_field_bwd_pipe_blocks(R, S, chain_waves, max_blocks) records per class in `workspace` itself (cnr_step_tail). */

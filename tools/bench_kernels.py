@@ -37,7 +37,7 @@ def run(C, R, S, blocks, iters=50):
     n = C * R * S
     line = f"C{C} R{R} S{S} blocks{blocks}: fwd {fwd:8.1f} us ({n*27422/fwd/1e6:7.1f} TF)"
     ref = None
-    for variant in ("split", "pipe2", "pipe3", "pipe4"):
+    for variant in ("split", "pipe4"):
         dtrunk.zero_(); dB.zero_(); dbr.zero_()
         ops.field_bwd(pts, B, packed, brows, ray_row, 2.0, dsig, drgb, 2048.0, dtrunk, dB, dbr, C, R, S, n_obj, blocks,
                       wsp, variant=variant)
