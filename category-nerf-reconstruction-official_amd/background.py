@@ -215,11 +215,29 @@ class FullStepTrainer:
     """train.py:113-184 in one replay: the background step and the fused category step captured into ONE hipGraph per
     state parity of the category trainer (its parameters / step state ping-pong between two copies)."""
 
-    def __init__(self, categories, background):
+    def __init__(self, categories, background, concurrent=None):
+        """concurrent: capture the background step on a second stream (forked from / joined to the capturing stream), so that
+        the graph holds two independent chains -- the two branches share no parameter and no buffer.  Default: on."""
+        import os
         self.obj, self.bg = categories, background
         assert not self.obj.grad_exchange, "ray-sharded category steps run a collective between their two graphs"
         self.graphs = {}
         self.steps_done = 0
+        self.concurrent = bool(int(os.environ.get("CNR_FULLSTEP_CONCURRENT", "1"))) if concurrent is None else bool(concurrent)
+        self._side = torch.cuda.Stream(device=self.obj.device) if self.concurrent else None
+
+    def _both(self):
+        """background + categories, on one stream or forked onto two"""
+        if not self.concurrent:
+            self.bg._body()
+            self.obj._step_body()
+            return
+        cur = torch.cuda.current_stream()
+        self._side.wait_stream(cur)
+        with torch.cuda.stream(self._side):
+            self.bg._body()
+        self.obj._step_body()
+        cur.wait_stream(self._side)
 
     def step(self):
         o, b = self.obj, self.bg
@@ -227,14 +245,12 @@ class FullStepTrainer:
         b.pre_step()
         par = o.parity
         if self.steps_done < 3:
-            b._body()
-            o._step_body()
+            self._both()
         else:
             if par not in self.graphs:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
-                    b._body()
-                    o._step_body()
+                    self._both()
                 self.graphs[par] = g
             self.graphs[par].replay()
         o._post_step()
