@@ -117,6 +117,15 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
   constexpr int L8_BL = l8_bl(GEO), L8_BR = l8_br(GEO), L8_CHAIN = l8_chain(WIDE, GEO), C8_BYTES = c8_bytes(WIDE),
                 K8_SMALL_BYTES = k8_small(WIDE);
   constexpr bool BROWS_LDS = brows_in_lds8(WIDE, GEO);
+  // PEDW: the PE backward (66 cosines and ~300 multiply-adds per sample, pure VALU work on the critical chain wave) runs on the
+  // chain wave's dW partner -- the wave that shares its SIMD and idles through the forward phase.  d e2 / d e1 travel lane to
+  // lane as f16 through LDS that is free at that point (the E2 image after step VD, three slot images after step XYZ); the
+  // partner needs a barrier between its reads and the chain wave's next writes there, which the composite exchange of rays
+  // that span tiles (KR > 1) provides.  Measured bound (PE backward deleted): 40.4 -> 36.9 us at 2048 x 64, 259 -> 228 at 8192 x 128.
+#ifndef CNR_PEDW
+#define CNR_PEDW 1   // 0: tools/exp A/B arm (PE backward on the chain wave, as for KR <= 1)
+#endif
+  constexpr bool PEDW = CNR_PEDW && KR > 1;
   constexpr int SP = TWO ? 16 : (KR > 0 ? 32 * KR : 32);   // padded sample slots per ray (one-launch form)
   constexpr int NCHW = NCH, NTHR = (NCH + NDW) * 64, NACC = 5, LI_RS = local8<NDW>(BK_RS), LI_RS2 = local8<NDW>(BK_RS2);
   constexpr int RS_ROWS = WIDE == 2 ? cnr_rec::ROWS_MAX : WIDE == 1 ? 7 : 4;  // most object rows this instance takes
@@ -199,6 +208,30 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
   f16v Wacc[NACC];
 #pragma unroll
   for (int b = 0; b < NACC; ++b) Wacc[b] = zero16();
+  // PEDW: the PE backward from the f16 copies of d e1 / d e2 a chain wave left in LDS (dq[2 b + reg / 8][reg % 8] = de[b][reg],
+  // dq[6 ..] likewise for d e2), for the lane's own sample at (t0x, t1x, t2x); both roles run it (the dW partner for every tile
+  // but a workgroup's last, the chain wave itself for that one, while the dW waves write the record)
+  auto pe_backward_h = [&](const h8 (&dq)[9], float t0x, float t1x, float t2x, float (&dbacc)[33]) {
+    const float* Blh = reinterpret_cast<const float*>(smem + L8_BL) + 33 * h;
+    float pd[11], gpa[11];
+#pragma unroll
+    for (int d = 0; d < 11; ++d) {
+      pd[d] = Blh[3 * d] * t0x + Blh[3 * d + 1] * t1x + Blh[3 * d + 2] * t2x;
+      gpa[d] = 0.0f;
+    }
+#pragma unroll
+    for (int q = 0; q < 66; ++q) {   // q < 44: d e1 (bands 0..3), then d e2 (bands 4, 5); 11 directions of this lane half per band
+      const int band = q / 11, d = q % 11, k = q < 44 ? q : 48 + (q - 44);
+      const float cs = __builtin_amdgcn_cosf(pd[d] * (0.5f * (float)(1 << band)));
+      gpa[d] = fmaf((float)dq[k >> 3][k & 7] * cs, 3.14159265358979f * (float)(1 << band), gpa[d]);
+    }
+#pragma unroll
+    for (int d = 0; d < 11; ++d) {
+      dbacc[3 * d + 0] = fmaf(gpa[d], t0x, dbacc[3 * d + 0]);
+      dbacc[3 * d + 1] = fmaf(gpa[d], t1x, dbacc[3 * d + 1]);
+      dbacc[3 * d + 2] = fmaf(gpa[d], t2x, dbacc[3 * d + 2]);
+    }
+  };
 #define DBACC(i) c_dbacc[i]
 #define DWS(i) c_dws[i]
 #define DBS c_dbs
@@ -208,6 +241,7 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
     // chain role: one tile per iteration
     // ===================================================================================================
     float c_dbacc[33], c_dws[16], c_dbs = 0.0f;
+    if constexpr (PEDW) __builtin_amdgcn_s_setprio(1);   // above its dW partner's PE backward (priority 0), below the partner's layer steps (3)
 #pragma unroll
     for (int i = 0; i < 33; ++i) c_dbacc[i] = 0.0f;
 #pragma unroll
@@ -307,6 +341,7 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
     }
     float* xch = reinterpret_cast<float*>(smem + l8_xch(NCH, WIDE, GEO));   // [4][8]
     bool any_iter = false;
+    float l0x = 0.f, l1x = 0.f, l2x = 0.f;   // PEDW: the last tile's sample position (its PE backward runs here, behind the loop)
     for (int tile = blockIdx.x * NCHW + wv, t0 = blockIdx.x * NCHW; t0 < ntiles; t0 += tile_step, tile += tile_step) {
       asm volatile("" ::: "memory");
       P8STAMP_RESET();
@@ -314,6 +349,7 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
       // ---- this lane's sample (fetched during the previous iteration's shape_layer_2 step) -------------------
       if constexpr (KR > 0) render_inputs(cur, tile);
       const float t0x = cur.px * inv_scale, t1x = cur.py * inv_scale, t2x = cur.pz * inv_scale;
+      if constexpr (PEDW) { l0x = t0x; l1x = t1x; l2x = t2x; }
       const int row = cur.row;
       // upstream gradients: given (KR == 0) or formed after this tile's forward by the composite / loss block below
       float draw = 0.0f, dr0 = 0.0f, dr1 = 0.0f, dr2 = 0.0f;
@@ -702,11 +738,21 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
       acc = MFMA(Wn1, D1, acc);  // d a3
       Wn0 = lds_frag(bwf, KT_S2 + 0, lane); Wn1 = lds_frag(bwf, KT_S2 + 1, lane);
       de2[2] = de2[1];
-      pe_backward(de2, 2, 4, 22);  // bands 4 and 5 -> dB
+      h8 de2h[3];   // PEDW: d e2 as f16, parked until the E2 image is free (after A(ES))
+      if constexpr (PEDW) {
+        de2h[0] = pack8(de2[0], 0, false); de2h[1] = pack8(de2[0], 1, false); de2h[2] = pack8(de2[1], 0, false);
+      } else {
+        pe_backward(de2, 2, 4, 22);  // bands 4 and 5 -> dB
+      }
       // ---- step ES (no activation)
       stage_hs(Dimg0, D0, D1, col, h);
       stage_hs(Ximg0, A3a, A3b, col, h);
       P8SYNC();                   // A(ES)
+      if constexpr (PEDW) {   // the dW waves have read the E2 image (step VD): it now carries d e2 to the partner, lane to lane
+        unsigned char* eq = E2img + lane * 16;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) *reinterpret_cast<h8*>(eq + k * 1024) = de2h[k];
+      }
       D0 = pack8_and(acc, 0, Mn0); D1 = pack8_and(acc, 1, Mn1);
       Mn0 = relu_mask(A2a); Mn1 = relu_mask(A2b);
       acc = MFMA(Wn0, D0, zero16());
@@ -750,11 +796,34 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
       // ---- step XYZ : input e1 (its image)
       stage_hs(Dimg0, D0, D1, col, h);
       P8SYNC();                   // A(XYZ)
-      pe_backward(de, 3, 0, 44);        // d e1 -> dB, bands 0..3
+      if constexpr (PEDW) {
+        // d e1 -> this wave's dW partner, lane to lane, through the three slot images no step uses any more (Ximg0, Dimg1, Ximg1:
+        // 6 KB = six 16-byte pieces per lane; the dW waves read step XYZ from Dimg0 and the E1 image).  The partner picks them
+        // up behind the iteration's last barrier and has finished with them before the composite-exchange barrier of the next
+        // iteration, in front of which this wave writes none of the three.
+        unsigned char* xq = cw + K_X + lane * 16;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+          *reinterpret_cast<h8*>(xq + (2 * b) * 1024) = pack8(de[b], 0, false);
+          *reinterpret_cast<h8*>(xq + (2 * b + 1) * 1024) = pack8(de[b], 1, false);
+        }
+      } else {
+        pe_backward(de, 3, 0, 44);        // d e1 -> dB, bands 0..3
+      }
       cur = nxt;
       any_iter = true;   // the barrier "dW waves are done with this tile's images" follows at the next iteration's image
     }                    // writes (below the PE arithmetic, which so runs beside the dW waves' last step), or here:
     if (any_iter) role_barrier();
+    if constexpr (PEDW) {
+      if (any_iter) {   // the workgroup's last tile: its d e1 / d e2 are still where this wave put them
+        h8 dq[9];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) dq[k] = *reinterpret_cast<const h8*>(cw + K_X + lane * 16 + k * 1024);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dq[6 + k] = *reinterpret_cast<const h8*>(E2img + lane * 16 + k * 1024);
+        pe_backward_h(dq, l0x, l1x, l2x, c_dbacc);
+      }
+    }
     {  // publish this wave's partial sums (the last barrier has passed: the dW waves no longer read the row table
        // this aliases): [0..31] d w_sigma, [32] d b_sigma, [64..126] dB
       float* small = reinterpret_cast<float*>(cw + K_SMALL);
@@ -830,8 +899,30 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
     // The role branches on the dW wave's index ONCE, around the whole iteration loop: with the branch inside every layer step
     // the accumulator blocks met at a join after each step, and the compiler copied them between register ranges there (16
     // moves behind the step's last MFMA, in front of the barrier the chain waves wait at).
+    // PEDW: this wave runs the PE backward of chain wave dwid's tiles (same lane = same sample column and lane half)
+    float w_dbacc[33];
+#pragma unroll
+    for (int i = 0; i < 33; ++i) w_dbacc[i] = 0.0f;
     auto dw_loop = [&](auto dwi_c) {
     constexpr int DWI = decltype(dwi_c)::value;
+    const unsigned char* pcw = chain_base + DWI * K_BYTES;
+    // the partner tile's sample position (same index arithmetic as the chain's fetch).  Requested one iteration ahead, right
+    // behind the iteration's last barrier: every barrier's release fence waits for the wave's outstanding loads, so a request
+    // in front of a layer-step barrier puts its round trip on the workgroup's critical path (~0.3 us per iteration, measured)
+    auto pts_of = [&](int tile, float& q0, float& q1, float& q2) {
+      const int tl = tile < ntiles ? tile : ntiles - 1, n0 = tl * 32;
+      int64_t gs;
+      if constexpr (PAD) {
+        const int slot = n0 + col, ray_l = slot / SP, sidx = slot % SP;
+        gs = ((int64_t)c * R + (ray_l < R ? ray_l : R - 1)) * S + (sidx < S ? sidx : S - 1);
+      } else {
+        gs = (int64_t)c * N + n0 + col;
+      }
+      const float* pp = pts + gs * 3;
+      q0 = pp[0]; q1 = pp[1]; q2 = pp[2];
+    };
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+    if constexpr (PEDW) pts_of(blockIdx.x * NCHW + DWI, p0, p1, p2);
     for (int t0 = blockIdx.x * NCHW; t0 < ntiles; t0 += tile_step) {
       asm volatile("" ::: "memory");
       P8STAMP_RESET();
@@ -951,8 +1042,29 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
       STEP8(0, 4, BK_CAT_Y, BK_CAT_E0, BK_CAT_E1, BK_CAT_E2, 1)              // cat_layer
       STEP8(1, 1, BK_S1, BK_S1, BK_S1, BK_S1, 0)                             // shape_layer_1
       STEP8(0, 3, BK_XYZ_E0, BK_XYZ_E1, BK_XYZ_E2, BK_XYZ_E2, -1)            // encoding_xyz
+      h8 dq[PEDW ? 9 : 1];
+      if constexpr (PEDW) {   // d e2 (in the E2 image since step ES): picked up BEFORE the barrier behind which the partner writes the next tile's E2 features
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dq[6 + k] = *reinterpret_cast<const h8*>(pcw + K_E2 + lane * 16 + k * 1024);
+      }
       P8SYNC();   // done with this iteration's images (the chain waves wait for it before they write the next ones)
 #undef STEP8
+      if constexpr (PEDW) {
+        // d e1 (written by the partner between step XYZ's barrier and the one above).  The workgroup's last tile is left to the
+        // chain wave: behind the loop this wave has the record to write (~10 k cycles, the longer pole) and the chain wave nothing
+        if (t0 + tile_step < ntiles) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) dq[k] = *reinterpret_cast<const h8*>(pcw + K_X + lane * 16 + k * 1024);
+          // filler work: below the chain wave (priority 1) while it lasts, so that it takes only issue slots the partner's forward
+          // leaves empty (at the dW role's priority 3 it pushed the forward back: 40.4 -> 42.0 us at 2048 x 64)
+          __builtin_amdgcn_s_setprio(0);
+          float n0x = 0.f, n1x = 0.f, n2x = 0.f;
+          pts_of(t0 + tile_step + DWI, n0x, n1x, n2x);
+          pe_backward_h(dq, p0 * inv_scale, p1 * inv_scale, p2 * inv_scale, w_dbacc);
+          p0 = n0x; p1 = n1x; p2 = n2x;
+          __builtin_amdgcn_s_setprio(3);
+        }
+      }
     }
     };
     if (dwid == 0) dw_loop(IC<0>{});
@@ -1004,6 +1116,15 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
         }
       }
     }
+    if constexpr (PEDW) {   // dB partial sums of the partner's tiles -> the partner's E1 image (free: the loop is over), 63 floats
+      float* e1f = reinterpret_cast<float*>(chain_base + dwid * K_BYTES + K_E1);
+#pragma unroll
+      for (int i = 0; i < 33; ++i) {
+        const float v = half_sum_dpp(w_dbacc[i]);
+        const int d = i / 3;
+        if (col == 31 && !(h == 1 && d == 10)) e1f[(11 * h + d) * 3 + (i % 3)] = v;
+      }
+    }
   }
 
   // ========================================= flush ====================================================
@@ -1018,7 +1139,15 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
       for (int w = 0; w < NCHW; ++w) v += reinterpret_cast<const float*>(chain_base + w * K_BYTES + K_SMALL)[i];
       return v;
     };
-    for (int i = threadIdx.x; i < 63; i += NTHR) { rec[TRUNK + i] = sum_chain(64 + i) * inv_gs; rec[TRUNK + 63 + i] = 0.0f; }
+    auto sum_dw = [&](int i) {   // PEDW: the dW waves' shares of dB
+      float v = 0.0f;
+      if constexpr (PEDW) {
+#pragma unroll
+        for (int w = 0; w < NCHW; ++w) v += reinterpret_cast<const float*>(chain_base + w * K_BYTES + K_E1)[i];
+      }
+      return v;
+    };
+    for (int i = threadIdx.x; i < 63; i += NTHR) { rec[TRUNK + i] = (sum_chain(64 + i) + sum_dw(i)) * inv_gs; rec[TRUNK + 63 + i] = 0.0f; }
     for (int i = threadIdx.x; i < 32; i += NTHR) rec[OFF_SG_W + i] = sum_chain(i) * inv_gs;
     if (threadIdx.x == 0) rec[OFF_SG_B] = sum_chain(32) * inv_gs;
     if constexpr (KR > 0) {   // per-block loss partials + the class header, the format of cnr_field_fwd_render

@@ -460,8 +460,10 @@ def test_one_launch_step_equals_forward_render_plus_backward(cnr, dev, C, R, n1,
     assert rel_l2(a["var"], b["var"]) < 1e-5
     assert rel_l2(a["losses"], b["losses"]) < 5e-5 and torch.equal(a["flags"], b["flags"])   # (v_rcp / v_sqrt in the depth weight)
     # (the one-launch kernel forms its quotients with v_rcp_f32, 1 ulp: d sigma differs in the last bit, which the f16 pack of
-    #  the scaled gradients turns into an f16 ulp here and there)
-    assert rel_l2(a["grad"], b["grad"]) < (2e-2 if precise else 1e-4), rel_l2(a["grad"], b["grad"])
+    #  the scaled gradients turns into an f16 ulp here and there; rays that span tiles (S > 32): the one-launch kernel hands d e1 / d e2
+    #  to the PE backward as f16, like every other pre-activation gradient of the chain, the two-launch form keeps them fp32: 1.2e-4
+    #  on the whole gradient, all of it in dB)
+    assert rel_l2(a["grad"], b["grad"]) < (2e-2 if precise else 3e-4), rel_l2(a["grad"], b["grad"])
     assert rel_l2(a["theta"], b["theta"]) < (4e-3 if precise else 1e-3)     # first AdamW step: +-lr per entry, the sign of a ~0 gradient entry is noise
     for s in range(3):   # still the same training run two steps later (AdamW's sign-like first steps amplify rounding)
         assert torch.isfinite(res["one"][s]["grad"]).all()
