@@ -44,6 +44,7 @@ SIGNATURES = {
                       _i64, _vp],
     "cnr_field_bwd_pipe": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i64, _i64, _i64, _i64, _vp, _i, _vp, _vp],
     "cnr_field_bwd_workspace_bytes": [_i, _i],
+    "cnr_field_bwd_rows_table_bytes": [_i64],
     "cnr_field_bwd_pipe_blocks": [_i, _i, _i, _i],
     "cnr_gather_pool": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "cnr_dense_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
@@ -125,7 +126,7 @@ def struct_type(name):
     return _struct_types[name]
 
 
-_RESTYPE64 = {"cnr_pack_bytes", "cnr_pack_lo_bytes", "cnr_field_bwd_workspace_bytes", "cnr_render_loss_workspace_bytes",
+_RESTYPE64 = {"cnr_pack_bytes", "cnr_pack_lo_bytes", "cnr_field_bwd_workspace_bytes", "cnr_field_bwd_rows_table_bytes", "cnr_render_loss_workspace_bytes",
               "cnr_dense_bwd_workspace_bytes", "cnr_field_fwd_render_workspace_bytes", "cnr_field_train_workspace_bytes", "cnr_pack_fp8_bytes", "cnr_bg_pack_bytes"}
 
 _lib = None
@@ -252,8 +253,11 @@ def pack_bytes():
     return int(load().cnr_pack_bytes())
 
 
-def field_bwd_workspace_bytes(C, max_blocks):
-    return int(load().cnr_field_bwd_workspace_bytes(int(C), int(max_blocks)))
+def field_bwd_workspace_bytes(C, max_blocks, table_rows=0):
+    """records of the field backward + (table_rows > 0) the fixed-point table of per-row bias sums behind them: pass the total
+    rows of ``biasrows`` when they do not fit the kernels' LDS tables (no ray_row, or more than four rows per class)"""
+    lib = load()
+    return int(lib.cnr_field_bwd_workspace_bytes(int(C), int(max_blocks))) + int(lib.cnr_field_bwd_rows_table_bytes(int(table_rows)))
 
 
 def render_loss_workspace_bytes(C, R):

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(
     const float* __restrict__ pts, const float* __restrict__ Bdir, const unsigned char* __restrict__ packed,
     const float* __restrict__ biasrows, const int* __restrict__ ray_row, float inv_scale,
     const float* __restrict__ d_sigma, const float* __restrict__ d_rgb, float gscale,
-    float* __restrict__ records, float* __restrict__ dbiasrows,
+    float* __restrict__ records, long long* __restrict__ rows_tab,
     int64_t N, int S, int R, int rows_per_class, int64_t B_stride) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int c = blockIdx.y;
@@ -236,7 +236,10 @@ __global__ __launch_bounds__(256, 1) void field_bwd_kernel(
         if (grow < 0) continue;
         if (latent_slot < 0) plain[plain_idx * 32 + col] += rs[reg];
         else if (lds_rows) rowtab[(grow - c * rows_per_class) * 128 + latent_slot * 32 + col] += rs[reg];
-        else atomicAdd(&dbiasrows[(int64_t)grow * 128 + latent_slot * 32 + col], rs[reg] * inv_gs);
+        else   // rows that do not fit the LDS tables (one per ray, or more than ROWS_LDS per class): 2^-40 fixed point, integer
+               // atomics -- order-free, hence bitwise reproducible (a float atomicAdd here made this path repeatable to rounding only)
+          atomicAdd(reinterpret_cast<unsigned long long*>(rows_tab + (int64_t)grow * 128 + latent_slot * 32 + col),
+                    (unsigned long long)__double2ll_rn((double)(rs[reg] * inv_gs) * cnr_rec::ROWS_FIX_SCALE));
       }
     };
     // PE backward: p_d recomputed from LDS (cheaper than 11 registers held across the chain), dL/dp_d from
@@ -532,6 +535,17 @@ extern "C" int64_t cnr_field_bwd_workspace_bytes(int C, int max_blocks) {
   const int64_t cap = max_blocks > 0 ? max_blocks : 256;
   return (int64_t)C * cap * REC_FLOATS * (int64_t)sizeof(float);
 }
+// the fixed-point table of the per-row bias sums, behind the records, when the rows do not fit the kernels' LDS tables
+extern "C" int64_t cnr_field_bwd_rows_table_bytes(int64_t total_rows) {
+  return total_rows > 0 ? total_rows * 128 * (int64_t)sizeof(long long) : 0;
+}
+namespace {
+__global__ __launch_bounds__(256) void rows_table_to_float_kernel(const long long* __restrict__ tab, float* __restrict__ dbiasrows,
+                                                                  int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    dbiasrows[i] += (float)((double)tab[i] * (1.0 / cnr_rec::ROWS_FIX_SCALE));
+}
+}  // namespace
 
 extern "C" int cnr_field_bwd(const float* pts, const float* B, const void* packed, const float* biasrows,
                              const int* ray_row, float scale, const float* d_sigma, const float* d_rgb,
@@ -551,7 +565,18 @@ extern "C" int cnr_field_bwd(const float* pts, const float* B, const void* packe
   const int64_t cap = max_blocks > 0 ? max_blocks : 256;
   if (blocks > cap) blocks = cap;
   const int64_t need = (int64_t)C * blocks * REC_FLOATS * (int64_t)sizeof(float);
-  if (workspace_bytes < need) return CNR_E_ARG;
+  // rows beyond the LDS tables (one per ray, or more than ROWS_LDS per class) are summed in a 2^-40 fixed-point table behind
+  // the records (cnr_field_bwd_rows_table_bytes): cleared, filled with integer atomics, added to dbiasrows -- all on `stream`
+  const bool rows_lds = rows_per_class > 0 && rows_per_class <= ROWS_LDS;
+  const int64_t total_rows = rows_lds ? 0 : (ray_row ? (int64_t)C * rows_per_class : (int64_t)C * R);
+  const int64_t tab_bytes = cnr_field_bwd_rows_table_bytes(total_rows);
+  if (!rows_lds && ray_row && rows_per_class <= 0) return CNR_E_ARG;
+  if (workspace_bytes < need + tab_bytes) return CNR_E_ARG;
+  long long* rows_tab = tab_bytes ? reinterpret_cast<long long*>(reinterpret_cast<unsigned char*>(workspace) + need) : nullptr;
+  if (rows_tab) {
+    const hipError_t e = hipMemsetAsync(rows_tab, 0, (size_t)tab_bytes, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+  }
   {  // once per device: the LDS attribute of the four instantiations and the constant table (static device storage)
     static cnr::DeviceOnce once[4], table;
     const void* fns[4] = {(const void*)field_bwd_kernel<true, 0>, (const void*)field_bwd_kernel<true, 1>,
@@ -569,7 +594,7 @@ extern "C" int cnr_field_bwd(const float* pts, const float* B, const void* packe
 #define CNR_LAUNCH_BWD(BIG, PART)                                                                               \
   hipLaunchKernelGGL((field_bwd_kernel<BIG, PART>), grid, dim3(256), LDS_TOTAL, (hipStream_t)stream, pts, B,    \
                      (const unsigned char*)packed, biasrows, ray_row, 1.0f / scale, d_sigma, d_rgb, grad_scale, \
-                     (float*)workspace, dbiasrows, N, S, R, rows_per_class, B_stride > 0 ? B_stride : (int64_t)63)
+                     (float*)workspace, rows_tab, N, S, R, rows_per_class, B_stride > 0 ? B_stride : (int64_t)63)
   if (S >= 32) { CNR_LAUNCH_BWD(true, 1); CNR_LAUNCH_BWD(true, 0); }
   else { CNR_LAUNCH_BWD(false, 1); CNR_LAUNCH_BWD(false, 0); }
 #undef CNR_LAUNCH_BWD
@@ -581,5 +606,11 @@ extern "C" int cnr_field_bwd(const float* pts, const float* B, const void* packe
                      (rows_per_class >= 1 && rows_per_class <= ROWS_LDS) ? rows_per_class : 0,
                      dtrunk_stride > 0 ? dtrunk_stride : (int64_t)TRUNK, dB_stride > 0 ? dB_stride : (int64_t)63);
   CNR_LAUNCH_CHECK();
+  if (rows_tab) {
+    const int64_t n = total_rows * 128;
+    hipLaunchKernelGGL(rows_table_to_float_kernel, dim3((unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const long long*)rows_tab, dbiasrows, n);
+    CNR_LAUNCH_CHECK();
+  }
   return CNR_OK;
 }

@@ -287,7 +287,7 @@ class FusedCategoryTrainer:
                                          int(_C.load().cnr_field_fwd_render_workspace_bytes(C, R, S)),
                                          int(_C.load().cnr_field_train_workspace_bytes(C, R, S, self.bwd_blocks))),
                                      device=self.device, dtype=torch.uint8)
-            o["bwd_ws"] = torch.empty(_C.field_bwd_workspace_bytes(C, self.bwd_blocks), device=self.device,
+            o["bwd_ws"] = torch.empty(_C.field_bwd_workspace_bytes(C, self.bwd_blocks, C * n_obj), device=self.device,
                                       dtype=torch.uint8)
         zl, brows, packed = o["zl"], o["brows"], o["packed"]
         lat_args = (lay.total, lay.latW[0], lay.latb[0], lay.shape[0], lay.tex[0], L, n_obj, C)

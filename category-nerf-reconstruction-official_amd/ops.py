@@ -462,7 +462,7 @@ class FusedFieldFn(Function):
         dtrunk = torch.zeros(ctx.trunk_shape, device=pts.device, dtype=torch.float32)
         dB = torch.zeros_like(B, memory_format=torch.contiguous_format)
         dbr = torch.zeros_like(biasrows, memory_format=torch.contiguous_format)
-        wsb = _C.field_bwd_workspace_bytes(C, ctx.mb)
+        wsb = _C.field_bwd_workspace_bytes(C, ctx.mb, biasrows.shape[0])   # (+ the fixed-point row table: used when rows are per ray / > 4 per class)
         wsp = torch.empty(wsb, device=pts.device, dtype=torch.uint8)
         field_bwd(pts.contiguous(), B.contiguous(), packed, biasrows.contiguous(), ctx.ray_row,
                   ctx.scale, d_sig.contiguous(), d_rgb.contiguous(), ctx.gs, dtrunk, dB, dbr, C, R, S, ctx.rpc, ctx.mb,

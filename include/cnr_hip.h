@@ -207,12 +207,16 @@ int cnr_field_fwd(const float* pts, const float* B, const void* packed, const fl
  * rows_per_class: rows of biasrows per class when rows are laid out class-major and ray_row != NULL
  * (<= 4 enables the in-LDS row accumulation); pass R when ray_row == NULL.  S <= 240.
  * max_blocks: workgroups per class (0 = 256).
- * workspace: caller-allocated, 16-B aligned, >= cnr_field_bwd_workspace_bytes(C, max_blocks) bytes, contents
- * irrelevant: every workgroup stores one record of partial sums into it with plain stores and a last small
- * kernel sums the records in a fixed order -- no float atomics on shared addresses, the gradient is bitwise
- * reproducible (the per-ray dbiasrows path, rows_per_class > 4, still uses atomics).
- * Three kernel launches on `stream`; capturable into a hipGraph. */
+ * workspace: caller-allocated, 16-B aligned, contents irrelevant, >= cnr_field_bwd_workspace_bytes(C, max_blocks)
+ * bytes -- every workgroup stores one record of partial sums into it with plain stores and a last small kernel sums
+ * the records in a fixed order -- PLUS cnr_field_bwd_rows_table_bytes(total rows of biasrows) bytes when the rows do
+ * not fit the kernels' LDS tables (ray_row == NULL, or rows_per_class > 4): their sums go through a 2^-40 fixed-point
+ * table behind the records (cleared on `stream`, integer atomics, added to dbiasrows by a last small kernel).  No
+ * float atomic on a shared address anywhere: the gradient is bitwise reproducible for every row layout (round 3;
+ * the per-ray / many-object path used float atomics before).  A workspace without room for the table: CNR_E_ARG.
+ * Three to five launches on `stream`; capturable into a hipGraph. */
 int64_t cnr_field_bwd_workspace_bytes(int C, int max_blocks);
+int64_t cnr_field_bwd_rows_table_bytes(int64_t total_rows);
 int cnr_field_bwd(const float* pts, const float* B, const void* packed, const float* biasrows,
                   const int* ray_row, float scale, const float* d_sigma, const float* d_rgb,
                   float grad_scale, float* dtrunk, float* dB, float* dbiasrows, int C, int R, int S,

@@ -371,7 +371,7 @@ def test_field_bwd_full_size_all_variants_agree_and_repeat(cnr, dev, C, R, S, n_
     ray_row = (torch.randint(0, n_obj, (C, R), device=dev) + torch.arange(C, device=dev)[:, None] * n_obj).to(torch.int32)
     dsig = torch.randn(C, R, S, device=dev) * 1e-3
     drgb = torch.randn(C, R, S, 3, device=dev) * 1e-3
-    wsp = torch.empty(_C.field_bwd_workspace_bytes(C, 0), device=dev, dtype=torch.uint8)
+    wsp = torch.empty(_C.field_bwd_workspace_bytes(C, 0, C * n_obj), device=dev, dtype=torch.uint8)
 
     def run(variant):
         dtrunk = torch.zeros(C, 13892, device=dev); dB = torch.zeros(C, 21, 3, device=dev); dbr = torch.zeros_like(brows)
@@ -405,7 +405,7 @@ def test_field_bwd_pipe_refuses_more_than_240_samples(cnr, dev):
     packed = ops.pack_weights(v["trunk"].contiguous())
     z = lambda *s: torch.zeros(*s, device=dev)
     brows, ray_row = z(C * n_obj, 4, 32), torch.zeros(C, R, device=dev, dtype=torch.int32)
-    wsp = torch.empty(_C.field_bwd_workspace_bytes(C, 0), device=dev, dtype=torch.uint8)
+    wsp = torch.empty(_C.field_bwd_workspace_bytes(C, 0, C * n_obj), device=dev, dtype=torch.uint8)
     for variant in ("pipe4",):
         with pytest.raises(_C.CnrError):
             ops.field_bwd(z(C, R, S, 3), v["B"].contiguous(), packed, brows, ray_row, 2.0, z(C, R, S), z(C, R, S, 3), 1.0,
@@ -428,7 +428,7 @@ def test_field_bwd_is_linear_in_the_upstream_gradients(cnr, dev, C, R, S):
     pts = torch.rand(C, R, S, 3, device=dev) * 2 - 1
     brows = torch.randn(C * n_obj, 4, 32, device=dev) * 0.1
     ray_row = (torch.randint(0, n_obj, (C, R), device=dev) + torch.arange(C, device=dev)[:, None] * n_obj).to(torch.int32)
-    wsp = torch.empty(_C.field_bwd_workspace_bytes(C, 0), device=dev, dtype=torch.uint8)
+    wsp = torch.empty(_C.field_bwd_workspace_bytes(C, 0, C * n_obj), device=dev, dtype=torch.uint8)
 
     def run(dsig, drgb):
         dtrunk = torch.zeros(C, 13892, device=dev); dB = torch.zeros(C, 21, 3, device=dev); dbr = torch.zeros_like(brows)
@@ -457,7 +457,7 @@ def test_loss_scale_clamp_is_reported(cnr, dev):
     pts = torch.rand(C, R, S, 3, device=dev) * 2 - 1
     brows = torch.randn(C * n_obj, 4, 32, device=dev) * 0.1
     ray_row = (torch.randint(0, n_obj, (C, R), device=dev) + torch.arange(C, device=dev)[:, None] * n_obj).to(torch.int32)
-    wsp = torch.empty(_C.field_bwd_workspace_bytes(C, 0), device=dev, dtype=torch.uint8)
+    wsp = torch.empty(_C.field_bwd_workspace_bytes(C, 0, C * n_obj), device=dev, dtype=torch.uint8)
     z = lambda *s_: torch.zeros(*s_, device=dev)
     for big_class in (None, 1):
         dsig = torch.randn(C, R, S, device=dev) * 1e-3
@@ -469,3 +469,46 @@ def test_loss_scale_clamp_is_reported(cnr, dev):
         torch.cuda.synchronize()
         want = [0, 0] if big_class is None else [0, 16]
         assert clamp.tolist() == want, clamp.tolist()
+
+
+@pytest.mark.gpu
+def test_backward_many_objects_is_bitwise_repeatable(cnr, dev):
+    """More than 15 objects per class (or one bias row per ray) take the block-split kernels, whose per-row bias sums do not fit an
+    LDS table.  They go through a 2^-40 fixed-point table with integer atomics (round 3; float atomics before: repeatable to
+    rounding only): two runs agree bit for bit, and the per-object sums equal the per-ray sums added up per object."""
+    ops, _C = cnr.ops, cnr._C
+    C, R, S, n_obj, L = 2, 1024, 32, 20, 32
+    theta, lay = cnr.fused.init_params(C, L, n_obj, torch.Generator().manual_seed(5), dev)
+    v = lay.views(theta)
+    packed = ops.pack_weights(v["trunk"].contiguous())
+    B = v["B"].contiguous()
+    g = torch.Generator(device=dev).manual_seed(11)
+    pts = torch.rand(C, R, S, 3, device=dev, generator=g) * 2 - 1
+    brows = torch.randn(C * n_obj, 4, 32, device=dev, generator=g) * 0.1
+    obj = torch.randint(0, n_obj, (C, R), device=dev, generator=g)
+    ray_row = (obj + torch.arange(C, device=dev)[:, None] * n_obj).to(torch.int32)
+    dsig = torch.randn(C, R, S, device=dev, generator=g) * 1e-3
+    drgb = torch.randn(C, R, S, 3, device=dev, generator=g) * 1e-3
+
+    def run(rows, rr, n_rows):
+        wsp = torch.empty(_C.field_bwd_workspace_bytes(C, 0, rows.shape[0]), device=dev, dtype=torch.uint8)
+        dtrunk = torch.zeros(C, 13892, device=dev); dB = torch.zeros(C, 21, 3, device=dev); dbr = torch.zeros_like(rows)
+        ops.field_bwd(pts, B, packed, rows, rr, 2.0, dsig, drgb, 2048.0, dtrunk, dB, dbr, C, R, S, n_rows, 0, wsp)
+        torch.cuda.synchronize()
+        return dtrunk, dB, dbr
+
+    a, b = run(brows, ray_row, n_obj), run(brows, ray_row, n_obj)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert a[2].abs().sum() > 0
+    # one row per ray with the same values: same trunk gradient, and its row sums add up to the per-object ones
+    per_ray = brows[ray_row.long().flatten()].contiguous()
+    c = run(per_ray, None, R)
+    assert rel_l2(c[0], a[0]) < 1e-6 and rel_l2(c[1], a[1]) < 1e-6
+    agg = torch.zeros_like(brows).index_add_(0, ray_row.long().flatten(), c[2])
+    assert rel_l2(agg, a[2]) < 1e-5, rel_l2(agg, a[2])
+    # a workspace without room for the table is refused, not overrun
+    small = torch.empty(_C.field_bwd_workspace_bytes(C, 0), device=dev, dtype=torch.uint8)
+    with pytest.raises(_C.CnrError):
+        ops.field_bwd(pts, B, packed, brows, ray_row, 2.0, dsig, drgb, 2048.0, torch.zeros(C, 13892, device=dev),
+                      torch.zeros(C, 21, 3, device=dev), torch.zeros_like(brows), C, R, S, n_obj, 0, small)

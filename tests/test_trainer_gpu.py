@@ -353,6 +353,30 @@ def test_many_epochs_graph_equals_eager(cnr, dev, n_obj):
     assert torch.equal(res["graph"][0], res["eager"][0]) and torch.equal(res["graph"][1], res["eager"][1])
 
 
+def test_twenty_objects_per_class_train_bitwise_repeatably(cnr, dev):
+    """More than fifteen objects per class leave the record path (the 8-wave kernel's row-sum blocks hold fifteen rows): the
+    trainer takes the block-split backward + separate latent / AdamW launches.  Since round 3 that path has no float atomic
+    either (fixed-point row table): graph replay and eager stepping end bit for bit in the same place, and the loss falls."""
+    res = {}
+    for name, graph in (("eager", False), ("graph", True)):
+        torch.manual_seed(78)
+        cfg = cnr.cfg.synthetic_config(device=str(dev), latent_dim=32, n_bins_cam2surface=4, n_bins=28)
+        gen = torch.Generator().manual_seed(5)
+        pools = [cnr.scene_cateogries.synthetic_pool(8 * 256, 20, gen, "cpu") for _ in range(2)]
+        tr = cnr.fused.FusedCategoryTrainer(cfg, 2, 20, pools, 256, dev, seed=2, generator=gen, use_graph=graph)
+        assert not tr.use_records and not tr.fused_tail
+        hist = []
+        for _ in range(24):
+            tr.step()
+            hist.append(tr.losses.clone())
+        torch.cuda.synchronize()
+        res[name] = (torch.stack(hist), tr.theta.clone())
+    assert torch.isfinite(res["graph"][0]).all()
+    assert torch.equal(res["graph"][0], res["eager"][0]) and torch.equal(res["graph"][1], res["eager"][1])
+    h = res["graph"][0]
+    assert float(h[-4:].sum()) < float(h[:4].sum())
+
+
 def test_code_tables_are_their_own_adamw_group(cnr, dev):
     """The reference gives the code tables their own AdamW group (code_lr / code_weight_decay, train.py:40,54-64).  With
     different values for the two groups the networks' parameters after a step are bitwise what a run with equal values gives,

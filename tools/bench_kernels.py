@@ -22,7 +22,7 @@ def run(C, R, S, blocks, iters=50):
     dsig = torch.randn(C, R, S, device=dev) * 1e-3
     drgb = torch.randn(C, R, S, 3, device=dev) * 1e-3
     dtrunk = torch.zeros(C, 13892, device=dev); dB = torch.zeros(C, 21, 3, device=dev); dbr = torch.zeros_like(brows)
-    wsp = torch.empty(_C.field_bwd_workspace_bytes(C, 0), device=dev, dtype=torch.uint8)
+    wsp = torch.empty(_C.field_bwd_workspace_bytes(C, 0, C * n_obj), device=dev, dtype=torch.uint8)
     sig = torch.empty(C, R, S, device=dev); rgb = torch.empty(C, R, S, 3, device=dev)
 
     def t(fn):

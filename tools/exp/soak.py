@@ -28,7 +28,7 @@ pts = torch.rand(C, R, S, 3, device=dev) * 2 - 1
 brows = torch.randn(C * n_obj, 4, 32, device=dev) * 0.1
 ray_row = (torch.randint(0, n_obj, (C, R), device=dev)).to(torch.int32)
 dsig, drgb = torch.randn(C, R, S, device=dev) * 1e-3, torch.randn(C, R, S, 3, device=dev) * 1e-3
-wsp = torch.empty(_C.field_bwd_workspace_bytes(C, 0), device=dev, dtype=torch.uint8)
+wsp = torch.empty(_C.field_bwd_workspace_bytes(C, 0, C * n_obj), device=dev, dtype=torch.uint8)
 def run():
     dtrunk = torch.zeros(C, 13892, device=dev); dB = torch.zeros(C, 21, 3, device=dev); dbr = torch.zeros_like(brows)
     ops.field_bwd(pts, B, packed, brows, ray_row, 2.0, dsig, drgb, 2048.0, dtrunk, dB, dbr, C, R, S, n_obj, 0, wsp)
