@@ -378,7 +378,8 @@ def main():
     tr.run(max(args.warmup, 4))
     tr.prepare_graphs()         # every graph the timed region can need exists before it starts (captures are host work)
     for _ in range(2):          # ... and has been launched once, from either state parity (the first launch of a graph uploads it)
-        tr.run(tr.unroll)
+        for u in tr._group_sizes(tr.unroll):     # 16, 8, 4, 2: what run() sends out at an epoch's end
+            tr.run(u)
         tr.run(1)
     dbg("warmup issued")
     dt = timed(args.steps)                      # EXACTLY --steps steps between barriers + synchronize, max over ranks
@@ -457,7 +458,7 @@ def main():
                       "operand_dtype": "f16 MFMA operands, fp32 accumulate, where BASELINE.json configs[1] says bf16: bf16 operands "
                                        "miss north_star's 1e-3 parity bar (3.9e-3 / 5.1e-3, BASELINE.md section 4), f16 has the "
                                        "same MFMA rate on gfx950 and three more mantissa bits",
-                      "hipgraph": (f"{tr.unroll} steps per graph launch (one step per launch at epoch ends)" if not tr.grad_exchange else "two graphs around the all-reduce, per state parity") if not args.no_graph else False,
+                      "hipgraph": (f"{tr.unroll} steps per graph launch (halving group sizes down to single steps at epoch ends)" if not tr.grad_exchange else "two graphs around the all-reduce, per state parity") if not args.no_graph else False,
                       "n_cu": info["n_cu"]},
            "long_run": long_run, "roofline": roofline}
     if world > 1 and shard == "ray":   # outside the timed region: every rank must hold bitwise identical parameters after the run

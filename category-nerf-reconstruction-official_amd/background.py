@@ -157,8 +157,8 @@ class BackgroundStep:
         self._loss = v
 
     def _body_fused(self):
-        """sample -> pack -> forward -> composite + losses + their gradient -> backward -> weight gradients -> reduce + AdamW +
-        advance: eight launches, nothing under autograd (train.py:113-121,172-184 for the background)."""
+        """sample -> forward -> composite + losses + their gradient -> backward -> weight gradients -> reduce + AdamW + fragment
+        refresh + loss values: six launches, nothing under autograd (train.py:113-121,172-184 for the background)."""
         cfg, o = self.cfg, self.fb
         b = ops.sample_rays(self.pool["rgbs"], self.pool["depth"], self.pool["dirs"], self.pool["T"], self.n1, self.n2,
                             cfg.surface_eps, cfg.stop_eps, min_bound=cfg.min_depth, world_frame=True, seed=self.seed,

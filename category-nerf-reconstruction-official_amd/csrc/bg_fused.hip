@@ -1,19 +1,20 @@
 // Fused f16-MFMA train step of the BACKGROUND field: vMAP-style OccupancyMap(hidden 128), src/model.py:86-155, trained every
 // iteration on 1200 world-frame rays x 14 samples (train.py:113-121,172-180).  Round 2 ran its seven Linear layers one launch
 // each under torch autograd (14 x 20.8 us + 7 x 26.6 us + ~40 glue kernels = 0.69 ms); here the step is
-//   cnr_bg_pack      fp32 parameters -> f16 MFMA fragment images (forward hi / geometry-branch residual / transposed)
-//   cnr_bg_forward   per 64-sample tile: PE -> in_layer -> mid1 -> cat_layer -> mid2 -> {out_alpha | color_linear -> out_color}
+//   cnr_bg_pack      fp32 parameters -> f16 MFMA fragment images (forward hi / geometry-branch residual / transposed); once, and
+//                    after outside changes of the parameters: inside the loop the tail launch keeps the images current
+//   cnr_bg_forward   per 32-sample tile: PE -> in_layer -> mid1 -> cat_layer -> mid2 -> {out_alpha | color_linear -> out_color}
 //                    with every activation in LDS; writes sigma, rgb and the f16 activations the backward needs
-//   (cnr_render_loss / cnr_render_loss_finish: composite, losses, d sigma, d colour -- the category path's kernels)
+//   (cnr_render_loss: composite, losses, d sigma, d colour -- the category path's kernel)
 //   cnr_bg_backward  per tile: the data-gradient chain, masks from the stored activations, PE backward; writes the f16
 //                    pre-activation gradients, and the small gradients (out_color, out_alpha, B) as per-workgroup records
 //   cnr_bg_dw        weight / bias gradients of the five 128-wide layers: dW = dPre^T X over all samples, split over sample
 //                    chunks (partials, fixed-order sum)
-//   cnr_bg_tail      partial + record reduction, AdamW in place, step state advance
-// Layout: a workgroup = 4 waves owns a tile of 64 samples; every layer is computed transposed, D = W X^T
-// (v_mfma_f32_32x32x16_f16): wave w owns output features [32 w, 32 w + 32) for both 32-sample halves of the tile; the A
-// operand (weights) comes pre-packed from global / L2 straight into registers, the B operand (activations) from a
-// [sample][feature] f16 image in LDS (16-byte reads, padded rows), the accumulators go back to such an image.
+//   cnr_bg_tail      partial + record reduction, AdamW in place, fragment refresh, loss values, step state advance
+// Layout: a workgroup = 4 waves owns a tile of TS = 32 samples; every layer is computed transposed, D = W X^T
+// (v_mfma_f32_32x32x16_f16): wave w owns output features [32 w, 32 w + 32) of the tile; the A operand (weights) comes
+// pre-packed from global / L2 straight into registers, the B operand (activations) from a [sample][feature] f16 image in LDS
+// (16-byte reads, padded rows), the accumulators go back to such an image.
 // Precision: the geometry branch (in_layer, mid1, cat_layer, mid2 -> out_alpha) as three f16 products per fragment,
 // Wh xh + Wl xh + Wh xl (residual weights and residual activation images), the x10 occupancy head as an fp32 dot product
 // of the fp32 accumulators -- the same reasoning as the category kernel (include/cnr_hip.h, cnr_pack_weights_lo); the

@@ -424,14 +424,22 @@ class FusedCategoryTrainer:
         and is not used around a gradient all-reduce; those steps go out one by one.  ``self.losses`` / ``self.flags``
         hold the LAST step's values, ``loss_history()`` the values of every step of the last launch; ``check_flags``
         looks at all of them."""
-        U = self.unroll if unroll is None else max(2, int(unroll) // 2 * 2)
-        U = min(U, self.unroll)
+        U0 = self.unroll if unroll is None else max(2, int(unroll) // 2 * 2)
+        U0 = min(U0, self.unroll)
         multi_ok = self.use_graph and not (self.grad_exchange or self.split_graph)
         while n > 0:
             if self.cursor >= self.pool_rows - self.Rg:
                 self._reshuffle()
             left = -(-(self.pool_rows - self.Rg - self.cursor) // self.Rg)     # steps before the next reshuffle
-            if not (multi_ok and self.steps_done >= 2 and n >= U and left >= U):
+            # the largest group of the ladder U0, U0 / 2, .., 2 that fits what is left of the request and of the epoch: an epoch
+            # of 63 steps goes out as 16 + 16 + 16 + 8 + 4 + 2 + 1 = 7 launches, not 3 + 15 (each launch boundary idles the GPU ~8 us)
+            U = 0
+            if multi_ok and self.steps_done >= 2:
+                for u in self._group_sizes(U0):
+                    if u <= n and u <= left:
+                        U = u
+                        break
+            if not U:
                 self.step()
                 n -= 1
                 continue
@@ -446,6 +454,15 @@ class FusedCategoryTrainer:
             n -= U
             if self.check_every and self.steps_done // self.check_every != before // self.check_every:
                 self.check_flags()
+
+    @staticmethod
+    def _group_sizes(U0):
+        """even group sizes of the multi-step graphs, largest first: U0, then halves rounded down to even, down to 2"""
+        out, u = [], int(U0)
+        while u >= 2:
+            out.append(u)
+            u = (u // 2) // 2 * 2 if u > 2 else 0
+        return out
 
     def _capture_multi(self, par, U):
         """Record (not run) U steps starting at state parity ``par`` as one graph."""
@@ -476,8 +493,9 @@ class FusedCategoryTrainer:
                     self._step_body()
                 self.graphs[par] = g
             self.parity = par0
-            if (par, U) not in self.graphs:
-                self._capture_multi(par, U)
+            for u in self._group_sizes(U):
+                if (par, u) not in self.graphs:
+                    self._capture_multi(par, u)
         self.parity = par0
 
     def loss_history(self):
