@@ -239,6 +239,51 @@ class FullStepTrainer:
         self.obj._step_body()
         cur.wait_stream(self._side)
 
+    def run(self, n, unroll=8):
+        """``n`` iterations, the same arithmetic as ``n`` calls of ``step()`` (bitwise: tests/test_bg_fused_gpu.py), with groups of up
+        to ``unroll`` iterations captured as ONE hipGraph -- both branches keep cursor, RNG step and optimiser step on the device, so
+        a group replays unchanged; it never crosses an epoch end of either pool (the reshuffles are host-launched).  Between two
+        graph launches the GPU idles ~8 us: 5 % of a 0.15 ms iteration."""
+        o, b = self.obj, self.bg
+        while n > 0:
+            o._pre_step()
+            b.pre_step()
+            left = min(-(-(o.pool_rows - o.Rg - o.cursor) // o.Rg), -(-(b.pool_rows - b.R - b.cursor) // b.R))
+            U = 0
+            if self.steps_done >= 3 and o.use_graph:
+                for u in o._group_sizes(min(int(unroll), o.unroll)):
+                    if u <= n and u <= left:
+                        U = u
+                        break
+            if not U:
+                self.step()
+                n -= 1
+                continue
+            key = (o.parity, U)
+            if key not in self.graphs:
+                par0 = o.parity
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    for i in range(U):
+                        o._out_slot = i if i < U - 1 else None
+                        self._both()
+                        o.parity ^= 1
+                o._out_slot, o.parity = None, par0
+                self.graphs[key] = g
+            self.graphs[key].replay()
+            before = o.steps_done
+            o._last_multi = U - 1
+            o.cursor += U * o.Rg
+            o.steps_done += U                     # (U is even: the state parity is where it was)
+            b.cursor += U * b.R
+            b.steps_done += U
+            if b.precision == "fused":
+                b._packed_for = b.flat._version
+            self.steps_done += U
+            n -= U
+            if o.check_every and o.steps_done // o.check_every != before // o.check_every:
+                o.check_flags()
+
     def step(self):
         o, b = self.obj, self.bg
         o._pre_step()

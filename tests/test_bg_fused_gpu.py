@@ -149,3 +149,77 @@ def test_fused_background_trainer_tracks_the_fp32_tier(dev):
     print("fused vs fp32 background trainer after 12 steps: cosine of the parameter displacement", round(cos, 4),
           "rel", round(rel_l2(a.flat, b.flat), 5))
     assert cos > 0.9 and rel_l2(a.flat, b.flat) < 5e-3
+
+
+def test_whole_iteration_run_in_multi_iteration_graphs_equals_single_steps(dev):
+    """FullStepTrainer.run(n): groups of up to eight iterations (background + categories, two forked branches each) as ONE
+    hipGraph, across epoch ends of BOTH pools (which differ in length) -- against step() called n times: bit for bit."""
+    import cnr_amd as cnr
+
+    def make():
+        torch.manual_seed(31)          # epoch permutations of the category trainer come from the default generator
+        cfg = cnr.cfg.synthetic_config(device=str(dev), latent_dim=32, n_bins_cam2surface=4, n_bins=28)
+        gen = torch.Generator().manual_seed(21)
+        pools = [cnr.scene_cateogries.synthetic_pool(11 * 256, 4, gen, "cpu") for _ in range(2)]
+        tr = cnr.fused.FusedCategoryTrainer(cfg, 2, 4, pools, 256, dev, seed=1, generator=gen)
+        cfg_bg = cnr.cfg.synthetic_config(device=str(dev), latent_dim=32, n_bins_cam2surface=4, n_bins=9)
+        cfg_bg.hidden_feature_size_bg, cfg_bg.n_bins_cam2surface_bg = 128, 5
+        bg = cnr.background.BackgroundStep(cfg_bg, cnr.scene_cateogries.synthetic_pool(7 * 300, 1, torch.Generator().manual_seed(12), "cpu"),
+                                           300, dev, seed=5, precision="fused")
+        return cnr.background.FullStepTrainer(tr, bg)
+    a, b = make(), make()
+    n = 37
+    a.run(n)
+    for _ in range(n):
+        b.step()
+    torch.cuda.synchronize()
+    assert any(isinstance(k, tuple) and k[1] >= 4 for k in a.graphs), list(a.graphs)      # multi-iteration graphs were used
+    assert a.obj.steps_done == b.obj.steps_done == n and a.bg.steps_done == b.bg.steps_done == n
+    assert a.obj.cursor == b.obj.cursor and a.bg.cursor == b.bg.cursor
+    assert torch.equal(a.obj.theta, b.obj.theta) and torch.equal(a.obj.losses, b.obj.losses)
+    assert torch.equal(a.bg.flat, b.bg.flat) and torch.equal(a.bg.losses, b.bg.losses)
+    assert torch.equal(a.bg.d_state, b.bg.d_state)
+
+
+def test_fused_background_forward_on_trained_weights(dev):
+    """The fused background forward against the fp32 oracle ON TRAINED WEIGHTS (the category kernel's occupancy left the 1e-3
+    bar after training with plain f16 operands, tests/test_trained_parity_gpu.py; the background kernel has the three-product
+    geometry branch from the start): 1500 steps of the fused trainer on a learnable pool, then the kernel's per-sample
+    occupancy / colour and the four renders against oracle.ref_cpu on the same weights and the same samples."""
+    import cnr_amd as cnr
+    from oracle import ref_cpu as O
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    cfg = cnr.cfg.synthetic_config(device=str(dev), latent_dim=32, n_bins_cam2surface=4, n_bins=9)
+    cfg.hidden_feature_size_bg, cfg.n_bins_cam2surface_bg = 128, 5
+    pool = cnr.scene_cateogries.synthetic_pool(16 * 1200, 1, torch.Generator().manual_seed(12), "cpu")
+    bg = cnr.background.BackgroundStep(cfg, pool, 1200, dev, seed=5, precision="fused")
+    first = None
+    for it in range(1500):
+        bg.step()
+        if it == 3:
+            first = bg.losses.clone()
+    torch.cuda.synchronize()
+    last = bg.losses.clone()
+    assert torch.isfinite(bg.flat).all() and float(last[1]) < float(first[1])          # the colour term fell
+    # one more forward of the kernels on the CURRENT weights, through the product's own step (its outputs stay in the buffers)
+    w_before = bg.flat.clone()
+    bg.step(use_graph=False)
+    torch.cuda.synchronize()
+    fb, bufs = bg.fb, bg.bufs
+    pts, z = bufs["pts"].cpu(), bufs["z"].cpu()                    # (1, R, S, 3), (1, R, S)
+    flat = w_before.cpu()
+    sd, off = {}, 0
+    for k, p_ in bg.trainer.fc_occ_map.named_parameters():
+        sd[k] = flat[off:off + p_.numel()].view(p_.shape); off += p_.numel()
+    Bm = flat[off:off + 63].view(1, 21, 3)
+    emb = O.unidirs_embed(pts, Bm, float(bg.trainer.pe._scale))
+    alpha, color = O.occupancy_map_forward(sd, emb)              # alpha: the x10 logit (src/model.py:151), colour after the sigmoid
+    occ_ref, _, depth_ref, _, rgb_ref, opa_ref = O.composite(alpha.squeeze(-1), color, z)
+    sig, col = fb["sigma"].cpu(), fb["rgbs"].cpu()
+    errs = dict(occupancy=rel_l2(torch.sigmoid(sig), occ_ref), colour=rel_l2(col, color), depth=rel_l2(fb["depth"].cpu(), depth_ref),
+                rgb=rel_l2(fb["rgb"].cpu(), rgb_ref), opacity=rel_l2(fb["opa"].cpu(), opa_ref))
+    print("fused background forward on trained weights:", {k: "%.2e" % v for k, v in errs.items()},
+          "max |x10 logit| %.1f" % float(sig.abs().max()), "losses first", first.tolist(), "last", last.tolist())
+    for k, v in errs.items():
+        assert v < 1e-3, (k, v)
