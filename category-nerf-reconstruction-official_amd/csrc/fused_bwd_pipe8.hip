@@ -47,10 +47,12 @@ __device__ long long g_pipe8_stamps[8 * 64];
 //   [ packed image PK_BYTES | GEO: residual fragments PK_LO_BYTES | B rows 272 | bias rows of the class | 4 chain waves | exchange ]
 // A class's bias rows (512 B per object row) sit in LDS except in the one instantiation where the budget is spent
 // (GEO with up to 15 rows: they are read from global there, ~1 k cycles per layer of the forward).
+// (WIDE = 3, any number of object rows: no per-object rows in LDS at all -- the row-sum block then holds one row per (chain wave,
+//  latent slot), see the kernel's comment; rs_rows8 is the one-hot table's row count, unused there)
 __host__ __device__ constexpr int rs_rows8(int wide) { return wide == 2 ? cnr_rec::ROWS_MAX : wide == 1 ? 7 : 4; }
-__host__ __device__ constexpr bool brows_in_lds8(int wide, bool geo) { return !(geo && wide == 2); }
+__host__ __device__ constexpr bool brows_in_lds8(int wide, bool geo) { return wide == 3 ? false : !(geo && wide == 2); }
 // row one-hot table per chain wave: rows + the ones row, 32 halfs each; the flush reuses it for 127 floats of partial sums
-__host__ __device__ constexpr int k8_small(int wide) { return (rs_rows8(wide) + 1) * 64 > 512 ? (rs_rows8(wide) + 1) * 64 : 512; }
+__host__ __device__ constexpr int k8_small(int wide) { return wide != 3 && (rs_rows8(wide) + 1) * 64 > 512 ? (rs_rows8(wide) + 1) * 64 : 512; }
 // PE images without the trailing pads of the 4-wave kernels: an E2 read of the (discarded) slot columns 48..63 of row 31
 // runs 16 B past the image -- into this wave's dPre slot, which follows it
 constexpr int E1IMG8 = 32 * ST_E1, E2IMG8 = 32 * ST_E2;
@@ -76,7 +78,7 @@ struct TrainArgs {
   float* depth_out; float* var_out; float* rgb_out; float* opacity_out; float* partials;
 };
 static_assert(l8_total(4, 0, true) <= 160 * 1024 && l8_total(4, 1, true) <= 160 * 1024 && l8_total(4, 2, true) <= 160 * 1024 &&
-              l8_total(4, 2, false) <= 160 * 1024, "LDS budget");
+              l8_total(4, 2, false) <= 160 * 1024 && l8_total(4, 3, true) <= 160 * 1024, "LDS budget");
 
 // Which dW wave owns a block kind, and the block's index among that wave's accumulators: at most 5 accumulators per
 // wave, one unit of work per wave and layer step (cat_layer: dW3 two)
@@ -101,6 +103,11 @@ template <> __host__ __device__ constexpr int local8<4>(int kind) {
 // value it cost 2.4 us of the kernel at 2048 x 64).  WIDE = 1: up to 7 rows,
 // one row-sum block [4 latent slots x rows | 2 plain biases] (4 * 7 + 2 <= 32 block rows).  WIDE = 2: up to ROWS_MAX =
 // 15 rows, two blocks: A = [slots 0, 1 x rows | 2 plain biases], B = [slots 2, 3 x rows]; a layer step feeds one of them.
+// WIDE = 3 (one-launch form with a whole ray per tile group, i.e. KR >= 1 and not TWO): ANY number of object rows per class.  A
+// 32-sample tile lies inside one ray, hence belongs to ONE object: its per-object row sum is the plain column sum of dPre.  The
+// row-sum block holds row 4 w + s for chain wave w's tile and latent slot s (A operand: all ones in that row) and rows 16, 17
+// for the two plain biases; after every iteration its owner adds rows 0..15 to the fixed-point table at the four tiles' object
+// rows (integer atomics: order-free, bitwise reproducible) and clears them.  No one-hot table, bias rows from global memory.
 // GEO (one-launch form only): the forward's geometry branch as three products per fragment with the residual weight image
 // packed_lo (fused_common.h, NKK_GEO) -- what keeps the occupancy within 1e-3 of fp32 for trained weights.
 template <int NCH, int NDW, int WIDE, int KR, bool TWO, bool PAD, bool GEO>
@@ -114,6 +121,7 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
   static_assert(!TWO || KR == 1, "two rays per tile only with one tile per ray");
   static_assert(!TWO || PAD, "16-slot rays are the padded form");   // PAD = false: S == SP exactly (the plain index arithmetic)
   static_assert(!GEO || KR > 0, "the precise geometry branch belongs to the one-launch form (the forward that is rendered)");
+  static_assert(WIDE != 3 || (KR > 0 && !TWO), "per-tile object rows need a whole ray per tile group");
   constexpr int L8_BL = l8_bl(GEO), L8_BR = l8_br(GEO), L8_CHAIN = l8_chain(WIDE, GEO), C8_BYTES = c8_bytes(WIDE),
                 K8_SMALL_BYTES = k8_small(WIDE);
   constexpr bool BROWS_LDS = brows_in_lds8(WIDE, GEO);
@@ -128,7 +136,8 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
   constexpr bool PEDW = CNR_PEDW && KR > 1;
   constexpr int SP = TWO ? 16 : (KR > 0 ? 32 * KR : 32);   // padded sample slots per ray (one-launch form)
   constexpr int NCHW = NCH, NTHR = (NCH + NDW) * 64, NACC = 5, LI_RS = local8<NDW>(BK_RS), LI_RS2 = local8<NDW>(BK_RS2);
-  constexpr int RS_ROWS = WIDE == 2 ? cnr_rec::ROWS_MAX : WIDE == 1 ? 7 : 4;  // most object rows this instance takes
+  constexpr int RS_ROWS = WIDE == 2 ? cnr_rec::ROWS_MAX : WIDE == 1 ? 7 : 4;  // most object rows this instance takes (WIDE = 3: unused)
+  constexpr bool ROWTILE = WIDE == 3;
   // per chain wave: E1 image, E2 image, dPre / input slot, row one-hot table (the flush reuses it for the wave's
   // partial sums)
   // The dPre / input images are double-buffered (K_PAR apart): layer step k uses copy k & 1, so the chain wave stages step
@@ -417,7 +426,7 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
       acc = acc_init(cf + CF_B_XYZ, h);
       catp = acc_init(brow_l + 1 * 32, h);
       if (any_iter) P8SYNC();   // the previous iteration's last barrier: the dW waves are done with this wave's images
-      {
+      if constexpr (!ROWTILE) {
         const int rl = row - c * rows_per_class;
         constexpr int rs = RS_ROWS;  // rows per latent slot in the row-sum block (4 / 7 / 15 by WIDE); the ones row follows
 #pragma unroll
@@ -857,7 +866,8 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
     // "ones" row each for the two plain biases (encoding_shape: group 4, rgb.0: group 5)
     constexpr int rs = RS_ROWS;  // rows per latent slot: a compile-time constant of the instantiation (a run-time stride cost 2.4 us)
     // (WIDE = 2: block A holds slots 0, 1 and the two bias rows, block B slots 2, 3)
-    const int nlat_rows = (WIDE == 2 ? 2 : 4) * rs;
+    // (WIDE = 3: rows 0..15 = 4 x chain wave + latent slot, flushed every iteration; rows 16, 17 the two bias rows)
+    const int nlat_rows = ROWTILE ? 16 : (WIDE == 2 ? 2 : 4) * rs;
     const int rpc_inv = (65536 + rs - 1) / rs;  // m / rs = (m * rpc_inv) >> 16 for m < 32
     const int col_slot = (col * rpc_inv) >> 16;
     const int m_row = col < nlat_rows ? col - col_slot * rs : rs,
@@ -923,6 +933,18 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
     };
     float p0 = 0.f, p1 = 0.f, p2 = 0.f;
     if constexpr (PEDW) pts_of(blockIdx.x * NCHW + DWI, p0, p1, p2);
+    // ROWTILE (the row-sum owner): the object rows of the iteration's four tiles, requested one iteration ahead like the position
+    constexpr bool RS_FLUSH = ROWTILE && DWI == owner8<NDW>(BK_RS);
+    auto obj_rows = [&](int t0_, int (&o)[4]) {
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const int tile = t0_ + w, tl = tile < ntiles ? tile : ntiles - 1;
+        const int ray_l = PAD ? (tl * 32) / SP : tl / (KR > 0 ? KR : 1);
+        o[w] = ray_row[(int64_t)c * R + (ray_l < R ? ray_l : R - 1)] - c * rows_per_class;
+      }
+    };
+    int orow[4] = {0, 0, 0, 0};
+    if constexpr (RS_FLUSH) obj_rows(blockIdx.x * NCHW, orow);
     for (int t0 = blockIdx.x * NCHW; t0 < ntiles; t0 += tile_step) {
       asm volatile("" ::: "memory");
       P8STAMP_RESET();
@@ -999,7 +1021,7 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
           if constexpr (OWN1) load_blk(w, IC<K1>{}, IC<SL1>{});
           if constexpr (OWN2) load_blk(w, IC<K2>{}, IC<SL2>{});
           if constexpr (OWN3) load_blk(w, IC<K3>{}, IC<SL3>{});
-          if constexpr (DO_RS) {
+          if constexpr (DO_RS && !ROWTILE) {
             const unsigned char* rowoh = cb + K_SMALL + a_r;   // [m_row][32] halfs: this lane's k = 8 h .. and 16 + 8 h ..
             fR[w % DEPTH][0] = __builtin_bit_cast(u4v, *reinterpret_cast<const h8*>(rowoh));
             fR[w % DEPTH][1] = __builtin_bit_cast(u4v, *reinterpret_cast<const h8*>(rowoh + 32));
@@ -1019,7 +1041,14 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
           if constexpr (OWN1) mma_blk(w, IC<K1>{}, IC<SL1>{});
           if constexpr (OWN2) mma_blk(w, IC<K2>{}, IC<SL2>{});
           if constexpr (OWN3) mma_blk(w, IC<K3>{}, IC<SL3>{});
-          if constexpr (DO_RS) {
+          if constexpr (DO_RS && ROWTILE) {
+            // the tile is one ray = one object: row 4 w + slot (latent layers) or 16 / 17 (plain biases) takes the column sum
+            const int mrow = RS_GRP < 4 ? 4 * w + RS_GRP : 16 + (RS_GRP - 4);
+            const unsigned int on = col == mrow ? 0x3c003c00u : 0u;     // f16 ones
+            const h8 ones = __builtin_bit_cast(h8, (u4v){on, on, on, on});
+            Wacc[LI_RS] = MFMA(ones, fD[w % DEPTH][0], Wacc[LI_RS]);
+            Wacc[LI_RS] = MFMA(ones, fD[w % DEPTH][1], Wacc[LI_RS]);
+          } else if constexpr (DO_RS) {
             // RS[m][:] += sum over the tile's samples in m's group of dPre
             constexpr bool BLK_B = WIDE == 2 && (RS_GRP == 2 || RS_GRP == 3);
             constexpr int LI = BLK_B ? LI_RS2 : LI_RS;
@@ -1049,6 +1078,24 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
       }
       P8SYNC();   // done with this iteration's images (the chain waves wait for it before they write the next ones)
 #undef STEP8
+      if constexpr (RS_FLUSH) {
+        // rows 0..15 of the row-sum block = (chain wave, latent slot) column sums of THIS iteration's tiles -> the fixed-point table
+        // at the tiles' object rows; this lane half holds rows 4 h + 0..3 (registers 0..3: chain wave h) and 8 + 4 h + 0..3
+        // (registers 4..7: chain wave 2 + h)
+        long long* tab = rows_fix + ((size_t)(blockIdx.x % cnr_rec::ROWS_FIX_COPIES) * gridDim.y + c) * rows_per_class * 128;
+        int nrow[4];
+        obj_rows(t0 + tile_step, nrow);
+#pragma unroll
+        for (int reg = 0; reg < 8; ++reg) {
+          const int o = reg < 4 ? (h ? orow[1] : orow[0]) : (h ? orow[3] : orow[2]);
+          const float v = Wacc[LI_RS][reg] * inv_gs;
+          atomicAdd(reinterpret_cast<unsigned long long*>(tab + (size_t)o * 128 + (reg & 3) * 32 + col),
+                    (unsigned long long)__double2ll_rn((double)v * cnr_rec::ROWS_FIX_SCALE));
+          Wacc[LI_RS][reg] = 0.0f;
+        }
+#pragma unroll
+        for (int w = 0; w < 4; ++w) orow[w] = nrow[w];
+      }
       if constexpr (PEDW) {
         // d e1 (written by the partner between step XYZ's barrier and the one above).  The workgroup's last tile is left to the
         // chain wave: behind the loop this wave has the record to write (~10 k cycles, the longer pole) and the chain wave nothing
@@ -1105,7 +1152,7 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
         const float v = (blk ? Wacc[LI_RS2][reg] : Wacc[LI_RS][reg]) * inv_gs;
         if (blk == 0 && m == nlat_rows) rec[OFF_ES_B + col] = v;
         else if (blk == 0 && m == nlat_rows + 1) { if (col < 16) rec[OFF_R0_B + col] = v; }
-        else if (m < nlat_rows && m - ((m * rpc_inv) >> 16) * rs < rows_per_class) {
+        else if (!ROWTILE && m < nlat_rows && m - ((m * rpc_inv) >> 16) * rs < rows_per_class) {   // (ROWTILE: flushed every iteration)
           const int slot = 2 * blk + ((m * rpc_inv) >> 16);
           const int i = (m - ((m * rpc_inv) >> 16) * rs) * 128 + slot * 32 + col;  // dbiasrows [row][latent slot][feature]
           rec[TRUNK + 126 + i] = v;
@@ -1270,8 +1317,11 @@ extern "C" int cnr_field_train(const cnr_field_train_args* a, void* stream) {
       !(a->grad_scale > 0.f))
     return CNR_E_ARG;
   const int blocks = cnr_field_train_blocks(R, S, a->max_blocks);
-  if (!blocks || rows_per_class < 1 || rows_per_class > cnr_rec::ROWS_MAX) return CNR_E_SHAPE;
   const int sp = train_slots(S);
+  // up to ROWS_MAX object rows per class in the row-sum blocks; more (up to ROWS_TILE_MAX) with one object per tile, i.e. a whole
+  // ray per tile group (S > 16) and the fixed-point table
+  if (!blocks || rows_per_class < 1 || rows_per_class > cnr_rec::ROWS_TILE_MAX) return CNR_E_SHAPE;
+  if (rows_per_class > cnr_rec::ROWS_MAX && (sp == 16 || !a->rows_fix)) return CNR_E_SHAPE;
   if ((int64_t)C * R * sp >= ((int64_t)1 << 31)) return CNR_E_SHAPE;   // 32-bit slot indices inside the kernel
   if (((uintptr_t)a->packed & 15) != 0 || ((uintptr_t)a->records & 15) != 0 || ((uintptr_t)a->packed_lo & 15) != 0 ||
       ((uintptr_t)a->biasrows & 15) != 0)
@@ -1294,6 +1344,19 @@ extern "C" int cnr_field_train(const cnr_field_train_args* a, void* stream) {
     if (pad) CNR_FT(W, 4, false, true, G);                                                                  \
     CNR_FT(W, 4, false, false, G);                                                                          \
   }
+#define CNR_FT_TILE(G)                                                                                      \
+  {                                                                                                         \
+    if (sp == 32) { if (pad) CNR_FT(3, 1, false, true, G); CNR_FT(3, 1, false, false, G); }                 \
+    if (sp == 64) { if (pad) CNR_FT(3, 2, false, true, G); CNR_FT(3, 2, false, false, G); }                 \
+    if (pad) CNR_FT(3, 4, false, true, G);                                                                  \
+    CNR_FT(3, 4, false, false, G);                                                                          \
+  }
+  // one object per tile whenever a ray has its own tiles and the table is there: it is also the faster form for 5 .. 15 objects
+  // (no one-hot table, one row-sum block: 38.4 us at 2048 x 64 for any count, against 40.7 / 41.9 us at 7 / 12 objects in the blocks)
+  if (rows_per_class > cnr_rec::ROWS_MAX || (rows_per_class > 4 && sp >= 32 && a->rows_fix)) {
+    if (a->packed_lo) CNR_FT_TILE(true)
+    CNR_FT_TILE(false)
+  }
   if (a->packed_lo) {
     if (rows_per_class > 7) CNR_FT_ALL(2, true)
     if (rows_per_class > 4) CNR_FT_ALL(1, true)
@@ -1302,6 +1365,7 @@ extern "C" int cnr_field_train(const cnr_field_train_args* a, void* stream) {
   if (rows_per_class > 7) CNR_FT_ALL(2, false)
   if (rows_per_class > 4) CNR_FT_ALL(1, false)
   CNR_FT_ALL(0, false)
+#undef CNR_FT_TILE
 #undef CNR_FT_ALL
 #undef CNR_FT
 }

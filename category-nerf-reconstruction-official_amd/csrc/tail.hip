@@ -304,7 +304,9 @@ extern "C" int cnr_step_tail(const cnr_step_tail_args* args, void* stream) {
       !losses || !flags || R <= 0)
     return CNR_E_ARG;
   if (do_latent && (!zl || !dbiasrows)) return CNR_E_ARG;
-  if (records && (!do_latent || !rows_fix || nwg <= 0 || n_obj > cnr_rec::ROWS_MAX)) return CNR_E_ARG;
+  // (more than ROWS_MAX object rows: the records carry no row sums, the fixed-point table has them all -- cnr_field_train's
+  //  one-object-per-tile form)
+  if (records && (!do_latent || !rows_fix || nwg <= 0 || n_obj > cnr_rec::ROWS_TILE_MAX)) return CNR_E_ARG;
   if (rows_fix && !do_latent) return CNR_E_ARG;
   if (n_obj > 64) return CNR_E_SHAPE;
   if (next_max_bound && (!depth || pool_rows < R)) return CNR_E_ARG;
@@ -348,7 +350,7 @@ extern "C" int cnr_step_grad(const float* theta, float* grad, int64_t class_stri
   if (!theta || !grad || class_stride <= 0 || L <= 0 || n_obj <= 0 || C <= 0 || !zl || !dbiasrows || !records ||
       nwg <= 0 || !rows_fix)
     return CNR_E_ARG;
-  if (n_obj > cnr_rec::ROWS_MAX) return CNR_E_SHAPE;
+  if (n_obj > cnr_rec::ROWS_TILE_MAX) return CNR_E_SHAPE;
   TailArgs a{};
   a.theta_in = theta; a.grad = grad;
   a.lay = FlatLayout{class_stride, off_latW, off_latb, off_shape, off_tex, L, n_obj};

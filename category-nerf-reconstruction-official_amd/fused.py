@@ -144,7 +144,15 @@ class FusedCategoryTrainer:
         # the latent backward: with AdamW and the epilogue when no gradient exchange follows (cnr_step_tail: single GPU,
         # class sharding), gradient only when rays are sharded (cnr_step_grad: the all-reduce comes between gradient and
         # optimiser)
-        self.use_records = n_obj <= 15 and ops.FIELD_BWD_VARIANT == "pipe4"
+        # Forward + render / loss + the whole backward in ONE launch (cnr_field_train, the 8-wave kernel's record path): a ray takes
+        # 16 / 32 / 64 / 128 padded sample slots; taken when at least 60 % of them are real samples (S = 10, 16, 20-32, 39-64,
+        # 77-128), else two calls, whose extra forward costs less than the dead lanes would.  CNR_ONE_LAUNCH=0 keeps the two calls.
+        one = bool(int(os.environ.get("CNR_ONE_LAUNCH", "1"))) if one_launch is None else bool(one_launch)
+        slots = 16 if self.S <= 16 else 32 if self.S <= 32 else 64 if self.S <= 64 else 128
+        one = one and fuse_render and self.S <= 128 and self.S >= 0.6 * slots and ops.FIELD_BWD_VARIANT == "pipe4"
+        # per-object bias-row sums: up to 15 objects per class in the kernel's row-sum blocks; 16 .. 32 on the one-launch path
+        # when a tile lies inside one ray (>= 32 slots per ray: one object per tile, sums straight to the fixed-point table)
+        self.use_records = ops.FIELD_BWD_VARIANT == "pipe4" and (n_obj <= 15 or (one and slots >= 32 and n_obj <= 32))
         self.grad_exchange = self.shard == "ray" and self.world > 1
         self.fused_tail = not self.grad_exchange and self.use_records
         fix_off = (n_th + n_db + 3) // 4 * 4                      # 16-byte aligned
@@ -230,13 +238,8 @@ class FusedCategoryTrainer:
         self.split_weights = self.precise
         # forward + render/loss in one launch where the shape allows (S a multiple of 32 up to 128), else two launches
         self._rl_blocks = int(_C.load().cnr_field_fwd_render_blocks(self.R, self.S)) if fuse_render else 0
-        # ... and forward + render / loss + the whole backward in ONE launch (cnr_field_train, the 8-wave kernel's record
-        # path): no second forward, no d sigma / d colour round trip.  A ray takes 16 / 32 / 64 / 128 padded sample slots;
-        # taken when at least 60 % of them are real samples (S = 10, 16, 20-32, 39-64, 77-128), else the two calls, whose
-        # extra forward costs less than the dead lanes would.  CNR_ONE_LAUNCH=0 keeps the two calls.
-        one = bool(int(os.environ.get("CNR_ONE_LAUNCH", "1"))) if one_launch is None else bool(one_launch)
-        slots = 16 if self.S <= 16 else 32 if self.S <= 32 else 64 if self.S <= 64 else 128
-        one = one and self.S <= 128 and self.S >= 0.6 * slots
+        # ... and forward + render / loss + the whole backward in ONE launch (``one``, decided above): no second forward, no
+        # d sigma / d colour round trip
         self._ft_blocks = int(_C.load().cnr_field_train_blocks(self.R, self.S, self.bwd_blocks)) \
             if (one and fuse_render and self.use_records and ops.FIELD_BWD_VARIANT == "pipe4") else 0
         if self._ft_blocks:

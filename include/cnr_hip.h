@@ -527,7 +527,13 @@ int cnr_field_fwd_fp8(const float* pts, const float* B, const void* packed, cons
  * `records` (>= C * cnr_field_train_blocks() * record size = cnr_field_bwd_workspace_bytes(C, blocks); reduce with
  * cnr_step_tail / cnr_step_grad, nwg = cnr_field_train_blocks()), rows_fix as cnr_field_bwd_pipe, and per-block loss
  * partials in loss_workspace (>= cnr_field_train_workspace_bytes()) for cnr_step_tail with rl_blocks =
- * cnr_field_train_blocks().  Returns CNR_E_SHAPE for S > 128 or more than 15 rows per class (use the two calls). */
+ * cnr_field_train_blocks().
+ * rows_per_class (objects per class): up to 15 travel in the kernel's row-sum blocks (and in the records); 16 .. 32 are taken
+ * when a ray has at least 32 sample slots (S > 16) and rows_fix is given: a 32-sample tile then lies inside one ray, i.e.
+ * belongs to one object, and its column sums go straight to the fixed-point table at that object's row (integer atomics,
+ * once per workgroup iteration); the records carry no row sums then and cnr_step_tail / cnr_step_grad take all of them from
+ * the table.  Returns CNR_E_SHAPE for S > 128, for more than 32 rows per class, and for more than 15 with S <= 16 or without
+ * rows_fix (use the two calls). */
 int cnr_field_train_blocks(int R, int S, int max_blocks);
 int64_t cnr_field_train_workspace_bytes(int C, int R, int S, int max_blocks);
 /* packed_lo (optional, (C, cnr_pack_lo_bytes()) from cnr_pack_weights_lo / cnr_step_prologue): the forward's geometry

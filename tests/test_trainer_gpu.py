@@ -26,13 +26,16 @@ def _oracle_params(cnr, tr, theta):
     return mlp, v["B"].clone(), v["shape"].clone(), v["tex"].clone()
 
 
-@pytest.mark.parametrize("C,R,n1,n2,L", [(1, 256, 4, 28, 256), (2, 128, 8, 56, 32)])
-def test_fused_train_step_against_oracle(cnr, dev, C, R, n1, n2, L):
+@pytest.mark.parametrize("C,R,n1,n2,L,n_obj", [(1, 256, 4, 28, 256, 4), (2, 128, 8, 56, 32, 4), (2, 256, 8, 56, 32, 20), (1, 256, 4, 28, 32, 31)])
+def test_fused_train_step_against_oracle(cnr, dev, C, R, n1, n2, L, n_obj):
+    """(20 / 31 objects per class: the one-launch kernel's one-object-per-tile row sums, S = 64 with the PE backward on the dW
+    partner and S = 32 without -- the latent-layer and code-table gradients below are what those sums feed.)"""
     torch.manual_seed(1234)  # the trainer draws its epoch permutation from the default generator
     cfg = cnr.cfg.synthetic_config(device=str(dev), latent_dim=L, n_bins_cam2surface=n1, n_bins=n2)
     gen = torch.Generator().manual_seed(7)
-    pools = [cnr.scene_cateogries.synthetic_pool(8 * R, 4, gen, "cpu") for _ in range(C)]
-    tr = cnr.fused.FusedCategoryTrainer(cfg, C, 4, pools, R, dev, seed=3, generator=gen, use_graph=False)
+    pools = [cnr.scene_cateogries.synthetic_pool(8 * R, n_obj, gen, "cpu") for _ in range(C)]
+    tr = cnr.fused.FusedCategoryTrainer(cfg, C, n_obj, pools, R, dev, seed=3, generator=gen, use_graph=False)
+    assert tr.use_records and tr.fused_tail and tr._ft_blocks
     theta0 = tr.theta.clone()
     rows = tr.perm[:, :R].long().cpu()          # pool rows of the first slice (epoch permutation)
     tr.step()
@@ -354,27 +357,41 @@ def test_many_epochs_graph_equals_eager(cnr, dev, n_obj):
 
 
 def test_twenty_objects_per_class_train_bitwise_repeatably(cnr, dev):
-    """More than fifteen objects per class leave the record path (the 8-wave kernel's row-sum blocks hold fifteen rows): the
-    trainer takes the block-split backward + separate latent / AdamW launches.  Since round 3 that path has no float atomic
-    either (fixed-point row table): graph replay and eager stepping end bit for bit in the same place, and the loss falls."""
-    res = {}
-    for name, graph in (("eager", False), ("graph", True)):
+    """More than fifteen objects per class.  With at least 32 sample slots per ray a tile lies inside one ray = one object, and
+    the one-launch kernel sends the per-object sums straight to the fixed-point table (up to 32 objects): the three-launch step,
+    graph replay and eager stepping bit for bit in the same place.  Otherwise (here: 12 samples per ray) the trainer takes the
+    block-split backward + separate latent / AdamW launches; since round 3 that path has no float atomic either (fixed-point row
+    table): also bitwise repeatable.  The two paths compute the same step."""
+    def make(n1, n2, graph, one=None):
         torch.manual_seed(78)
-        cfg = cnr.cfg.synthetic_config(device=str(dev), latent_dim=32, n_bins_cam2surface=4, n_bins=28)
+        cfg = cnr.cfg.synthetic_config(device=str(dev), latent_dim=32, n_bins_cam2surface=n1, n_bins=n2)
         gen = torch.Generator().manual_seed(5)
         pools = [cnr.scene_cateogries.synthetic_pool(8 * 256, 20, gen, "cpu") for _ in range(2)]
-        tr = cnr.fused.FusedCategoryTrainer(cfg, 2, 20, pools, 256, dev, seed=2, generator=gen, use_graph=graph)
-        assert not tr.use_records and not tr.fused_tail
-        hist = []
-        for _ in range(24):
-            tr.step()
-            hist.append(tr.losses.clone())
-        torch.cuda.synchronize()
-        res[name] = (torch.stack(hist), tr.theta.clone())
-    assert torch.isfinite(res["graph"][0]).all()
-    assert torch.equal(res["graph"][0], res["eager"][0]) and torch.equal(res["graph"][1], res["eager"][1])
-    h = res["graph"][0]
-    assert float(h[-4:].sum()) < float(h[:4].sum())
+        return cnr.fused.FusedCategoryTrainer(cfg, 2, 20, pools, 256, dev, seed=2, generator=gen, use_graph=graph, one_launch=one)
+    for n1, n2, fast in ((4, 28, True), (4, 8, False)):
+        res = {}
+        for name, graph in (("eager", False), ("graph", True)):
+            tr = make(n1, n2, graph)
+            assert (tr.use_records and tr.fused_tail and bool(tr._ft_blocks)) == fast
+            hist = []
+            for _ in range(24):
+                tr.step()
+                hist.append(tr.losses.clone())
+            torch.cuda.synchronize()
+            res[name] = (torch.stack(hist), tr.theta.clone())
+        assert torch.isfinite(res["graph"][0]).all()
+        assert torch.equal(res["graph"][0], res["eager"][0]) and torch.equal(res["graph"][1], res["eager"][1])
+        h = res["graph"][0]
+        assert float(h[-4:].sum()) < float(h[:4].sum())
+    # same first step on either path (same samples; the record path's forward is the one-launch kernel's, the other's the
+    # forward + render launch: equal products, see test_one_launch_step_equals_forward_render_plus_backward)
+    a, b = make(4, 28, False), make(4, 28, False, one=False)
+    assert a._ft_blocks and not b._ft_blocks and not b.use_records
+    a.step(); b.step()
+    torch.cuda.synchronize()
+    assert rel_l2(a.losses, b.losses) < 1e-4
+    ga, gb = a.grad.double().flatten(), b.grad.double().flatten()
+    assert float(ga @ gb / (ga.norm() * gb.norm())) > 0.9999 and rel_l2(a.grad, b.grad) < 2e-2
 
 
 def test_code_tables_are_their_own_adamw_group(cnr, dev):
