@@ -439,7 +439,7 @@ def main():
                 "frac": achieved / PEAK_MFMA_F16_TFLOPS, "traffic": traffic,
                 "variant": cnr_amd.ops.FIELD_BWD_VARIANT,
                 "kernel_ms": {k: round(v, 5) for k, v in avg.items()},
-                "kernel_ms_note": "HIP events on the launch stream; %s back to back x50 (one launch at a time in the "
+                "kernel_ms_note": "HIP events on the launch stream; %s back to back, median of five batches of ten launches (one launch at a time in the "
                                   "eager step, gaps included: %.5f), the others one launch at a time" % (bwd_name, eager_bwd_ms),
                 "step_tflops": rays_per_step_global * S * FLOP_PER_SAMPLE_STEP / (dt / args.steps) / 1e12}
 

@@ -561,16 +561,23 @@ class FusedCategoryTrainer:
         clamp = torch.zeros_like(self.clamp)
         st = self.d_state2[self.parity]
         args = self._field_train_args(b, o, Bc, st, 1.0, fix, clamp)
-        run = lambda: _C.call_struct("cnr_field_train", **args)
+        # the argument block is filled ONCE (~40 us of host work per call otherwise: as long as the kernel itself, so that a slow
+        # host moment showed up as kernel time -- 135 instead of 38 us in one run of eight); median of five batches
+        blk = _C._prepare_struct("cnr_field_train", args)
+        run = lambda: _C._invoke_struct("cnr_field_train", blk)
         for _ in range(3):
             run()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            run()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / iters
+        per = max(10, iters // 5)
+        ts = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(per):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) / per)
+        return sorted(ts)[2]
 
     def time_field_bwd(self, iters=50):
         """Average duration (ms) of the dominant call -- the fused field backward on the live buffers of the last step
