@@ -347,24 +347,249 @@ __device__ __forceinline__ void latent_bwd_block_1trip(const float* __restrict__
   }
 }
 
+// ---- the tail launch's latent blocks for classes of MORE than four objects ---------------------------------------------------
+// latent_bwd_block lets every block rebuild the whole d pre table (n_obj x 128 dot products of 32) and walk the fixed-point
+// table in full: its time grows by ~0.85 us per object (tail launch 10 -> 24 us from 4 to 20 objects).  Here a block builds only
+// the d pre entries ITS elements read, from only the table rows those need, with every global load issued before the first
+// barrier -- one memory round trip per block whatever the object count (like latent_bwd_block_1trip, which covers <= 4 objects):
+//   * a block of 256 consecutive d Wl elements spans max(1, 256 / L) rows (k, o) of the latent weights and reads, per row,
+//     d pre[ob][k][o] of every object: n_obj dot products per row.  The thread that owns a row's first element also forms
+//     d bl[k][o] = sum over objects of the same entries (there is no separate bias block);
+//   * a block of 256 consecutive code-gradient elements spans max(1, 256 / L) objects and reads d pre[ob][.] of those only.
+// Blocks are dealt per group (NW = ceil(128 L / 256) weight blocks, then NS = ceil(n_obj L / 256) shape and NS texture blocks),
+// so a block never straddles two groups.  Same expressions in the same order as latent_bwd_block: same bits.
+__host__ __device__ inline bool latent_local_ok(int L, int n_obj) {
+  if (L <= 0 || n_obj <= 0) return false;
+  if (!(256 % L == 0 || L % 256 == 0)) return false;      // rows / objects per block: a whole number, block-aligned
+  const int per = L >= 256 ? 1 : 256 / L;
+  return n_obj <= 32 && per * n_obj <= 256 && per <= 8;
+}
+__host__ __device__ inline int latent_local_blocks(int L, int n_obj) {
+  return (128 * L + 255) / 256 + 2 * ((n_obj * L + 255) / 256);
+}
+template <class Sink>
+__device__ __forceinline__ void latent_bwd_block_local(const float* __restrict__ th, const FlatLayout& lay,
+                                                       const float* __restrict__ z,
+                                                       const long long* __restrict__ rows_fix_c, int64_t copy_stride,
+                                                       int ncopies, double fix_inv_scale, float reg_scale, float* sm,
+                                                       const Sink& sink, int blk, int n_real = 1 << 30) {
+  const int n_obj = lay.n_obj, L = lay.L;
+  const int NW = (128 * L + 255) / 256, NS = (n_obj * L + 255) / 256;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  float* rowsL = sm;                               // table rows this block needs, as floats
+  auto row_entry = [&](int idx, long long (&f)[8]) {   // the 8 copies of table entry idx (this class), all in flight
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] = k < ncopies ? rows_fix_c[(int64_t)k * copy_stride + idx] : 0;
+  };
+  auto row_value = [&](const long long (&f)[8]) {
+    long long t = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += f[k];
+    return (float)((double)t * fix_inv_scale);
+  };
+  if (blk < NW) {
+    // ================================ d Wl (and d bl) ================================
+    const int e0 = blk * 256, e = e0 + tid;
+    const bool live = e < 128 * L;
+    const int p_lo = e0 / L, p_hi = min((e0 + 255) / L, 127), np = p_hi - p_lo + 1;   // rows (k, o) = p / 32, p % 32
+    const int k_lo = p_lo >> 5, nk = (p_hi >> 5) - k_lo + 1;                             // <= 2 latent slots
+    float* dsel = rowsL + nk * n_obj * 32;            // [np][n_obj] d pre of the block's rows
+    // ---- every global load of the block ----
+    // (a) table rows (ob, k) for k_lo .. : nk * n_obj * 32 entries, thread r takes entries r, r + 256, ..
+    const int nrow = nk * n_obj * 32;
+    long long fx[4][8];
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
+      const int r = tid + 256 * sl;
+      const int rr = r < nrow ? r : 0;
+      const int kk = rr / (n_obj * 32), ob = (rr / 32) % n_obj, o_ = rr & 31;
+      row_entry((ob * 4 + k_lo + kk) * 32 + o_, fx[sl]);
+    }
+    // (b) the d pre entry this thread forms: q = row_local * n_obj + ob  (np * n_obj <= 256)
+    const int q = tid, qrow = q / n_obj, qob = q - qrow * n_obj;
+    const bool qon = q < np * n_obj;
+    const int qp = p_lo + (qon ? qrow : 0), qk = qp >> 5, qo = qp & 31;
+    float wq[32], zq;
+    {
+      int w_off, b_off, ld;
+      latent_target(qk, w_off, b_off, ld);
+#pragma unroll
+      for (int o_ = 0; o_ < 32; ++o_) wq[o_] = th[w_off + o_ * ld + qo];
+      zq = z[((qon ? qob : 0) * 4 + qk) * 32 + qo];
+    }
+    // (c) this thread's element: code entries of every object at its l
+    const int ee = live ? e : 0, ep = ee / L, el = ee - ep * L, ek = ep >> 5;
+    const float* cbase = th + (ek == 3 ? lay.tex : lay.shape) + el;
+    float cv[32];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) cv[u] = u < n_obj ? cbase[(int64_t)u * L] : 0.0f;
+    if (live) sink.prefetch(lay.latW + e);
+    // ---- table rows -> floats in LDS ----
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
+      const int r = tid + 256 * sl;
+      if (r < nrow) rowsL[r] = row_value(fx[sl]);
+    }
+    for (int r = tid + 1024; r < nrow; r += 256) {     // (more than 32 objects' worth of rows: not reached with n_obj <= 32, nk <= 1)
+      const int kk = r / (n_obj * 32), ob = (r / 32) % n_obj, o_ = r & 31;
+      long long f[8];
+      row_entry((ob * 4 + k_lo + kk) * 32 + o_, f);
+      rowsL[r] = row_value(f);
+    }
+    __syncthreads();
+    // ---- d pre of the block's rows ----
+    if (qon) {
+      const float* rr = rowsL + ((qk - k_lo) * n_obj + qob) * 32;
+      float s_ = 0.0f;
+#pragma unroll
+      for (int o_ = 0; o_ < 32; ++o_) s_ = fmaf(rr[o_], wq[o_], s_);
+      dsel[q] = zq > 0.0f ? s_ : 0.0f;
+    }
+    __syncthreads();
+    // ---- the element, then (first element of a row) the row's bias ----
+    if (live) {
+      const float* dp = dsel + (ep - p_lo) * n_obj;
+      float s_ = 0.0f;
+#pragma unroll
+      for (int u = 0; u < 32; ++u)
+        if (u < n_obj) s_ = fmaf(dp[u], cv[u], s_);
+      sink.latent_set(lay.latW + e, s_);
+      if (el == 0) {
+        sink.prefetch(lay.latb + ep);
+        float b_ = 0.0f;
+        for (int ob = 0; ob < n_obj; ++ob) b_ += dp[ob];
+        sink.latent_set(lay.latb + ep, b_);
+      }
+    }
+    return;
+  }
+  // ================================ code tables ================================
+  const bool is_tex = blk >= NW + NS;
+  const int bc = blk - NW - (is_tex ? NS : 0);
+  const int i0 = bc * 256, i = i0 + tid;
+  const bool live = i < n_obj * L;
+  const int ob_lo = i0 / L, ob_hi = min((i0 + 255) / L, n_obj - 1), nob = ob_hi - ob_lo + 1;   // objects of this block (<= per)
+  const int NK = is_tex ? 32 : 96, K0 = is_tex ? 96 : 0;       // d pre entries per object this group reads: [K0, K0 + NK)
+  float* dsel = rowsL + nob * NK;                   // [nob][NK]
+  float* inv_n = dsel + nob * NK;                   // [nob] reg_scale / ||code||
+  // ---- every global load of the block ----
+  // (a) table rows: entries (ob, K0 + j) for the block's objects
+  const int nrow = nob * NK;                        // <= 8 * 96 = 768
+  long long fx[3][8];
+#pragma unroll
+  for (int sl = 0; sl < 3; ++sl) {
+    const int r = tid + 256 * sl;
+    const int rr = r < nrow ? r : 0;
+    const int ob = ob_lo + rr / NK, j = rr % NK;
+    row_entry(ob * 128 + K0 + j, fx[sl]);
+  }
+  // (b) code norms: wave wv takes object ob_lo + wv (and + 4): the same loads and sums as latent_bwd_block
+  float cvn[2][4];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int t = wv + 4 * r;
+    const bool on = t < nob;
+    const float* code = th + (is_tex ? lay.tex : lay.shape) + (int64_t)(ob_lo + (on ? t : 0)) * L;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int l = lane + 64 * j; cvn[r][j] = (on && l < L) ? code[l] : 0.0f; }
+  }
+  // (c) this thread's element: the 96 (32) weights of its l, its own code entry
+  const int ii = live ? i : 0, eob = ii / L, el = ii - eob * L;
+  float opv[96];
+#pragma unroll
+  for (int ko = 0; ko < 96; ++ko) opv[ko] = ko < NK ? th[lay.latW + (int64_t)(K0 + ko) * L + el] : 0.0f;
+  const float own = th[(is_tex ? lay.tex : lay.shape) + ii];
+  if (live) sink.prefetch((is_tex ? lay.tex : lay.shape) + i);
+  // (d) the trunk-weight column and activation of the FIRST d pre entry this thread forms (entries tid, tid + 256, ..): with
+  //     one object per block (L = 256) that is all of them
+  float wq0[32], zq0;
+  {
+    const int q = tid < nrow ? tid : 0;
+    const int jj = K0 + q % NK, k = jj >> 5, j = jj & 31;
+    int w_off, b_off, ld;
+    latent_target(k, w_off, b_off, ld);
+#pragma unroll
+    for (int o_ = 0; o_ < 32; ++o_) wq0[o_] = th[w_off + o_ * ld + j];
+    zq0 = z[(ob_lo + q / NK) * 128 + jj];
+  }
+  // ---- table rows -> LDS ----
+#pragma unroll
+  for (int sl = 0; sl < 3; ++sl) {
+    const int r = tid + 256 * sl;
+    if (r < nrow) rowsL[r] = row_value(fx[sl]);
+  }
+  // ---- code norms ----
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int t = wv + 4 * r;
+    if (t < nob) {      // (wave-uniform)
+      const int ob = ob_lo + t;
+      const float* code = th + (is_tex ? lay.tex : lay.shape) + (int64_t)ob * L;
+      float s_ = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s_ = fmaf(cvn[r][j], cvn[r][j], s_);
+      for (int l = lane + 256; l < L; l += 64) s_ = fmaf(code[l], code[l], s_);
+      s_ = wave_sum(s_);
+      if (lane == 0) inv_n[t] = ob < n_real ? reg_scale / sqrtf(s_) : 0.0f;
+    }
+  }
+  __syncthreads();
+  // ---- d pre entries (ob, K0 + j): dot of the object's slot-k table row with column j of the slot's trunk weights ----
+  for (int q = tid; q < nrow; q += 256) {
+    const int t = q / NK, jj = K0 + q % NK, k = jj >> 5, j = jj & 31;
+    float wq[32], zq;
+    if (q == tid) {
+#pragma unroll
+      for (int o_ = 0; o_ < 32; ++o_) wq[o_] = wq0[o_];
+      zq = zq0;
+    } else {
+      int w_off, b_off, ld;
+      latent_target(k, w_off, b_off, ld);
+#pragma unroll
+      for (int o_ = 0; o_ < 32; ++o_) wq[o_] = th[w_off + o_ * ld + j];
+      zq = z[(ob_lo + t) * 128 + jj];
+    }
+    const float* rr = rowsL + t * NK + (k - (K0 >> 5)) * 32;
+    float s_ = 0.0f;
+#pragma unroll
+    for (int o_ = 0; o_ < 32; ++o_) s_ = fmaf(rr[o_], wq[o_], s_);
+    dsel[q] = zq > 0.0f ? s_ : 0.0f;
+  }
+  __syncthreads();
+  if (live) {
+    const float* dp = dsel + (eob - ob_lo) * NK;
+    float s_ = 0.0f;
+#pragma unroll
+    for (int ko = 0; ko < 96; ++ko)
+      if (ko < NK) s_ = fmaf(dp[ko], opv[ko], s_);
+    sink.latent_set((is_tex ? lay.tex : lay.shape) + i, s_ + inv_n[eob - ob_lo] * own);
+  }
+}
+
 // the trunk-entry term of that first group for ONE trunk index q of a class row (0 when q is not a latent-target
 // weight / bias): what latent_bwd_block would have added there.  For consumers that finish the trunk gradient
 // themselves (tail.hip).
-__device__ __forceinline__ float latent_trunk_term(int q, const float* __restrict__ z, const float* __restrict__ dbr,
-                                                   int n_obj) {
-  int k, o, j;
+// which (latent slot k, output o, input j; j = 32: the bias) trunk index q of a class row is, false when the latent path adds
+// nothing there
+__device__ __forceinline__ bool latent_trunk_index(int q, int& k, int& o, int& j) {
   if (q >= OFF_S1_W && q < OFF_S1_W + 1024) { k = 0; o = (q - OFF_S1_W) >> 5; j = (q - OFF_S1_W) & 31; }
   else if (q >= OFF_S1_B && q < OFF_S1_B + 32) { k = 0; o = q - OFF_S1_B; j = 32; }
   else if (q >= OFF_CAT_W && q < OFF_CAT_W + 32 * (32 + E1)) {
     k = 1; o = (q - OFF_CAT_W) / (32 + E1); j = (q - OFF_CAT_W) % (32 + E1);
-    if (j >= 32) return 0.0f;
+    if (j >= 32) return false;
   }
   else if (q >= OFF_CAT_B && q < OFF_CAT_B + 32) { k = 1; o = q - OFF_CAT_B; j = 32; }
   else if (q >= OFF_S2_W && q < OFF_S2_W + 1024) { k = 2; o = (q - OFF_S2_W) >> 5; j = (q - OFF_S2_W) & 31; }
   else if (q >= OFF_S2_B && q < OFF_S2_B + 32) { k = 2; o = q - OFF_S2_B; j = 32; }
   else if (q >= OFF_T1_W && q < OFF_T1_W + 1024) { k = 3; o = (q - OFF_T1_W) >> 5; j = (q - OFF_T1_W) & 31; }
   else if (q >= OFF_T1_B && q < OFF_T1_B + 32) { k = 3; o = q - OFF_T1_B; j = 32; }
-  else return 0.0f;
+  else return false;
+  return true;
+}
+__device__ __forceinline__ float latent_trunk_term(int q, const float* __restrict__ z, const float* __restrict__ dbr,
+                                                   int n_obj) {
+  int k, o, j;
+  if (!latent_trunk_index(q, k, o, j)) return 0.0f;
   float s = 0.0f;
   for (int ob = 0; ob < n_obj; ++ob) {
     const float d = dbr[(ob * 4 + k) * 32 + o];

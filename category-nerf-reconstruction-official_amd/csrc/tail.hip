@@ -34,6 +34,7 @@ struct TailArgs {
   const float* partials; int nb; float* losses; int32_t* flags;
   const float* depth; int64_t pool_rows; const int* perm; int R; float* max_bound;
   int do_latent, NL, NA;
+  int local_latent;   // latent blocks in the per-block form of latent_bwd_block_local (more than four objects, rows from the table)
   // optional: the field backward's per-workgroup records (nwg per class) are reduced HERE, and the per-object
   // bias-row sums come from the fixed-point table the field backward accumulated with integer atomics
   const float* records; int nwg; const long long* rows_fix; int NR;
@@ -152,6 +153,21 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
       TAIL_T1(0);
       return;
     }
+    if (a.rows_fix && a.local_latent) {
+      // more than four objects: every block builds only the d pre entries its own elements read (latent_common.h); the float
+      // rows are published by the class's epilogue block
+      const int n = a.lay.n_obj * 128;
+      latent_bwd_block_local(a.theta_in + (int64_t)c * P, a.lay, a.zl + (int64_t)c * n, a.rows_fix + (size_t)c * n,
+                             (int64_t)a.C * n, cnr_rec::ROWS_FIX_COPIES, 1.0 / cnr_rec::ROWS_FIX_SCALE, reg_c, sm, sink, blk,
+                             n_real);
+      if (a.grad_only && blk == 0 && a.dbiasrows) {   // (no epilogue blocks in the gradient-only launch)
+        __syncthreads();
+        load_rows_fix(a, c, sm);
+        for (int i = threadIdx.x; i < n; i += 256) a.dbiasrows[(int64_t)c * n + i] = sm[i];
+      }
+      TAIL_T1(0);
+      return;
+    }
     if (a.rows_fix) {  // rows from the fixed-point table (block 0 of the class also publishes them as floats)
       float* rows = sm;
       load_rows_fix(a, c, rows);
@@ -173,15 +189,40 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
       // nwg / NQ records.  Measured at configs[1] (256 records): EPB = 64 (two rounds of 32 loads per thread, 256-byte
       // segments per wave load) 30.75 M rays/s; EPB = 32 29.9 M; EPB = 16 (one round, 64-byte segments, 4 x the blocks) 24.2 M
       constexpr int EPB = cnr_rec::TAIL_EPB, NQ = 256 / EPB;
-      float* rows = sm;                      // [n_obj * 128] bias-row gradient of the class
-      float* part = sm + a.lay.n_obj * 128;  // [NQ][EPB] (+ [NQ][EPB] for the second dB addend)
-      // only blocks that hold a latent-conditioned layer's weights or biases need the rows (block-uniform test)
-      const int lo = blk * EPB, hi = lo + EPB;
-      auto hits = [&](int off, int len) { return lo < off + len && hi > off; };
-      if (hits(OFF_S1_W, 1056) || hits(OFF_CAT_W, 32 * (32 + E1) + 32) || hits(OFF_S2_W, 1056) || hits(OFF_T1_W, 1056))
-        load_rows_fix(a, c, rows);
+      float* part = sm;                      // [NQ][EPB] (+ [NQ][EPB] for the second dB addend, + [NQ][EPB] for the latent-path term)
       const int e = threadIdx.x % EPB, q = threadIdx.x / EPB;
       const int i = blk * EPB + e;
+      // The latent path's share of a latent-conditioned layer's weight / bias gradient, sum over objects of d biasrow[ob][k][o] *
+      // (z[ob][k][j] | 1): the NQ threads of an entry split the objects (ob = q, q + NQ, ..) and read their table entries straight
+      // into registers -- no walk over the whole table, no barrier, nothing that grows with the object count beyond n_obj / NQ
+      // entries per thread; the loads go out together with the record loads below.
+      float lat_part = 0.0f;
+      {
+        int lk, lo_, lj;
+        if (i < TRUNK && latent_trunk_index(i, lk, lo_, lj)) {
+          const int n_obj = a.lay.n_obj, n = n_obj * 128;
+          const long long* tabc = a.rows_fix + (size_t)c * n;
+          const float* zc = a.zl + (int64_t)c * n;
+          for (int ob0 = q; ob0 < n_obj; ob0 += 4 * NQ) {       // four objects (32 table loads) in flight at a time
+            long long f[4][cnr_rec::ROWS_FIX_COPIES];
+            float zz[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int ob = ob0 + u * NQ, on = ob < n_obj, idx = ((on ? ob : 0) * 4 + lk) * 32;
+#pragma unroll
+              for (int k = 0; k < cnr_rec::ROWS_FIX_COPIES; ++k) f[u][k] = on ? tabc[(size_t)k * a.C * n + idx + lo_] : 0;
+              zz[u] = on ? (lj < 32 ? zc[idx + lj] : 1.0f) : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              long long t = 0;
+#pragma unroll
+              for (int k = 0; k < cnr_rec::ROWS_FIX_COPIES; ++k) t += f[u][k];
+              lat_part = fmaf((float)((double)t * (1.0 / cnr_rec::ROWS_FIX_SCALE)), zz[u], lat_part);
+            }
+          }
+        }
+      }
       // trunk entries and the first dB half own an output; the second dB half is the other addend of the first
       const bool owner = i < TRUNK + 63;
       float s0 = 0.0f, s1 = 0.0f;
@@ -194,7 +235,7 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
         if (cnr_rec::rec_entry_written(i, a.lay.n_obj)) s0 = cnr_rec::record_range_sum(r, w0, w1);
         if (i >= TRUNK) s1 = cnr_rec::record_range_sum(r + 63, w0, w1);
       }
-      part[q * EPB + e] = s0; part[256 + q * EPB + e] = s1;
+      part[q * EPB + e] = s0; part[256 + q * EPB + e] = s1; part[512 + q * EPB + e] = lat_part;
       __syncthreads();
       if (q == 0 && owner) {
         auto tree = [&](const float* pp) {       // fixed-order pairwise sum of the NQ partials of entry e
@@ -210,7 +251,7 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
         };
         float g = tree(part);
         if (i >= TRUNK) g += tree(part + 256);
-        if (i < TRUNK) g += latent_trunk_term(i, a.zl + (int64_t)c * a.lay.n_obj * 128, rows, a.lay.n_obj);
+        if (i < TRUNK) g += tree(part + 512);
         a.grad[idx] = g;
         if (!a.grad_only) {
           float pi = p0 * (1.0f - a.lr * a.wd);
@@ -248,6 +289,11 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
   // ---- epilogue of class b: loss values + flags, next slice's max depth, next step state (class 0)
   const int c = b, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   float* red = sm;
+  if (a.local_latent && a.rows_fix && a.dbiasrows) {   // the class's bias-row gradient as floats (the latent blocks no longer walk the whole table)
+    load_rows_fix(a, c, sm);
+    for (int i = threadIdx.x; i < a.lay.n_obj * 128; i += 256) a.dbiasrows[(int64_t)c * a.lay.n_obj * 128 + i] = sm[i];
+    __syncthreads();
+  }
   const int64_t cursor = a.state_cur[0] + a.add_rows;
   if (wv == 0) {
     cnr_rl::finish_class(a.partials, a.nb, a.losses, a.flags, C, c, lane);
@@ -326,6 +372,8 @@ extern "C" int cnr_step_tail(const cnr_step_tail_args* args, void* stream) {
   const int64_t nlat_out = (int64_t)4 * 32 * L + 128 + (int64_t)2 * n_obj * L;
   a.NL = (int)((nlat_out + 255) / 256);
   if (a.NL > 256) a.NL = 256;
+  a.local_latent = (do_latent && rows_fix && n_obj > 4 && latent_local_ok(L, n_obj)) ? 1 : 0;
+  if (a.local_latent) a.NL = latent_local_blocks(L, n_obj);
   const int64_t n = (int64_t)C * class_stride;
   int64_t na = (n + 255) / 256;
   if (na > 2048) na = 2048;
@@ -359,6 +407,8 @@ extern "C" int cnr_step_grad(const float* theta, float* grad, int64_t class_stri
   const int64_t nlat_out = (int64_t)4 * 32 * L + 128 + (int64_t)2 * n_obj * L;
   a.NL = (int)((nlat_out + 255) / 256);
   if (a.NL > 256) a.NL = 256;
+  a.local_latent = (n_obj > 4 && latent_local_ok(L, n_obj)) ? 1 : 0;
+  if (a.local_latent) a.NL = latent_local_blocks(L, n_obj);
   a.records = (const float*)records; a.nwg = nwg; a.rows_fix = rows_fix; a.NR = cnr_rec::REC_FLOATS / cnr_rec::TAIL_EPB;
   const unsigned grid = (unsigned)(a.NL * C + a.NR * C);
   const size_t lds = (size_t)(2 * n_obj * 128 + 2 * n_obj + 520) * sizeof(float);
