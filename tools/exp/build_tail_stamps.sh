@@ -3,6 +3,6 @@
 # compiled in (tools/exp/tail_phases.py); run `make -C category-nerf-reconstruction-official_amd/csrc` first
 cd "$(dirname "$0")/../../category-nerf-reconstruction-official_amd/csrc" && mkdir -p ../../tools/exp/libs && \
 objs=$(ls build/*.o | grep -v "build/tail.o\|build/fused_fwd.o\|_stamps.o") && \
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -I../../include -DCNR_TAIL_STAMPS -c tail.hip -o ../../tools/exp/libs/tail_stamps.o && \
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -I../../include -DCNR_PREP_STAMPS -c fused_fwd.hip -o ../../tools/exp/libs/fused_fwd_stamps.o && \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -I../../include -fno-slp-vectorize -DCNR_TAIL_STAMPS -c tail.hip -o ../../tools/exp/libs/tail_stamps.o && \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -I../../include -fno-slp-vectorize -DCNR_PREP_STAMPS -c fused_fwd.hip -o ../../tools/exp/libs/fused_fwd_stamps.o && \
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/exp/libs/libcnr_stamps.so $objs ../../tools/exp/libs/tail_stamps.o ../../tools/exp/libs/fused_fwd_stamps.o
