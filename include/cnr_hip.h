@@ -485,7 +485,7 @@ int cnr_step_grad(const float* theta, float* grad, int64_t class_stride, int64_t
 /* Same contract and results as cnr_field_bwd, ONE field kernel + the record reduction: a workgroup is four chain waves that
  * run forward recompute + data-gradient chain + PE backward for one 32-sample tile each, plus four waves that own the
  * weight-gradient accumulators and consume the chain waves' per-layer images behind a workgroup barrier -- eight waves, two
- * per SIMD (csrc/fused_bwd_pipe8.hip).  chain_waves must be 4 (the 4-wave pipelines with 2 / 3 chain waves of rounds 1-2 are
+ * per SIMD (csrc/fused_bwd_pipe8_kernel.h).  chain_waves must be 4 (the 4-wave pipelines with 2 / 3 chain waves of rounds 1-2 are
  * gone; the parameter stays in the signature).  max_blocks / workspace as above.
  * Class-major rows, up to 15 per class, stay on this path -- their bias-row sums travel in the records (and in rows_fix);
  * anything else (no ray_row, more rows) is handed to cnr_field_bwd (rows_fix / skip_reduce must then be NULL / 0). */

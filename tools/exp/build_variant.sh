@@ -1,6 +1,7 @@
 #!/bin/bash
 # tools/exp/libs/libcnr_<name>.so: the library with ONE translation unit rebuilt with extra flags (an A/B arm for
 # tools/exp/ab_step.py: CNR_HIP_LIB=tools/exp/libs/libcnr_<name>.so).  usage: build_variant.sh <name> <file.hip> <flags...>
+# (the 8-wave kernel lives in fused_bwd_pipe8_kernel.h: configs[1]'s one-launch instantiation is in fused_bwd_pipe8_w0.hip)
 set -e
 name=$1; file=$2; shift 2
 cd "$(dirname "$0")/../../category-nerf-reconstruction-official_amd/csrc"
