@@ -140,6 +140,7 @@ __device__ __forceinline__ f16v bias_acc(const float* __restrict__ b, int w, int
 }
 // copy a [TS][128] f16 image (stride ST_X) to global rows [m0, m0 + TS) of an (M, 128) f16 array, 16 bytes per thread and trip
 __device__ __forceinline__ void image_to_global(const unsigned char* img, _Float16* __restrict__ dst, int m0, int M) {
+#pragma unroll
   for (int i = threadIdx.x; i < TS * 16; i += 256) {
     const int row = i >> 4, ch = i & 15;
     if (m0 + row < M)
@@ -147,13 +148,26 @@ __device__ __forceinline__ void image_to_global(const unsigned char* img, _Float
           *reinterpret_cast<const f4*>(img + row * ST_X + ch * 16);
   }
 }
-__device__ __forceinline__ void global_to_image(unsigned char* img, const _Float16* __restrict__ src, int m0, int M) {
-  for (int i = threadIdx.x; i < TS * 16; i += 256) {
-    const int row = i >> 4, ch = i & 15;
-    f4 v = {0.f, 0.f, 0.f, 0.f};
-    if (m0 + row < M)
-      v = *reinterpret_cast<const f4*>(reinterpret_cast<const unsigned char*>(src + (size_t)(m0 + row) * BH) + ch * 16);
-    *reinterpret_cast<f4*>(img + row * ST_X + ch * 16) = v;
+// The opposite copy in two halves, so that the rows' round trip runs under the layer step in front of it: image_fetch issues this
+// thread's two 16-byte loads (TS x 16 pieces over 256 threads), image_commit stores them.  (As one loop the compiler kept the two
+// trips serial -- load, wait, store, load, wait, store: two dependent memory round trips per layer step of the backward.)
+struct ImgRows { f4 v[TS * 16 / 256]; };
+__device__ __forceinline__ ImgRows image_fetch(const _Float16* __restrict__ src, int m0, int M) {
+  ImgRows r;
+#pragma unroll
+  for (int t = 0; t < TS * 16 / 256; ++t) {
+    const int i = threadIdx.x + 256 * t, row = i >> 4, ch = i & 15;
+    const int rc = m0 + row < M ? m0 + row : M - 1;
+    r.v[t] = *reinterpret_cast<const f4*>(reinterpret_cast<const unsigned char*>(src + (size_t)rc * BH) + ch * 16);
+  }
+  return r;
+}
+__device__ __forceinline__ void image_commit(unsigned char* img, const ImgRows& r, int m0, int M) {
+#pragma unroll
+  for (int t = 0; t < TS * 16 / 256; ++t) {
+    const int i = threadIdx.x + 256 * t, row = i >> 4, ch = i & 15;
+    const f4 z = {0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f4*>(img + row * ST_X + ch * 16) = m0 + row < M ? r.v[t] : z;
   }
 }
 
@@ -192,7 +206,9 @@ __device__ __forceinline__ void pe_images(const float* __restrict__ pts, const f
 
 // The weight fragments of a k-range (hi, and for the geometry branch the residual) as a register set, loaded from global / L2 right
 // in front of their use.  (Loading them a layer ahead was measured: 256 instead of 82 registers, two instead of three workgroups
-// per CU, forward 25.5 instead of 20.5 us -- the neighbours on the CU hide the round trip better than a prefetch does.)
+// per CU, forward 25.5 instead of 20.5 us -- the neighbours on the CU hide the round trip better than a prefetch does.  Requesting
+// the next layer's set behind this layer's products, in front of its epilogue and barrier -- one set at a time, 138 registers --
+// changed nothing here either: 28.7 against 28.3 us eager; the backward, whose sets are half the size, gains from it.)
 template <int NS, bool GEO>
 struct Frags {
   h8 wh[NS], wl[GEO ? NS : 1];
@@ -438,7 +454,10 @@ __global__ __launch_bounds__(256, 2) void bg_bwd_kernel(BgBwdArgs a) {
     tpos[3 * s + 2] = a.pts[(size_t)mc * 3 + 2] * a.inv_scale;
   }
   BFrags bf;
-  global_to_image(Aim, a.act + 4 * MH, m0, M);   // a5
+  // activation images: the rows of layer step k + 1 are requested when step k's have been stored, a whole step ahead of their use
+  ImgRows nx = image_fetch(a.act + 4 * MH, m0, M);
+  image_commit(Aim, nx, m0, M);                   // a5
+  nx = image_fetch(a.act + 3 * MH, m0, M);
   __syncthreads();
   // ---- out_color: weight / bias gradient on the VALU (3 x 128 + 3), d a5 on the matrix core -----------------------------
   {
@@ -468,12 +487,14 @@ __global__ __launch_bounds__(256, 2) void bg_bwd_kernel(BgBwdArgs a) {
       acc[half] = MFMA(wt, x, acc[half]);
     }
   }
+  // (every layer step's transposed fragments are requested HERE, behind the previous step's products and in front of its mask /
+  //  barrier / store phase: the register set is free at that point and the L2 round trip runs under that phase)
+  bf.load(a.packed, bwd_base(L_CL) + 8 * w, lane);
   mask_tile(D0, Aim, c, w, h, acc);      // dPre5
   __syncthreads();
   image_to_global(D0, a.dpre + 4 * MH, m0, M);
   // ---- color_linear^T: d a4 (colour part) + d e2 ; + out_alpha ------------------------------------------------------------
   zero_tile(acc);
-  bf.load(a.packed, bwd_base(L_CL) + 8 * w, lane);
   bf.mma(D0, lane, acc);
   if (w < 2) {
     zero_tile(ae);
@@ -487,7 +508,9 @@ __global__ __launch_bounds__(256, 2) void bg_bwd_kernel(BgBwdArgs a) {
         if (q < BE2P) DE2[(c + 32 * half) * BE2P + q] = ae[half][reg];
       }
   }
-  global_to_image(Aim, a.act + 3 * MH, m0, M);   // a4 (the a5 image was last read before the barrier above)
+  bf.load(a.packed, bwd_base(L_M2) + 8 * w, lane);
+  image_commit(Aim, nx, m0, M);                   // a4 (the a5 image was last read before the barrier above)
+  nx = image_fetch(a.act + 2 * MH, m0, M);
   __syncthreads();
   {
     // out_alpha: dW = sum_s (10 d sigma_s) a4[s][f], db = sum_s 10 d sigma_s ; d a4 += w_alpha 10 d sigma
@@ -512,39 +535,40 @@ __global__ __launch_bounds__(256, 2) void bg_bwd_kernel(BgBwdArgs a) {
   image_to_global(D1, a.dpre + 3 * MH, m0, M);
   // ---- mid2^T -> dPre3 ---------------------------------------------------------------------------------------------------
   zero_tile(acc);
-  bf.load(a.packed, bwd_base(L_M2) + 8 * w, lane);
   bf.mma(D1, lane, acc);
-  global_to_image(Aim, a.act + 2 * MH, m0, M);   // a3 (the a4 image was last read before the barrier above)
+  bf.load(a.packed, bwd_base(L_CAT) + 8 * w, lane);
+  image_commit(Aim, nx, m0, M);                   // a3 (the a4 image was last read before the barrier above)
+  nx = image_fetch(a.act + 1 * MH, m0, M);
   __syncthreads();
   mask_tile(D0, Aim, c, w, h, acc);
   __syncthreads();
   image_to_global(D0, a.dpre + 2 * MH, m0, M);
   // ---- cat_layer^T -> d a2, d e1 -------------------------------------------------------------------------------------------
   zero_tile(acc);
-  bf.load(a.packed, bwd_base(L_CAT) + 8 * w, lane);
   bf.mma(D0, lane, acc);
   if (w < 3) {
     zero_tile(ae);
     bf.load(a.packed, bwd_base(L_CAT) + 8 * (4 + w), lane);
     bf.mma(D0, lane, ae);
   }
-  global_to_image(Aim, a.act + 1 * MH, m0, M);   // a2
+  bf.load(a.packed, bwd_base(L_M1) + 8 * w, lane);
+  image_commit(Aim, nx, m0, M);                   // a2
+  nx = image_fetch(a.act + 0 * MH, m0, M);
   __syncthreads();
   mask_tile(D1, Aim, c, w, h, acc);      // dPre2
   __syncthreads();
   image_to_global(D1, a.dpre + 1 * MH, m0, M);
   // ---- mid1^T -> dPre1 -----------------------------------------------------------------------------------------------------
   zero_tile(acc);
-  bf.load(a.packed, bwd_base(L_M1) + 8 * w, lane);
   bf.mma(D1, lane, acc);
-  global_to_image(Aim, a.act + 0 * MH, m0, M);   // a1
+  if (w < 3) bf.load(a.packed, bwd_base(L_IN) + 8 * w, lane);
+  image_commit(Aim, nx, m0, M);                   // a1
   __syncthreads();
   mask_tile(D0, Aim, c, w, h, acc);
   __syncthreads();
   image_to_global(D0, a.dpre + 0 * MH, m0, M);
   // ---- in_layer^T -> d e1 (on top of cat_layer's) --------------------------------------------------------------------------
   if (w < 3) {
-    bf.load(a.packed, bwd_base(L_IN) + 8 * w, lane);
     bf.mma(D0, lane, ae);
 #pragma unroll
     for (int half = 0; half < NH; ++half)
