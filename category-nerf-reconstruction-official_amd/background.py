@@ -83,6 +83,10 @@ class BackgroundStep:
         self.cursor = 0
         if self.precision == "fused":
             _C.call("cnr_slice_maxdepth", self.pool["depth"], self.perm, self.pool_rows, 1, self.R, self.n_slices, self.slice_max)
+            # ... and its mask counts (src/render_rays.py:66-95 are pool-row properties): the composite / loss launch reads its
+            # slice's entry instead of every block counting the batch's 1200 labels first
+            _C.call("cnr_slice_maskcounts", self.pool["rgbs"], self.pool["depth"], self.perm, self.pool_rows, 1, self.R,
+                    self.n_slices, float(self.cfg.min_depth), self.counts_tab)
 
     def _body(self):
         """sample -> PE -> OccupancyMap -> composite + losses -> backward -> AdamW -> advance (all stream-ordered)."""
@@ -125,6 +129,7 @@ class BackgroundStep:
         self.gscale = float(2 ** round(math.log2(max(self.R, 2))))      # power-of-two loss scale of the f16 gradient chain
         self.n_slices = self.pool_rows // self.R
         self.slice_max = torch.zeros(1, self.n_slices, device=dev)
+        self.counts_tab = torch.zeros(self.n_slices, 2, 4, device=dev)
         self._packed_for = None          # version of self.flat the fragment images were packed from
         f = lambda *sh, dt=torch.float32: torch.empty(*sh, device=dev, dtype=dt)
         self.fb = dict(packed=f(int(lib.cnr_bg_pack_bytes()), dt=torch.uint8), sigma=f(1, self.R, self.S),
@@ -168,7 +173,7 @@ class BackgroundStep:
         _C.call("cnr_bg_forward", b["pts"], self.flat, o["packed"], scale, M, o["sigma"], o["rgbs"], o["act"], o["eimg"])
         _C.call("cnr_render_loss", o["sigma"], o["rgbs"], b["z"], b["gt_depth"], b["gt_rgb"], b["labels"], b["depth_mask"],
                 5.0, 10.0, self.gscale, o["dsig"], o["drgb"], o["depth"], o["var"], o["rgb"], o["opa"], 1, self.R, self.S,
-                o["rl_ws"], o["rl_ws"].numel(), None, None)
+                o["rl_ws"], o["rl_ws"].numel(), self.counts_tab, self.d_state)
         _C.call("cnr_bg_backward", b["pts"], self.flat, o["packed"], scale, M, o["dsig"], o["drgb"], o["rgbs"], o["act"],
                 o["dpre"], o["records"], self.d_state, self.R)
         _C.call("cnr_bg_dw", o["act"], o["dpre"], o["eimg"], M, self.dw_chunk, o["partials"])
