@@ -81,7 +81,9 @@ SIGNATURES = {
     "cnr_bg_pack": [_vp, _vp, _vp],
     "cnr_bg_forward": [_vp, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp],
     "cnr_bg_backward": [_vp, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
-    "cnr_bg_dw": [_vp, _vp, _vp, _i, _i, _vp, _vp],
+    "cnr_bg_dw": [_vp, _vp, _vp, _i, _i, _vp, _vp, _i64, _vp],
+    "cnr_bg_backward_render_workspace_bytes": [_i],
+    "cnr_bg_backward_render": [_vp, _vp],
     "cnr_bg_tail": [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _f, _f, _f, _f, _f, _f, _vp, _i64, _vp, _vp, _i, _vp, _vp, _vp],
 }
 # The three launches of the fused trainer's step take ONE versioned struct (include/cnr_hip.h: struct_size and abi_version
@@ -114,6 +116,12 @@ STRUCTS = {
         ("depth", _vp), ("var", _vp), ("rgb", _vp), ("opacity", _vp), ("C", _i32), ("R", _i32), ("S", _i32),
         ("rows_per_class", _i32), ("max_blocks", _i32), ("records", _vp), ("records_bytes", _i64), ("loss_workspace", _vp),
         ("loss_workspace_bytes", _i64), ("B_stride", _i64), ("rows_fix", _vp), ("clamp_flags", _vp)],
+    "cnr_bg_backward_render": [
+        ("pts", _vp), ("theta", _vp), ("packed", _vp), ("scale", _f), ("R", _i32), ("S", _i32), ("sigma", _vp), ("rgb", _vp),
+        ("z", _vp), ("gt_depth", _vp), ("gt_rgb", _vp), ("labels", _vp), ("depth_mask", _vp), ("counts_tab", _vp),
+        ("d_state", _vp), ("color_scaling", _f), ("opacity_scaling", _f), ("grad_scale", _f), ("act", _vp), ("dpre", _vp),
+        ("records", _vp), ("depth", _vp), ("var", _vp), ("rgb_render", _vp), ("opacity", _vp), ("d_sigma", _vp), ("d_rgb", _vp), ("loss_workspace", _vp),
+        ("loss_workspace_bytes", _i64)],
 }
 _struct_types = {}
 
@@ -127,7 +135,7 @@ def struct_type(name):
 
 
 _RESTYPE64 = {"cnr_pack_bytes", "cnr_pack_lo_bytes", "cnr_field_bwd_workspace_bytes", "cnr_field_bwd_rows_table_bytes", "cnr_render_loss_workspace_bytes",
-              "cnr_dense_bwd_workspace_bytes", "cnr_field_fwd_render_workspace_bytes", "cnr_field_train_workspace_bytes", "cnr_pack_fp8_bytes", "cnr_bg_pack_bytes"}
+              "cnr_dense_bwd_workspace_bytes", "cnr_field_fwd_render_workspace_bytes", "cnr_field_train_workspace_bytes", "cnr_pack_fp8_bytes", "cnr_bg_pack_bytes", "cnr_bg_backward_render_workspace_bytes"}
 
 _lib = None
 _double = None

@@ -122,6 +122,9 @@ class BackgroundStep:
         assert [tuple(p.shape) for p in self.trainer.pe.parameters()] == [(21, 3)]
         self.S = self.n1 + self.n2
         M = self.M = self.R * self.S
+        # composite / losses inside the backward launch (cnr_bg_backward_render: a ray on one wave, S <= 64); CNR_BG_FUSE_RENDER=0:
+        # the separate cnr_render_loss launch
+        self.fuse_render = self.S <= 64 and __import__('os').environ.get('CNR_BG_FUSE_RENDER', '1') != '0'
         # samples per weight-gradient workgroup: 384 -> 5 layers x 44 chunks = 220 workgroups, one round on 256 CUs (measured 17.5 us;
         # 256: 20.2, 512: 21.2)
         self.dw_chunk = int(__import__('os').environ.get('CNR_BG_DW_CHUNK', '384'))
@@ -137,7 +140,8 @@ class BackgroundStep:
                        dpre=f(5, M, 128, dt=torch.float16), records=f(self.nblk, int(lib.cnr_bg_record_floats())),
                        partials=f(self.nchunk, n), dsig=f(1, self.R, self.S), drgb=f(1, self.R, self.S, 3),
                        depth=f(1, self.R), var=f(1, self.R), rgb=f(1, self.R, 3), opa=f(1, self.R),
-                       rl_ws=torch.zeros(_C.render_loss_workspace_bytes(1, self.R), device=dev, dtype=torch.uint8),
+                       rl_ws=torch.zeros(max(_C.render_loss_workspace_bytes(1, self.R),
+                                             int(lib.cnr_bg_backward_render_workspace_bytes(M))), device=dev, dtype=torch.uint8),
                        losses=torch.zeros(3, 1, device=dev), flags=torch.zeros(1, device=dev, dtype=torch.int32))
 
     @property
@@ -171,15 +175,26 @@ class BackgroundStep:
                             max_bound_slices=self.n_slices)
         scale, M = float(self.trainer.pe._scale), self.M
         _C.call("cnr_bg_forward", b["pts"], self.flat, o["packed"], scale, M, o["sigma"], o["rgbs"], o["act"], o["eimg"])
-        _C.call("cnr_render_loss", o["sigma"], o["rgbs"], b["z"], b["gt_depth"], b["gt_rgb"], b["labels"], b["depth_mask"],
-                5.0, 10.0, self.gscale, o["dsig"], o["drgb"], o["depth"], o["var"], o["rgb"], o["opa"], 1, self.R, self.S,
-                o["rl_ws"], o["rl_ws"].numel(), self.counts_tab, self.d_state)
-        _C.call("cnr_bg_backward", b["pts"], self.flat, o["packed"], scale, M, o["dsig"], o["drgb"], o["rgbs"], o["act"],
-                o["dpre"], o["records"], self.d_state, self.R)
-        _C.call("cnr_bg_dw", o["act"], o["dpre"], o["eimg"], M, self.dw_chunk, o["partials"])
+        if self.fuse_render:
+            # composite + losses + their gradient in front of the backward chain, in the backward's launch (one launch and the
+            # d sigma / d colour round trip less); the step state then moves in the weight-gradient launch
+            _C.call_struct("cnr_bg_backward_render", pts=b["pts"], theta=self.flat, packed=o["packed"], scale=scale, R=self.R,
+                           S=self.S, sigma=o["sigma"], rgb=o["rgbs"], z=b["z"], gt_depth=b["gt_depth"], gt_rgb=b["gt_rgb"],
+                           labels=b["labels"], depth_mask=b["depth_mask"], counts_tab=self.counts_tab, d_state=self.d_state,
+                           color_scaling=5.0, opacity_scaling=10.0, grad_scale=self.gscale, act=o["act"], dpre=o["dpre"],
+                           records=o["records"], depth=o["depth"], var=o["var"], rgb_render=o["rgb"], opacity=o["opa"], d_sigma=None, d_rgb=None,
+                           loss_workspace=o["rl_ws"], loss_workspace_bytes=o["rl_ws"].numel())
+            _C.call("cnr_bg_dw", o["act"], o["dpre"], o["eimg"], M, self.dw_chunk, o["partials"], self.d_state, self.R)
+        else:
+            _C.call("cnr_render_loss", o["sigma"], o["rgbs"], b["z"], b["gt_depth"], b["gt_rgb"], b["labels"], b["depth_mask"],
+                    5.0, 10.0, self.gscale, o["dsig"], o["drgb"], o["depth"], o["var"], o["rgb"], o["opa"], 1, self.R, self.S,
+                    o["rl_ws"], o["rl_ws"].numel(), self.counts_tab, self.d_state)
+            _C.call("cnr_bg_backward", b["pts"], self.flat, o["packed"], scale, M, o["dsig"], o["drgb"], o["rgbs"], o["act"],
+                    o["dpre"], o["records"], self.d_state, self.R)
+            _C.call("cnr_bg_dw", o["act"], o["dpre"], o["eimg"], M, self.dw_chunk, o["partials"], None, 0)
         _C.call("cnr_bg_tail", self.flat, self.gflat, self.exp_avg, self.exp_avg_sq, o["partials"], self.nchunk, o["records"],
                 self.nblk, self.gscale, cfg.learning_rate, 0.9, 0.999, 1e-8, cfg.weight_decay, self.d_state, -1, o["packed"],
-                o["rl_ws"], self.R, o["losses"], o["flags"])
+                o["rl_ws"], 0 if self.fuse_render else self.R, o["losses"], o["flags"])
         # (self.losses / self.loss are views of / derived from o["losses"]: see the properties -- no torch kernel in the step)
 
     def repack(self):

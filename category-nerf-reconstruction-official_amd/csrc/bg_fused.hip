@@ -379,6 +379,11 @@ struct BgBwdArgs {
   _Float16* dpre;                      // 5 x (M,128): scaled pre-activation gradients of in_layer, mid1, cat, mid2, color_linear
   float* records;                      // (blocks, BG_REC)
   int64_t* d_state; int64_t add_rows;  // d_state != NULL: block 0 advances the step state (see cnr_bg_backward)
+  // RENDER (cnr_bg_backward_render): the composite, the losses and their gradient in front of the chain -- d_sigma / d_rgb unused
+  const float* sigma; const float* z; const float* gt_depth; const float* gt_rgb; const uint8_t* labels; const uint8_t* depth_mask;
+  const float* counts_tab; const int64_t* cursor; int R, S; float color_scaling, opacity_scaling, grad_scale;
+  float* depth_out; float* var_out; float* rgb_out; float* opacity_out; float* rl_partials;
+  float* d_sigma_out; float* d_rgb_out;   // optional: the loss gradient per sample, as cnr_render_loss writes it
 };
 
 // the 8 k-steps (128 output features) of W^T block `fb`; acc[half] += W^T x dPre image
@@ -418,6 +423,15 @@ __device__ __forceinline__ void zero_tile(f16v (&acc)[NH]) {
     for (int i = 0; i < 16; ++i) acc[half][i] = 0.0f;
 }
 
+// dPre of out_color for one colour channel, d rgb * rgb (1 - rgb), rounded to fp32 and THEN to f16 in both forms of the kernel
+// (gradient from memory / from the in-kernel composite): left alone, the compiler turned the last product and the conversion
+// into one v_fma_mixlo_f16 -- a single rounding -- in one form and not in the other, three samples of 3360 one f16 ulp apart.
+__device__ __forceinline__ _Float16 oc_dpre(float d, float r) {
+  float v = d * r * (1.0f - r);
+  asm volatile("" : "+v"(v));   // no instruction: the product exists as an fp32 value
+  return (_Float16)v;
+}
+template <bool RENDER>
 __global__ __launch_bounds__(256, 2) void bg_bwd_kernel(BgBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* D0 = smem;
@@ -428,27 +442,79 @@ __global__ __launch_bounds__(256, 2) void bg_bwd_kernel(BgBwdArgs a) {
   unsigned char* OCimg = reinterpret_cast<unsigned char*>(DE2 + TS * BE2P);   // [TS][16] f16 (+ pad): dPre of out_color in columns 0..2
   float* dsg = reinterpret_cast<float*>(OCimg + TS * ST_OC);                   // [TS] 10 x scaled d sigma
   float* tpos = dsg + TS;                                                      // [TS][3] t = x / scale
+  float* lsum = tpos + 3 * TS;                                                 // [4][3] RENDER: the waves' loss terms
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
   const int m0 = blockIdx.x * TS, M = a.M;
   const float* th = a.theta;
   const size_t MH = (size_t)M * BH;
   float* rec = a.records + (size_t)blockIdx.x * BG_REC;
   // the step state moves here: the sampler (which reads the cursor) ran earlier in the step, the optimiser launch (which reads
-  // the step count) comes later -- no launch of its own for three integer adds
-  if (a.d_state && blockIdx.x == 0 && threadIdx.x == 0) { a.d_state[0] += a.add_rows; a.d_state[1] += 1; a.d_state[2] += 1; }
-  // ---- upstream: dPre of out_color = d rgb * rgb (1 - rgb); 10 x d sigma; sample positions ------------------------------
-  if (threadIdx.x < TS) {
+  // the step count) comes later -- no launch of its own for three integer adds.  (RENDER: every block reads the cursor for its
+  // mask-count entry, so the state moves one launch later, in cnr_bg_dw.)
+  if (!RENDER && a.d_state && blockIdx.x == 0 && threadIdx.x == 0) { a.d_state[0] += a.add_rows; a.d_state[1] += 1; a.d_state[2] += 1; }
+  // the f16 chain needs |10 d sigma| within range: clipped like the category kernel's (include/cnr_hip.h, clamp_flags)
+  auto clip10 = [](float v) { return fminf(fmaxf(v, -8192.0f), 8192.0f) * 10.0f; };
+  if constexpr (RENDER) {
+    // ---- a11-a15 for the rays this tile's samples belong to (src/render_rays.py:3-7,25-33,46-95; src/loss.py:18-74): one wave
+    // per ray, lane = sample (S <= 64), cnr_render_loss's arithmetic (render_common.h: ray_small).  A ray that straddles two tiles
+    // is composited by both; the tile that holds its FIRST sample accounts for its renders and loss terms.
+    const int S = a.S;
+    const float* t = a.counts_tab + (size_t)(a.cursor ? a.cursor[0] / a.R : 0) * 8;      // (slices, C + 1 = 2, 4), C = 1
+    const float wd = t[4] != 0.f ? 0.f : 1.0f / (t[0] + 1e-10f), wc = t[5] != 0.f ? 0.f : 1.0f / (t[1] + 1e-10f),
+                wo = t[6] != 0.f ? 0.f : 1.0f / (t[2] + 1e-10f);
+    if (threadIdx.x < TS) {   // columns 3..15 of the out_color image, rows beyond M, sample positions
+      const int s = threadIdx.x, m = m0 + s;
+      _Float16* o = reinterpret_cast<_Float16*>(OCimg + s * ST_OC);
+#pragma unroll
+      for (int j = 3; j < 16; ++j) o[j] = (_Float16)0.0f;
+      if (m >= M) { o[0] = o[1] = o[2] = (_Float16)0.0f; dsg[s] = 0.0f; }
+      const int mc = m < M ? m : M - 1;
+      tpos[3 * s + 0] = a.pts[(size_t)mc * 3 + 0] * a.inv_scale; tpos[3 * s + 1] = a.pts[(size_t)mc * 3 + 1] * a.inv_scale;
+      tpos[3 * s + 2] = a.pts[(size_t)mc * 3 + 2] * a.inv_scale;
+    }
+    const int mlast = (m0 + TS < M ? m0 + TS : M) - 1;
+    float ld = 0.f, lc = 0.f, lo = 0.f;
+    for (int ray = m0 / S + w; ray <= mlast / S; ray += 4) {   // wave-uniform
+      const size_t base = (size_t)ray * S;
+      const cnr_rl::RayOut q = cnr_rl::ray_small(a.sigma, a.rgb, a.z, base, S, lane, a.gt_depth[ray], a.gt_rgb[ray * 3 + 0],
+                                                 a.gt_rgb[ray * 3 + 1], a.gt_rgb[ray * 3 + 2], a.labels[ray], a.depth_mask[ray],
+                                                 wd, wc, wo, a.color_scaling, a.opacity_scaling, a.grad_scale);
+      const bool owner = (int64_t)base >= m0;                  // the ray's first sample lies in this tile
+      if (owner) {
+        ld += q.ld; lc += q.lc; lo += q.lo;
+        if (lane == 0) {
+          if (a.depth_out) a.depth_out[ray] = q.sd;
+          if (a.var_out) a.var_out[ray] = q.sv;
+          if (a.opacity_out) a.opacity_out[ray] = q.so;
+          if (a.rgb_out) { a.rgb_out[ray * 3 + 0] = q.sr; a.rgb_out[ray * 3 + 1] = q.sg; a.rgb_out[ray * 3 + 2] = q.sb; }
+        }
+      }
+      const int64_t m = (int64_t)base + lane;
+      if (q.live && m >= m0 && m <= mlast) {
+        const int s = (int)(m - m0);
+        const float* cp = a.rgb + (size_t)m * 3;
+        _Float16* o = reinterpret_cast<_Float16*>(OCimg + s * ST_OC);
+        o[0] = oc_dpre(q.dc0, cp[0]); o[1] = oc_dpre(q.dc1, cp[1]); o[2] = oc_dpre(q.dc2, cp[2]);
+        dsg[s] = clip10(q.dsig);
+        if (a.d_sigma_out) a.d_sigma_out[m] = q.dsig;
+        if (a.d_rgb_out) { float* dc = a.d_rgb_out + (size_t)m * 3; dc[0] = q.dc0; dc[1] = q.dc1; dc[2] = q.dc2; }
+      }
+    }
+    if (lane == 0) { lsum[3 * w + 0] = ld; lsum[3 * w + 1] = lc; lsum[3 * w + 2] = lo; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {   // the normalisers and the empty-mask bits (cnr_rl::finish_class reads them)
+      float* hdr = a.rl_partials + (size_t)gridDim.x * 3;
+      hdr[0] = wd; hdr[1] = wc; hdr[2] = wo;
+      hdr[3] = (float)((t[4] != 0.f ? 2 : 0) | (t[5] != 0.f ? 4 : 0) | (t[6] != 0.f ? 8 : 0));
+    }
+  } else if (threadIdx.x < TS) {
+    // ---- upstream: dPre of out_color = d rgb * rgb (1 - rgb); 10 x d sigma; sample positions ----------------------------
     const int s = threadIdx.x, m = m0 + s;
     const bool ok = m < M;
     _Float16* o = reinterpret_cast<_Float16*>(OCimg + s * ST_OC);
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      float v = 0.0f;
-      if (ok && j < 3) { const float r = a.rgb[(size_t)m * 3 + j]; v = a.d_rgb[(size_t)m * 3 + j] * r * (1.0f - r); }
-      o[j] = (_Float16)v;
-    }
-    // the f16 chain needs |10 d sigma| within range: clipped like the category kernel's (include/cnr_hip.h, clamp_flags)
-    dsg[s] = ok ? fminf(fmaxf(a.d_sigma[m], -8192.0f), 8192.0f) * 10.0f : 0.0f;
+    for (int j = 0; j < 16; ++j)
+      o[j] = (ok && j < 3) ? oc_dpre(a.d_rgb[(size_t)m * 3 + j], a.rgb[(size_t)m * 3 + j]) : (_Float16)0.0f;
+    dsg[s] = ok ? clip10(a.d_sigma[m]) : 0.0f;
     const int mc = ok ? m : M - 1;
     tpos[3 * s + 0] = a.pts[(size_t)mc * 3 + 0] * a.inv_scale; tpos[3 * s + 1] = a.pts[(size_t)mc * 3 + 1] * a.inv_scale;
     tpos[3 * s + 2] = a.pts[(size_t)mc * 3 + 2] * a.inv_scale;
@@ -459,6 +525,11 @@ __global__ __launch_bounds__(256, 2) void bg_bwd_kernel(BgBwdArgs a) {
   image_commit(Aim, nx, m0, M);                   // a5
   nx = image_fetch(a.act + 3 * MH, m0, M);
   __syncthreads();
+  if constexpr (RENDER) {
+    if (threadIdx.x < 3)
+      a.rl_partials[(size_t)blockIdx.x * 3 + threadIdx.x] =
+          ((lsum[threadIdx.x] + lsum[3 + threadIdx.x]) + lsum[6 + threadIdx.x]) + lsum[9 + threadIdx.x];
+  }
   // ---- out_color: weight / bias gradient on the VALU (3 x 128 + 3), d a5 on the matrix core -----------------------------
   {
     const int f = threadIdx.x & 127, jj = threadIdx.x >> 7;   // outputs j = jj and jj + 2
@@ -601,7 +672,7 @@ __global__ __launch_bounds__(256, 2) void bg_bwd_kernel(BgBwdArgs a) {
     }
   }
 }
-constexpr int BG_BWD_LDS = 3 * XIMG + TS * (BE1P + BE2P) * 4 + TS * ST_OC + TS * 4 + TS * 12 + 64;
+constexpr int BG_BWD_LDS = 3 * XIMG + TS * (BE1P + BE2P) * 4 + TS * ST_OC + TS * 4 + TS * 12 + 64;   // (+ 12 floats of loss terms inside the 64)
 
 // ------------------------------------------------------------------------------------------------------------------------
 // weight gradients of the five 128-wide layers: dW[n][k] = sum_m dPre[m][n] X[m][k], db[n] = sum_m dPre[m][n]
@@ -628,6 +699,7 @@ __device__ __forceinline__ h8 tr_frag_b(const unsigned char* img, int stride, in
 struct BgDwArgs {
   const _Float16* act; const _Float16* dpre; const _Float16* eimg; int M; int chunk;   // chunk: samples per block (multiple of 64)
   float* partials;                                                                       // (chunks, BG_NPARAM)
+  int64_t* d_state; int64_t add_rows;      // d_state != NULL: block (0, 0) advances the step state (see cnr_bg_dw)
 };
 // tile row strides (bytes), = 48 and 16 mod 64 dwords: the four rows a transposing read's 32 lanes touch (64 bytes each) then
 // sit in four different quarters of the 64 banks (272 / 464 bytes put them 4 / 52 dwords apart: 2- to 4-way conflicts)
@@ -737,6 +809,7 @@ __device__ __forceinline__ void dw_layer(const BgDwArgs& a, unsigned char* smem)
 }
 __global__ __launch_bounds__(256, 1) void bg_dw_kernel(BgDwArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (a.d_state && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { a.d_state[0] += a.add_rows; a.d_state[1] += 1; a.d_state[2] += 1; }
   switch (blockIdx.x) {
     case 0: dw_layer<L_CAT>(a, smem); break;       // heaviest layer first in the dispatch order
     case 1: dw_layer<L_CL>(a, smem); break;
@@ -883,6 +956,9 @@ extern "C" int cnr_bg_param_count(void) { return BG_NPARAM; }
 extern "C" int cnr_bg_blocks(int M) { return M > 0 ? (M + TS - 1) / TS : 0; }
 extern "C" int cnr_bg_dw_chunks(int M, int chunk) { return (M > 0 && chunk > 0) ? (M + chunk - 1) / chunk : 0; }
 extern "C" int cnr_bg_record_floats(void) { return BG_REC; }
+extern "C" int64_t cnr_bg_backward_render_workspace_bytes(int M) {
+  return M > 0 ? ((int64_t)cnr_bg_blocks(M) * 3 + 4) * (int64_t)sizeof(float) : 0;
+}
 
 extern "C" int cnr_bg_pack(const float* theta, void* packed, void* stream) {
   if (!theta || !packed) return CNR_E_ARG;
@@ -912,22 +988,51 @@ extern "C" int cnr_bg_backward(const float* pts, const float* theta, const void*
     return CNR_E_ARG;
   if (((uintptr_t)packed & 15) != 0 || ((uintptr_t)act & 15) != 0 || ((uintptr_t)dpre & 15) != 0) return CNR_E_ALIGN;
   static cnr::DeviceOnce once;
-  const int er = cnr::set_max_dynamic_lds(once, (const void*)bg_bwd_kernel, BG_BWD_LDS);
+  const int er = cnr::set_max_dynamic_lds(once, (const void*)bg_bwd_kernel<false>, BG_BWD_LDS);
   if (er) return er;
-  BgBwdArgs a{pts, theta, (const unsigned char*)packed, 1.0f / scale, M, d_sigma, d_rgb, rgb, (const _Float16*)act,
-              (_Float16*)dpre, records, d_state, add_rows};
-  hipLaunchKernelGGL(bg_bwd_kernel, dim3((unsigned)cnr_bg_blocks(M)), dim3(256), BG_BWD_LDS, (hipStream_t)stream, a);
+  BgBwdArgs a{};
+  a.pts = pts; a.theta = theta; a.packed = (const unsigned char*)packed; a.inv_scale = 1.0f / scale; a.M = M;
+  a.d_sigma = d_sigma; a.d_rgb = d_rgb; a.rgb = rgb; a.act = (const _Float16*)act; a.dpre = (_Float16*)dpre;
+  a.records = records; a.d_state = d_state; a.add_rows = add_rows;
+  hipLaunchKernelGGL(bg_bwd_kernel<false>, dim3((unsigned)cnr_bg_blocks(M)), dim3(256), BG_BWD_LDS, (hipStream_t)stream, a);
   CNR_LAUNCH_CHECK();
   return CNR_OK;
 }
 
-extern "C" int cnr_bg_dw(const void* act, const void* dpre, const void* eimg, int M, int chunk, float* partials, void* stream) {
+extern "C" int cnr_bg_backward_render(const cnr_bg_backward_render_args* p, void* stream) {
+  if (!p || p->struct_size != sizeof(cnr_bg_backward_render_args) || p->abi_version != CNR_ABI_VERSION) return CNR_E_ARG;
+  if (!p->pts || !p->theta || !p->packed || !p->sigma || !p->rgb || !p->z || !p->gt_depth || !p->gt_rgb || !p->labels ||
+      !p->depth_mask || !p->counts_tab || !p->act || !p->dpre || !p->records || !p->loss_workspace || p->R <= 0 ||
+      p->S <= 0 || !(p->scale > 0.f))
+    return CNR_E_ARG;
+  if (p->S > 64 || (int64_t)p->R * p->S > 0x7fffffff) return CNR_E_SHAPE;
+  const int M = p->R * p->S;
+  if (p->loss_workspace_bytes < cnr_bg_backward_render_workspace_bytes(M)) return CNR_E_ARG;
+  if (((uintptr_t)p->packed & 15) != 0 || ((uintptr_t)p->act & 15) != 0 || ((uintptr_t)p->dpre & 15) != 0) return CNR_E_ALIGN;
+  static cnr::DeviceOnce once;
+  const int er = cnr::set_max_dynamic_lds(once, (const void*)bg_bwd_kernel<true>, BG_BWD_LDS);
+  if (er) return er;
+  BgBwdArgs a{};
+  a.pts = p->pts; a.theta = p->theta; a.packed = (const unsigned char*)p->packed; a.inv_scale = 1.0f / p->scale; a.M = M;
+  a.rgb = p->rgb; a.act = (const _Float16*)p->act; a.dpre = (_Float16*)p->dpre; a.records = p->records;
+  a.sigma = p->sigma; a.z = p->z; a.gt_depth = p->gt_depth; a.gt_rgb = p->gt_rgb; a.labels = p->labels;
+  a.depth_mask = p->depth_mask; a.counts_tab = p->counts_tab; a.cursor = p->d_state; a.R = p->R; a.S = p->S;
+  a.color_scaling = p->color_scaling; a.opacity_scaling = p->opacity_scaling; a.grad_scale = p->grad_scale;
+  a.depth_out = p->depth; a.var_out = p->var; a.rgb_out = p->rgb_render; a.opacity_out = p->opacity;
+  a.rl_partials = (float*)p->loss_workspace; a.d_sigma_out = p->d_sigma; a.d_rgb_out = p->d_rgb;
+  hipLaunchKernelGGL(bg_bwd_kernel<true>, dim3((unsigned)cnr_bg_blocks(M)), dim3(256), BG_BWD_LDS, (hipStream_t)stream, a);
+  CNR_LAUNCH_CHECK();
+  return CNR_OK;
+}
+
+extern "C" int cnr_bg_dw(const void* act, const void* dpre, const void* eimg, int M, int chunk, float* partials,
+                         int64_t* d_state, int64_t add_rows, void* stream) {
   if (!act || !dpre || !eimg || !partials || M <= 0 || chunk <= 0 || (chunk & 63) != 0) return CNR_E_ARG;
   if (((uintptr_t)act & 15) != 0 || ((uintptr_t)dpre & 15) != 0 || ((uintptr_t)eimg & 15) != 0) return CNR_E_ALIGN;
   static cnr::DeviceOnce once;
   const int er = cnr::set_max_dynamic_lds(once, (const void*)bg_dw_kernel, BG_DW_LDS);
   if (er) return er;
-  BgDwArgs a{(const _Float16*)act, (const _Float16*)dpre, (const _Float16*)eimg, M, chunk, partials};
+  BgDwArgs a{(const _Float16*)act, (const _Float16*)dpre, (const _Float16*)eimg, M, chunk, partials, d_state, add_rows};
   hipLaunchKernelGGL(bg_dw_kernel, dim3(5, (unsigned)cnr_bg_dw_chunks(M, chunk)), dim3(256), BG_DW_LDS, (hipStream_t)stream, a);
   CNR_LAUNCH_CHECK();
   return CNR_OK;
@@ -937,14 +1042,15 @@ extern "C" int cnr_bg_tail(float* theta, float* grad, float* exp_avg, float* exp
                            const float* records, int nrec, float grad_scale, float lr, float beta1, float beta2, float eps,
                            float weight_decay, int64_t* d_state, int64_t add_rows, void* packed, const void* rl_workspace,
                            int R, float* losses, int32_t* flags, void* stream) {
-  if (rl_workspace && (!losses || !flags || R <= 0)) return CNR_E_ARG;
+  if (rl_workspace && (!losses || !flags || R < 0)) return CNR_E_ARG;
   if (((uintptr_t)packed & 15) != 0) return CNR_E_ALIGN;
   if (!theta || !grad || !exp_avg || !exp_avg_sq || !partials || !records || chunks <= 0 || nrec <= 0 || !d_state ||
       !(grad_scale > 0.f) || !(lr > 0.f) || BG_REC % 64 != 0)
     return CNR_E_ARG;
   BgTailArgs a{theta, grad, exp_avg, exp_avg_sq, partials, chunks, records, nrec, 1.0f / grad_scale, lr, beta1, beta2, eps,
                weight_decay, d_state, add_rows, (unsigned char*)packed, (const float*)rl_workspace, 0, losses, flags};
-  if (rl_workspace) { const int rpb = cnr_rl::rl_rays_per_block(1, R); a.rl_nb = (R + rpb - 1) / rpb; }
+  // R > 0: cnr_render_loss's workspace for R rays; R = 0: cnr_bg_backward_render's (one partial per backward block = nrec)
+  if (rl_workspace) { const int rpb = cnr_rl::rl_rays_per_block(1, R > 0 ? R : 1); a.rl_nb = R > 0 ? (R + rpb - 1) / rpb : nrec; }
   // (the step count is read by every block: the state moves in a second, one-thread launch behind them -- or, add_rows < 0,
   //  it was moved by cnr_bg_backward already, the launch between the sampler, which reads the cursor, and this one)
   hipLaunchKernelGGL(bg_tail_kernel, dim3(TAIL_NBIG + BG_REC / 16), dim3(256), 0, (hipStream_t)stream, a);

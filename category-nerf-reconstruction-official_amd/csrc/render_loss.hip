@@ -24,25 +24,6 @@
 
 namespace {
 using namespace cnr_rl;
-__device__ __forceinline__ float incl_prod(float v, int lane) {
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const float p = __shfl_up(v, o, 64);
-    if (lane >= o) v *= p;
-  }
-  return v;
-}
-__device__ __forceinline__ float incl_suffix_sum(float v, int lane) {
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const float p = __shfl_down(v, o, 64);
-    if (lane + o < 64) v += p;
-  }
-  return v;
-}
-__device__ __forceinline__ float sigmoid_exact(float x) { return 1.0f / (1.0f + expf(-x)); }
-__device__ __forceinline__ float sgn(float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
-
 // grid (ceil(R / rays_per_block), C)
 __global__ __launch_bounds__(RL_THREADS) void render_loss_kernel(
     const float* __restrict__ sigmas, const float* __restrict__ colors, const float* __restrict__ z,
@@ -92,54 +73,21 @@ __global__ __launch_bounds__(RL_THREADS) void render_loss_kernel(
     const size_t ray = (size_t)c * R + r;
     const size_t base = ray * S;
     if (nchunk == 1) {
-      // ---- S <= 64: the whole ray sits in one register per lane; sigmoid, scan and loads happen once -------------
-      const int s = lane;
-      const bool live = s < S;
-      const float occ = live ? sigmoid_exact(sigmas[base + s]) : 0.0f;
-      const float f = live ? (1.0f - occ + 1e-10f) : 1.0f;
-      const float incl = incl_prod(f, lane);
-      float T = __shfl_up(incl, 1, 64);
-      if (lane == 0) T = 1.0f;
-      const float term = occ * (1.0f * T);
-      float zz = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
-      if (live) { zz = z[base + s]; const float* cp = colors + (base + s) * 3; c0 = cp[0]; c1 = cp[1]; c2 = cp[2]; }
-      float sd = 0.f, so = 0.f, sr = 0.f, sg = 0.f, sb = 0.f;
-      if (live) { sd += term * zz; so += term; sr += term * c0; sg += term * c1; sb += term * c2; }
-      sd = cnr::wave_sum(sd); so = cnr::wave_sum(so);
-      sr = cnr::wave_sum(sr); sg = cnr::wave_sum(sg); sb = cnr::wave_sum(sb);
-      float sv = 0.f;
-      if (live) { const float dz = zz - sd; sv += occ * 1.0f * T * dz * dz; }
-      sv = cnr::wave_sum(sv);
+      // ---- S <= 64: the whole ray sits in one register per lane; sigmoid, scan and loads happen once (render_common.h) --
+      const RayOut q = ray_small(sigmas, colors, z, base, S, lane, gt_depth[ray], gt_rgb[ray * 3 + 0], gt_rgb[ray * 3 + 1],
+                                 gt_rgb[ray * 3 + 2], labels[ray], depth_mask[ray], wd, wc, wo, color_scaling, opacity_scaling,
+                                 grad_scale);
       if (lane == 0) {
-        if (depth_out) depth_out[ray] = sd;
-        if (var_out) var_out[ray] = sv;
-        if (opacity_out) opacity_out[ray] = so;
-        if (rgb_out) { rgb_out[ray * 3 + 0] = sr; rgb_out[ray * 3 + 1] = sg; rgb_out[ray * 3 + 2] = sb; }
+        if (depth_out) depth_out[ray] = q.sd;
+        if (var_out) var_out[ray] = q.sv;
+        if (opacity_out) opacity_out[ray] = q.so;
+        if (rgb_out) { rgb_out[ray * 3 + 0] = q.sr; rgb_out[ray * 3 + 1] = q.sg; rgb_out[ray * 3 + 2] = q.sb; }
       }
-      const uint8_t lab = labels[ray];
-      const bool mo = lab != 0, ms = lab != 2, md = (depth_mask[ray] != 0) && mo;
-      const float fd = md ? 1.f : 0.f, fo = mo ? 1.f : 0.f, fs = ms ? 1.f : 0.f;
-      const float rd = sd - gt_depth[ray];
-      const float info = 1.0f / (sqrtf(sv) + 1e-4f);
-      const float rc0 = sr - gt_rgb[ray * 3 + 0], rc1 = sg - gt_rgb[ray * 3 + 1], rc2 = sb - gt_rgb[ray * 3 + 2];
-      const float ro = so - fo;
-      ld += fabsf(rd) * fd * info;
-      lc += (fabsf(rc0) + fabsf(rc1) + fabsf(rc2)) * fo;
-      lo += fabsf(ro) * fs;
-      const float dD = grad_scale * sgn(rd) * fd * info * wd;
-      const float dR = grad_scale * color_scaling * sgn(rc0) * fo * wc;
-      const float dG = grad_scale * color_scaling * sgn(rc1) * fo * wc;
-      const float dBl = grad_scale * color_scaling * sgn(rc2) * fo * wc;
-      const float dO = grad_scale * opacity_scaling * sgn(ro) * fs * wo;
-      const float g = live ? dD * zz + dR * c0 + dG * c1 + dBl * c2 + dO : 0.0f;
-      const float tg = term * g;
-      const float incl_suf = incl_suffix_sum(tg, lane);
-      const float suf = (incl_suf - tg) + 0.0f;
-      if (live) {
-        const float docc = T * g - suf / f;
-        d_sigmas[base + s] = docc * occ * (1.0f - occ);
-        float* dc = d_colors + (base + s) * 3;
-        dc[0] = term * dR; dc[1] = term * dG; dc[2] = term * dBl;
+      ld += q.ld; lc += q.lc; lo += q.lo;
+      if (q.live) {
+        d_sigmas[base + lane] = q.dsig;
+        float* dc = d_colors + (base + lane) * 3;
+        dc[0] = q.dc0; dc[1] = q.dc1; dc[2] = q.dc2;
       }
       continue;
     }

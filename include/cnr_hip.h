@@ -583,7 +583,8 @@ int cnr_field_train(const cnr_field_train_args* args, void* stream);
  * samples (1200 x 14).  theta: the flat fp32 parameter buffer in the modules' registration order,
  *   in_layer.0 W (128,87) b | mid1.0.0 W (128,128) b | cat_layer.0 W (128,215) b | mid2.0.0 W (128,128) b | out_alpha W (1,128) b |
  *   color_linear.0 W (128,170) b | out_color W (3,128) b | B_layer.weight (21,3)          = cnr_bg_param_count() = 94 403 floats.
- * One step = cnr_bg_pack -> cnr_bg_forward -> cnr_render_loss (+ _finish) -> cnr_bg_backward -> cnr_bg_dw -> cnr_bg_tail, M = R S:
+ * One step = cnr_bg_pack -> cnr_bg_forward -> cnr_render_loss (+ _finish) -> cnr_bg_backward -> cnr_bg_dw -> cnr_bg_tail, M = R S
+ * (or, one launch less, cnr_bg_forward -> cnr_bg_backward_render -> cnr_bg_dw -> cnr_bg_tail, below):
  *   pack:     theta -> (cnr_bg_pack_bytes()) f16 MFMA fragments: forward, geometry-branch residual, transposed.
  *   forward:  pts (M,3) -> sigma (M,) = 10 raw, rgb (M,3); act (5,M,128) f16 = post-ReLU outputs of in_layer, mid1, cat_layer,
  *             mid2, color_linear; eimg (M,144) f16 = PE features (E1 in columns 0..95, E2 in 96..143).  Geometry branch
@@ -591,14 +592,16 @@ int cnr_field_train(const cnr_field_train_args* args, void* stream);
  *   backward: d_sigma (M,), d_rgb (M,3) (already multiplied by the loss scale) -> dpre (5,M,128) f16 pre-activation gradients,
  *             records (cnr_bg_blocks(M), cnr_bg_record_floats()): per-workgroup gradients of out_color, out_alpha, B_layer.
  *   dw:       weight / bias gradients of the five 128-wide layers over sample chunks of `chunk` (a multiple of 64) samples
- *             -> partials (cnr_bg_dw_chunks(M, chunk), cnr_bg_param_count()).
+ *             -> partials (cnr_bg_dw_chunks(M, chunk), cnr_bg_param_count()).  d_state != NULL: the launch also advances the
+ *             step state by (add_rows, 1, 1) (for steps whose backward is cnr_bg_backward_render; then pass add_rows = -1 to the tail).
  *   tail:     fixed-order sums of partials and records, x 1 / grad_scale -> grad; AdamW in place (step = d_state[2] + 1);
  *             d_state += (add_rows, 1, 1).  With d_state given to cnr_bg_backward (it then advances the state: the sampler, which
  *             reads the cursor, ran before it, the optimiser, which reads the step count, runs after it) pass add_rows = -1
  *             here: the step count is then d_state[2] as it stands and no state launch follows.
  *             packed != NULL: every weight's f16 fragment slots are refreshed by the thread that updates it (the next step then
  *             needs no cnr_bg_pack; call cnr_bg_pack once before the first step and after any outside change of theta);
- *             rl_workspace != NULL: cnr_render_loss's workspace for R rays -> losses (3,1), flags (1) (= cnr_render_loss_finish).
+ *             rl_workspace != NULL: cnr_render_loss's workspace for R rays -> losses (3,1), flags (1) (= cnr_render_loss_finish);
+ *             R = 0: rl_workspace is cnr_bg_backward_render's loss workspace (one partial per backward block, nrec of them).
  * No float atomics: two runs give the same bits. */
 int64_t cnr_bg_pack_bytes(void);
 int cnr_bg_param_count(void);
@@ -611,7 +614,52 @@ int cnr_bg_forward(const float* pts, const float* theta, const void* packed, flo
 int cnr_bg_backward(const float* pts, const float* theta, const void* packed, float scale, int M, const float* d_sigma,
                     const float* d_rgb, const float* rgb, const void* act, void* dpre, float* records, int64_t* d_state,
                     int64_t add_rows, void* stream);
-int cnr_bg_dw(const void* act, const void* dpre, const void* eimg, int M, int chunk, float* partials, void* stream);
+int cnr_bg_dw(const void* act, const void* dpre, const void* eimg, int M, int chunk, float* partials, int64_t* d_state,
+              int64_t add_rows, void* stream);
+/* cnr_render_loss + cnr_bg_backward in ONE launch (R rays x S <= 64 samples, ray-major: sample m = ray S + s): every backward
+ * workgroup first composites the (at most 32 / S + 2) rays its 32-sample tile touches -- one wave per ray, cnr_render_loss's
+ * arithmetic expression for expression, so d sigma / d colour are that call's bit for bit -- and walks straight into the
+ * data-gradient chain; d sigma / d colour never reach memory.  The tile that holds a ray's first sample writes its renders
+ * (depth / var / rgb_render / opacity, each optional) and accounts for its loss terms: loss_workspace
+ * (cnr_bg_backward_render_workspace_bytes(M)) holds one partial per workgroup, which cnr_bg_tail (rl_workspace, R = 0) turns
+ * into loss values and flags.  counts_tab (cnr_slice_maskcounts, C = 1) is required; d_state (may be NULL: entry 0) is READ for
+ * the cursor and not advanced here: give d_state to cnr_bg_dw.  rgb = the forward's per-sample colours.  d_sigma (M,) /
+ * d_rgb (M,3), optional: the loss gradient per sample as cnr_render_loss writes it (the chain itself does not need them). */
+typedef struct cnr_bg_backward_render_args {
+  uint32_t struct_size;
+  uint32_t abi_version;
+  const float* pts;
+  const float* theta;
+  const void* packed;
+  float scale;
+  int32_t R;
+  int32_t S;
+  const float* sigma;
+  const float* rgb;
+  const float* z;
+  const float* gt_depth;
+  const float* gt_rgb;
+  const uint8_t* labels;
+  const uint8_t* depth_mask;
+  const float* counts_tab;
+  const int64_t* d_state;
+  float color_scaling;
+  float opacity_scaling;
+  float grad_scale;
+  const void* act;
+  void* dpre;
+  float* records;
+  float* depth;
+  float* var;
+  float* rgb_render;
+  float* opacity;
+  float* d_sigma;
+  float* d_rgb;
+  void* loss_workspace;
+  int64_t loss_workspace_bytes;
+} cnr_bg_backward_render_args;
+int64_t cnr_bg_backward_render_workspace_bytes(int M);
+int cnr_bg_backward_render(const cnr_bg_backward_render_args* args, void* stream);
 int cnr_bg_tail(float* theta, float* grad, float* exp_avg, float* exp_avg_sq, const float* partials, int chunks,
                 const float* records, int nrec, float grad_scale, float lr, float beta1, float beta2, float eps,
                 float weight_decay, int64_t* d_state, int64_t add_rows, void* packed, const void* rl_workspace, int R,

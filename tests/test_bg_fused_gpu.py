@@ -66,7 +66,31 @@ def test_fused_background_step_against_the_reference_vectors(dev, name):
     for k, key in enumerate(("loss_depth", "loss_color", "loss_opacity")):
         assert rel_l2(losses[k], g.t(key)) < 1e-3, key
     _C.call("cnr_bg_backward", pts, theta, packed, g.scale, M, dsig, drgb, rgbs, act, dpre, records, None, 0)
-    _C.call("cnr_bg_dw", act, dpre, eimg, M, chunk, partials)
+    _C.call("cnr_bg_dw", act, dpre, eimg, M, chunk, partials, None, 0)
+    # ---- the same two calls as ONE launch (cnr_bg_backward_render: every backward workgroup composites the rays its tile
+    # touches): d sigma / d colour never reach memory, everything downstream must be the two-call form's bit for bit; the mask
+    # counts come from the per-epoch table (here: one slice = the fixture's rays in order)
+    pool_rgbs = torch.zeros(1, R, 4, device=dev, dtype=torch.uint8)
+    pool_rgbs[0, :, 3] = g.t("labels").reshape(-1).to(torch.uint8)
+    pool_depth = torch.where(g.t("depth_mask").reshape(1, R).bool(), torch.ones(1, R, device=dev), torch.zeros(1, R, device=dev))
+    tab = f(1, 2, 4)
+    _C.call("cnr_slice_maskcounts", pool_rgbs, pool_depth, None, R, 1, R, 1, 0.0, tab)
+    ws2 = torch.zeros(int(lib.cnr_bg_backward_render_workspace_bytes(M)), device=dev, dtype=torch.uint8)
+    dpre2, records2 = torch.zeros_like(dpre), torch.zeros_like(records)
+    depth2, var2, rgb2, opa2 = f(1, R), f(1, R), f(1, R, 3), f(1, R)
+    dsig2, drgb2 = f(1, R, S), f(1, R, S, 3)
+    _C.call_struct("cnr_bg_backward_render", pts=pts, theta=theta, packed=packed, scale=g.scale, R=R, S=S, sigma=sigma, rgb=rgbs,
+                   z=g.t("z").contiguous(), gt_depth=g.t("gt_depth").contiguous(), gt_rgb=g.t("gt_rgb").contiguous(),
+                   labels=g.t("labels").contiguous(), depth_mask=g.t("depth_mask").to(torch.uint8).contiguous(), counts_tab=tab,
+                   d_state=None, color_scaling=5.0, opacity_scaling=10.0, grad_scale=gscale, act=act, dpre=dpre2, records=records2,
+                   depth=depth2, var=var2, rgb_render=rgb2, opacity=opa2, d_sigma=dsig2, d_rgb=drgb2, loss_workspace=ws2, loss_workspace_bytes=ws2.numel())
+    torch.cuda.synchronize()
+    assert torch.equal(dsig2, dsig) and torch.equal(drgb2, drgb)
+    assert torch.equal(dpre2, dpre) and torch.equal(records2, records)
+    assert torch.equal(depth2, depth) and torch.equal(var2, var) and torch.equal(rgb2, rgb) and torch.equal(opa2, opa)
+    losses2, flags2 = f(3, 1), f(1, dt=torch.int32)
+    _C.call("cnr_render_loss_finish", ws2, losses2, flags2, 1, R, nblk)       # same partial format, one per backward block
+    assert rel_l2(losses2, losses) < 1e-6 and torch.equal(flags2, flags)
     # the weight-gradient kernel on its own: dW = dPre^T X, db = column sums, from the very f16 arrays it reads
     torch.cuda.synchronize()
     psum = partials.sum(0)
@@ -115,7 +139,7 @@ def test_fused_background_step_against_the_reference_vectors(dev, name):
     th3, grad3 = theta.clone(), f(n)
     st3 = torch.zeros(3, device=dev, dtype=torch.int64)
     _C.call("cnr_bg_backward", pts, theta, packed, g.scale, M, dsig, drgb, rgbs, act, dpre, records, st3, R)   # the state moves here ...
-    _C.call("cnr_bg_dw", act, dpre, eimg, M, chunk, partials)
+    _C.call("cnr_bg_dw", act, dpre, eimg, M, chunk, partials, None, 0)
     _C.call("cnr_bg_tail", th3, grad3, f(n), f(n), partials, nch, records, nblk, gscale, 1e-3, 0.9, 0.999, 1e-8, 0.013,
             st3, -1, None, None, 0, None, None)                                                                                          # ... and the tail reads it as it stands
     assert torch.equal(grad3, grad) and torch.equal(th3, th2) and st3.tolist() == [R, 1, 1]
