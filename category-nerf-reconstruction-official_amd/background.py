@@ -245,6 +245,8 @@ class FullStepTrainer:
         self.steps_done = 0
         self.concurrent = bool(int(os.environ.get("CNR_FULLSTEP_CONCURRENT", "1"))) if concurrent is None else bool(concurrent)
         self._side = torch.cuda.Stream(device=self.obj.device) if self.concurrent else None
+        # run(): fork once per graph (True) or once per iteration (False: every iteration ends with a join of the two chains)
+        self.free_chains = os.environ.get("CNR_FULLSTEP_FREE", "1") != "0"
 
     def _both(self):
         """background + categories, on one stream or forked onto two"""
@@ -284,10 +286,24 @@ class FullStepTrainer:
                 par0 = o.parity
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
-                    for i in range(U):
-                        o._out_slot = i if i < U - 1 else None
-                        self._both()
-                        o.parity ^= 1
+                    if self.concurrent and self.free_chains:
+                        # the two chains of all U iterations as two branches that meet only at the end of the graph: iteration
+                        # i + 1 of one chain waits for nothing of the other (they share no parameter and no buffer)
+                        cur = torch.cuda.current_stream()
+                        self._side.wait_stream(cur)
+                        with torch.cuda.stream(self._side):
+                            for i in range(U):
+                                self.bg._body()
+                        for i in range(U):
+                            o._out_slot = i if i < U - 1 else None
+                            o._step_body()
+                            o.parity ^= 1
+                        cur.wait_stream(self._side)
+                    else:
+                        for i in range(U):
+                            o._out_slot = i if i < U - 1 else None
+                            self._both()
+                            o.parity ^= 1
                 o._out_slot, o.parity = None, par0
                 self.graphs[key] = g
             self.graphs[key].replay()
