@@ -84,6 +84,7 @@ SIGNATURES = {
     "cnr_bg_dw": [_vp, _vp, _vp, _i, _i, _vp, _vp, _i64, _vp],
     "cnr_bg_backward_render_workspace_bytes": [_i],
     "cnr_bg_backward_render": [_vp, _vp],
+    "cnr_bg_tail_sample": [_vp, _vp],
     "cnr_bg_tail": [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _f, _f, _f, _f, _f, _f, _vp, _i64, _vp, _vp, _i, _vp, _vp, _vp],
 }
 # The three launches of the fused trainer's step take ONE versioned struct (include/cnr_hip.h: struct_size and abi_version
@@ -116,6 +117,14 @@ STRUCTS = {
         ("depth", _vp), ("var", _vp), ("rgb", _vp), ("opacity", _vp), ("C", _i32), ("R", _i32), ("S", _i32),
         ("rows_per_class", _i32), ("max_blocks", _i32), ("records", _vp), ("records_bytes", _i64), ("loss_workspace", _vp),
         ("loss_workspace_bytes", _i64), ("B_stride", _i64), ("rows_fix", _vp), ("clamp_flags", _vp)],
+    "cnr_bg_tail_sample": [
+        ("theta", _vp), ("grad", _vp), ("exp_avg", _vp), ("exp_avg_sq", _vp), ("partials", _vp), ("chunks", _i32), ("records", _vp),
+        ("nrec", _i32), ("grad_scale", _f), ("lr", _f), ("beta1", _f), ("beta2", _f), ("adam_eps", _f), ("weight_decay", _f),
+        ("packed", _vp), ("rl_workspace", _vp), ("rl_R", _i32), ("losses", _vp), ("flags", _vp), ("rgbs", _vp), ("depth", _vp),
+        ("dirs_c", _vp), ("T", _vp), ("seed", _u64), ("offset", _u64), ("d_state", _vp), ("pool_rows", _i64), ("max_bound", _vp),
+        ("max_bound_slices", _i32), ("world_frame", _i32), ("R", _i32), ("n1", _i32), ("n2", _i32), ("eps", _f), ("stop_eps", _f),
+        ("min_bound", _f), ("perm", _vp), ("z", _vp), ("pts", _vp), ("origins", _vp), ("dirs_o", _vp), ("gt_rgb", _vp),
+        ("gt_depth", _vp), ("depth_mask", _vp), ("labels", _vp)],
     "cnr_bg_backward_render": [
         ("pts", _vp), ("theta", _vp), ("packed", _vp), ("scale", _f), ("R", _i32), ("S", _i32), ("sigma", _vp), ("rgb", _vp),
         ("z", _vp), ("gt_depth", _vp), ("gt_rgb", _vp), ("labels", _vp), ("depth_mask", _vp), ("counts_tab", _vp),

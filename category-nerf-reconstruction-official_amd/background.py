@@ -87,6 +87,8 @@ class BackgroundStep:
             # slice's entry instead of every block counting the batch's 1200 labels first
             _C.call("cnr_slice_maskcounts", self.pool["rgbs"], self.pool["depth"], self.perm, self.pool_rows, 1, self.R,
                     self.n_slices, float(self.cfg.min_depth), self.counts_tab)
+            if self.sample_in_tail:
+                self._sample()      # the epoch's first batch; every later one is drawn by the previous step's last launch
 
     def _body(self):
         """sample -> PE -> OccupancyMap -> composite + losses -> backward -> AdamW -> advance (all stream-ordered)."""
@@ -125,6 +127,9 @@ class BackgroundStep:
         # composite / losses inside the backward launch (cnr_bg_backward_render: a ray on one wave, S <= 64); CNR_BG_FUSE_RENDER=0:
         # the separate cnr_render_loss launch
         self.fuse_render = self.S <= 64 and __import__('os').environ.get('CNR_BG_FUSE_RENDER', '1') != '0'
+        # the NEXT step's rays sampled by extra blocks of this step's last launch (cnr_bg_tail_sample): the step then starts with the
+        # forward; CNR_BG_SAMPLE_IN_TAIL=0: cnr_sample_rays as every step's first launch
+        self.sample_in_tail = __import__('os').environ.get('CNR_BG_SAMPLE_IN_TAIL', '1') != '0'
         # samples per weight-gradient workgroup: 384 -> 5 layers x 44 chunks = 220 workgroups, one round on 256 CUs (measured 17.5 us;
         # 256: 20.2, 512: 21.2)
         self.dw_chunk = int(__import__('os').environ.get('CNR_BG_DW_CHUNK', '384'))
@@ -169,10 +174,7 @@ class BackgroundStep:
         """sample -> forward -> composite + losses + their gradient -> backward -> weight gradients -> reduce + AdamW + fragment
         refresh + loss values: six launches, nothing under autograd (train.py:113-121,172-184 for the background)."""
         cfg, o = self.cfg, self.fb
-        b = ops.sample_rays(self.pool["rgbs"], self.pool["depth"], self.pool["dirs"], self.pool["T"], self.n1, self.n2,
-                            cfg.surface_eps, cfg.stop_eps, min_bound=cfg.min_depth, world_frame=True, seed=self.seed,
-                            d_state=self.d_state, rays=self.R, out=self.bufs, perm=self.perm, max_bound=self.slice_max,
-                            max_bound_slices=self.n_slices)
+        b = self.bufs if self.sample_in_tail else self._sample()      # (in the tail: drawn by the previous step, or by _reshuffle)
         scale, M = float(self.trainer.pe._scale), self.M
         _C.call("cnr_bg_forward", b["pts"], self.flat, o["packed"], scale, M, o["sigma"], o["rgbs"], o["act"], o["eimg"])
         if self.fuse_render:
@@ -192,10 +194,30 @@ class BackgroundStep:
             _C.call("cnr_bg_backward", b["pts"], self.flat, o["packed"], scale, M, o["dsig"], o["drgb"], o["rgbs"], o["act"],
                     o["dpre"], o["records"], self.d_state, self.R)
             _C.call("cnr_bg_dw", o["act"], o["dpre"], o["eimg"], M, self.dw_chunk, o["partials"], None, 0)
-        _C.call("cnr_bg_tail", self.flat, self.gflat, self.exp_avg, self.exp_avg_sq, o["partials"], self.nchunk, o["records"],
-                self.nblk, self.gscale, cfg.learning_rate, 0.9, 0.999, 1e-8, cfg.weight_decay, self.d_state, -1, o["packed"],
-                o["rl_ws"], 0 if self.fuse_render else self.R, o["losses"], o["flags"])
+        if self.sample_in_tail:
+            _C.call_struct("cnr_bg_tail_sample", theta=self.flat, grad=self.gflat, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq,
+                           partials=o["partials"], chunks=self.nchunk, records=o["records"], nrec=self.nblk, grad_scale=self.gscale,
+                           lr=cfg.learning_rate, beta1=0.9, beta2=0.999, adam_eps=1e-8, weight_decay=cfg.weight_decay,
+                           packed=o["packed"], rl_workspace=o["rl_ws"], rl_R=0 if self.fuse_render else self.R, losses=o["losses"],
+                           flags=o["flags"], rgbs=self.pool["rgbs"], depth=self.pool["depth"], dirs_c=self.pool["dirs"],
+                           T=self.pool["T"], seed=int(self.seed), offset=0, d_state=self.d_state, pool_rows=self.pool_rows,
+                           max_bound=self.slice_max, max_bound_slices=self.n_slices, world_frame=1, R=self.R, n1=self.n1,
+                           n2=self.n2, eps=float(cfg.surface_eps), stop_eps=float(cfg.stop_eps), min_bound=float(cfg.min_depth),
+                           perm=self.perm, z=b["z"], pts=b["pts"], origins=None, dirs_o=None, gt_rgb=b["gt_rgb"],
+                           gt_depth=b["gt_depth"], depth_mask=b["depth_mask"], labels=b["labels"])
+        else:
+            _C.call("cnr_bg_tail", self.flat, self.gflat, self.exp_avg, self.exp_avg_sq, o["partials"], self.nchunk, o["records"],
+                    self.nblk, self.gscale, cfg.learning_rate, 0.9, 0.999, 1e-8, cfg.weight_decay, self.d_state, -1, o["packed"],
+                    o["rl_ws"], 0 if self.fuse_render else self.R, o["losses"], o["flags"])
         # (self.losses / self.loss are views of / derived from o["losses"]: see the properties -- no torch kernel in the step)
+
+    def _sample(self):
+        """a2-a6 for the step at the device cursor (cnr_sample_rays, world frame, per-epoch max-depth table) into self.bufs"""
+        cfg = self.cfg
+        return ops.sample_rays(self.pool["rgbs"], self.pool["depth"], self.pool["dirs"], self.pool["T"], self.n1, self.n2,
+                               cfg.surface_eps, cfg.stop_eps, min_bound=cfg.min_depth, world_frame=True, seed=self.seed,
+                               d_state=self.d_state, rays=self.R, out=self.bufs, perm=self.perm, max_bound=self.slice_max,
+                               max_bound_slices=self.n_slices)
 
     def repack(self):
         """Fused tier: rebuild the f16 fragment images from ``self.flat`` (cnr_bg_pack).  Needed once before the first step and

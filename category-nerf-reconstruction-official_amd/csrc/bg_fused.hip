@@ -23,6 +23,7 @@
 #include "adamw_common.h"
 #include "fused_common.h"
 #include "render_common.h"
+#include "sample_common.h"
 
 namespace {
 using namespace fz;
@@ -832,6 +833,7 @@ struct BgTailArgs {
   float inv_gscale, lr, b1, b2, eps, wd; int64_t* d_state; int64_t add_rows;
   unsigned char* packed;               // != NULL: the thread that updates a weight also refreshes its f16 fragment slots
   const float* rl_partials; int rl_nb; float* losses; int32_t* flags;   // != NULL: one more block forms the step's loss values
+  cnr_sample::SampleArgs sa; int sample_blocks;   // cnr_bg_tail_sample: the NEXT step's rays, four per block behind the others
 };
 // Where weight (layer l, output o, input column c) sits in the packed images: the forward fragment (and, geometry layers, its
 // residual twin at the same index) and the transposed fragment.  The inverse of bg_pack_kernel's maps: with `packed` given to
@@ -882,7 +884,16 @@ __device__ __forceinline__ int rec_param(int e) {   // parameter of record entry
   return -1;
 }
 constexpr int TAIL_NBIG = (BG_NPARAM + 255) / 256;
+constexpr int TAIL_NREC = BG_REC / 16;
 __global__ __launch_bounds__(256) void bg_tail_kernel(BgTailArgs a) {
+  if ((int)blockIdx.x >= TAIL_NBIG + TAIL_NREC) {
+    // ---- a2-a5 for the NEXT step (cnr_bg_tail_sample): nothing in this launch reads the sampler's outputs, the step state was
+    // advanced earlier in the step (cnr_bg_dw), so cursor and RNG step are already the next step's.  At the epoch's last step
+    // there is no next slice yet (the host reshuffles, then samples with cnr_sample_rays): nothing is written.
+    const int64_t ray = (int64_t)((int)blockIdx.x - TAIL_NBIG - TAIL_NREC) * 4 + (threadIdx.x >> 6);
+    if (ray < a.sa.R && a.sa.d_state[0] + a.sa.R <= a.sa.pool_rows) cnr_sample::sample_ray(a.sa, ray, threadIdx.x & 63);
+    return;
+  }
   __shared__ float part[16][16];
   const int64_t t = a.d_state[2] + (a.add_rows >= 0 ? 1 : 0);   // add_rows < 0: the state was advanced earlier in the step
   cnr::AdamArgs ad{a.theta, a.grad, a.m, a.v, BG_NPARAM, a.lr, a.b1, a.b2, a.eps, a.wd, 1.0f};
@@ -944,7 +955,7 @@ __global__ __launch_bounds__(256) void bg_tail_kernel(BgTailArgs a) {
     if (a.packed) refresh_param(a.packed, i, p);
   }
   // the step's loss values out of the render kernel's per-block partials (cnr_render_loss_finish's job, one block of this launch)
-  if (a.rl_partials && blockIdx.x == gridDim.x - 1 && threadIdx.x < 64)
+  if (a.rl_partials && blockIdx.x == TAIL_NBIG + TAIL_NREC - 1 && threadIdx.x < 64)
     cnr_rl::finish_class(a.rl_partials, a.rl_nb, a.losses, a.flags, 1, 0, threadIdx.x);
 }
 __global__ void bg_advance_kernel(int64_t* d_state, int64_t add_rows) {
@@ -1042,23 +1053,52 @@ extern "C" int cnr_bg_dw(const void* act, const void* dpre, const void* eimg, in
   return CNR_OK;
 }
 
-extern "C" int cnr_bg_tail(float* theta, float* grad, float* exp_avg, float* exp_avg_sq, const float* partials, int chunks,
-                           const float* records, int nrec, float grad_scale, float lr, float beta1, float beta2, float eps,
-                           float weight_decay, int64_t* d_state, int64_t add_rows, void* packed, const void* rl_workspace,
-                           int R, float* losses, int32_t* flags, void* stream) {
+static int bg_tail_launch(float* theta, float* grad, float* exp_avg, float* exp_avg_sq, const float* partials, int chunks,
+                          const float* records, int nrec, float grad_scale, float lr, float beta1, float beta2, float eps,
+                          float weight_decay, int64_t* d_state, int64_t add_rows, void* packed, const void* rl_workspace, int R,
+                          float* losses, int32_t* flags, const cnr_sample::SampleArgs* sa, void* stream) {
   if (rl_workspace && (!losses || !flags || R < 0)) return CNR_E_ARG;
   if (((uintptr_t)packed & 15) != 0) return CNR_E_ALIGN;
   if (!theta || !grad || !exp_avg || !exp_avg_sq || !partials || !records || chunks <= 0 || nrec <= 0 || !d_state ||
       !(grad_scale > 0.f) || !(lr > 0.f) || BG_REC % 64 != 0)
     return CNR_E_ARG;
-  BgTailArgs a{theta, grad, exp_avg, exp_avg_sq, partials, chunks, records, nrec, 1.0f / grad_scale, lr, beta1, beta2, eps,
-               weight_decay, d_state, add_rows, (unsigned char*)packed, (const float*)rl_workspace, 0, losses, flags};
+  BgTailArgs a{};
+  a.theta = theta; a.grad = grad; a.m = exp_avg; a.v = exp_avg_sq; a.partials = partials; a.chunks = chunks; a.records = records;
+  a.nrec = nrec; a.inv_gscale = 1.0f / grad_scale; a.lr = lr; a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.wd = weight_decay;
+  a.d_state = d_state; a.add_rows = add_rows; a.packed = (unsigned char*)packed; a.rl_partials = (const float*)rl_workspace;
+  a.losses = losses; a.flags = flags;
   // R > 0: cnr_render_loss's workspace for R rays; R = 0: cnr_bg_backward_render's (one partial per backward block = nrec)
   if (rl_workspace) { const int rpb = cnr_rl::rl_rays_per_block(1, R > 0 ? R : 1); a.rl_nb = R > 0 ? (R + rpb - 1) / rpb : nrec; }
+  if (sa) { a.sa = *sa; a.sample_blocks = (sa->R + 3) / 4; }
   // (the step count is read by every block: the state moves in a second, one-thread launch behind them -- or, add_rows < 0,
-  //  it was moved by cnr_bg_backward already, the launch between the sampler, which reads the cursor, and this one)
-  hipLaunchKernelGGL(bg_tail_kernel, dim3(TAIL_NBIG + BG_REC / 16), dim3(256), 0, (hipStream_t)stream, a);
+  //  it was moved by cnr_bg_backward / cnr_bg_dw already, the launch between the sampler, which reads the cursor, and this one)
+  hipLaunchKernelGGL(bg_tail_kernel, dim3(TAIL_NBIG + TAIL_NREC + a.sample_blocks), dim3(256), 0, (hipStream_t)stream, a);
   if (add_rows >= 0) hipLaunchKernelGGL(bg_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_state, add_rows);
   CNR_LAUNCH_CHECK();
   return CNR_OK;
+}
+
+extern "C" int cnr_bg_tail(float* theta, float* grad, float* exp_avg, float* exp_avg_sq, const float* partials, int chunks,
+                           const float* records, int nrec, float grad_scale, float lr, float beta1, float beta2, float eps,
+                           float weight_decay, int64_t* d_state, int64_t add_rows, void* packed, const void* rl_workspace,
+                           int R, float* losses, int32_t* flags, void* stream) {
+  return bg_tail_launch(theta, grad, exp_avg, exp_avg_sq, partials, chunks, records, nrec, grad_scale, lr, beta1, beta2, eps,
+                        weight_decay, d_state, add_rows, packed, rl_workspace, R, losses, flags, nullptr, stream);
+}
+
+extern "C" int cnr_bg_tail_sample(const cnr_bg_tail_sample_args* p, void* stream) {
+  if (!p || p->struct_size != sizeof(cnr_bg_tail_sample_args) || p->abi_version != CNR_ABI_VERSION) return CNR_E_ARG;
+  if (!p->rgbs || !p->depth || !p->dirs_c || !p->T || !p->d_state || !p->z || !p->pts || !p->gt_rgb || !p->depth_mask ||
+      !p->labels || p->R <= 0 || p->n1 < 0 || p->n2 <= 0 || p->pool_rows < p->R)
+    return CNR_E_ARG;
+  if (p->n2 > 128) return CNR_E_SHAPE;
+  if (p->max_bound_slices < 0 || (p->max_bound_slices > 1 && !p->max_bound)) return CNR_E_ARG;
+  const cnr_sample::SampleArgs sa{p->rgbs, p->depth, p->dirs_c, p->T, nullptr, nullptr, p->seed, p->offset, p->d_state,
+                                  p->pool_rows, p->max_bound, p->world_frame, 1, p->R, p->n1, p->n2, p->eps, p->stop_eps,
+                                  p->min_bound, p->z, p->pts, p->origins, p->dirs_o, p->gt_rgb, p->gt_depth, p->depth_mask,
+                                  p->labels, nullptr, 0, nullptr, p->perm, p->max_bound_slices, 0, 0, 0, 0};
+  // the sampler blocks read the NEXT step's cursor: the state must have moved earlier in the step (add_rows = -1 semantics)
+  return bg_tail_launch(p->theta, p->grad, p->exp_avg, p->exp_avg_sq, p->partials, p->chunks, p->records, p->nrec, p->grad_scale,
+                        p->lr, p->beta1, p->beta2, p->adam_eps, p->weight_decay, (int64_t*)p->d_state, -1, p->packed,
+                        p->rl_workspace, p->rl_R, p->losses, p->flags, &sa, stream);
 }

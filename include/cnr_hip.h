@@ -665,6 +665,63 @@ int cnr_bg_tail(float* theta, float* grad, float* exp_avg, float* exp_avg_sq, co
                 float weight_decay, int64_t* d_state, int64_t add_rows, void* packed, const void* rl_workspace, int R,
                 float* losses, int32_t* flags, void* stream);
 
+/* cnr_bg_tail with the NEXT step's sampler (cnr_sample_rays: world or object frame, device pool + cursor + permutation, in-kernel
+ * Philox, C = 1) as extra blocks of the same launch: nothing in the tail reads what the sampler writes, and the step state has
+ * been advanced earlier in the step (cnr_bg_dw with d_state; this entry point has cnr_bg_tail's add_rows = -1 semantics), so
+ * cursor and RNG step are the next step's -- the step after then starts with cnr_bg_forward straight away.  When no whole slice
+ * is left in the epoch (cursor + R > pool_rows) the sampler blocks write nothing: the host reshuffles and calls cnr_sample_rays.
+ * Tail fields as cnr_bg_tail's (rl_R = its R: 0 for cnr_bg_backward_render's workspace); sampler fields as cnr_sample_rays'. */
+typedef struct cnr_bg_tail_sample_args {
+  uint32_t struct_size;
+  uint32_t abi_version;
+  float* theta;
+  float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  const float* partials;
+  int32_t chunks;
+  const float* records;
+  int32_t nrec;
+  float grad_scale;
+  float lr;
+  float beta1;
+  float beta2;
+  float adam_eps;
+  float weight_decay;
+  void* packed;
+  const void* rl_workspace;
+  int32_t rl_R;
+  float* losses;
+  int32_t* flags;
+  const uint8_t* rgbs;
+  const float* depth;
+  const float* dirs_c;
+  const float* T;
+  uint64_t seed;
+  uint64_t offset;
+  const int64_t* d_state;
+  int64_t pool_rows;
+  const float* max_bound;
+  int32_t max_bound_slices;
+  int32_t world_frame;
+  int32_t R;
+  int32_t n1;
+  int32_t n2;
+  float eps;
+  float stop_eps;
+  float min_bound;
+  const int32_t* perm;
+  float* z;
+  float* pts;
+  float* origins;
+  float* dirs_o;
+  float* gt_rgb;
+  float* gt_depth;
+  uint8_t* depth_mask;
+  uint8_t* labels;
+} cnr_bg_tail_sample_args;
+int cnr_bg_tail_sample(const cnr_bg_tail_sample_args* args, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -87,7 +87,7 @@ def test_argument_blocks_match_the_header():
     import cnr_amd
     _C = cnr_amd._C
     structs = declared_structs()
-    assert set(structs) == set(_C.STRUCTS) and len(structs) == 4
+    assert set(structs) == set(_C.STRUCTS) and len(structs) == 5
     ctype_of = {"float": ctypes.c_float, "int32_t": ctypes.c_int32, "uint32_t": ctypes.c_uint32, "int64_t": ctypes.c_int64,
                 "uint64_t": ctypes.c_uint64}
     for name, fields in structs.items():
@@ -95,14 +95,15 @@ def test_argument_blocks_match_the_header():
         assert [f for f, _ in fields[2:]] == [f for f, _ in _C.STRUCTS[name]], name
         for (f, typ), (_, ct) in zip(fields[2:], _C.STRUCTS[name]):
             assert ct is (ctypes.c_void_p if "*" in typ else ctype_of[typ]), (name, f, typ)
-    src = '#include <stdio.h>\n#include "cnr_hip.h"\nint main(void){printf("%zu %zu %zu %zu %d", sizeof(cnr_step_prologue_args), ' \
-          'sizeof(cnr_step_tail_args), sizeof(cnr_field_train_args), sizeof(cnr_bg_backward_render_args), CNR_ABI_VERSION);return 0;}'
+    src = '#include <stdio.h>\n#include "cnr_hip.h"\nint main(void){printf("%zu %zu %zu %zu %zu %d", sizeof(cnr_step_prologue_args), ' \
+          'sizeof(cnr_step_tail_args), sizeof(cnr_field_train_args), sizeof(cnr_bg_backward_render_args), ' \
+          'sizeof(cnr_bg_tail_sample_args), CNR_ABI_VERSION);return 0;}'
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "s.c"), "w").write(src)
         subprocess.run(["gcc", "-I", os.path.dirname(HEADER), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")], check=True)
-        a, b, c, e, ver = (int(v) for v in subprocess.run([os.path.join(d, "s")], capture_output=True, text=True).stdout.split())
-    assert (a, b, c, e) == tuple(ctypes.sizeof(_C.struct_type(n)) for n in ("cnr_step_prologue", "cnr_step_tail", "cnr_field_train",
-                                                                              "cnr_bg_backward_render"))
+        a, b, c, e, f5, ver = (int(v) for v in subprocess.run([os.path.join(d, "s")], capture_output=True, text=True).stdout.split())
+    assert (a, b, c, e, f5) == tuple(ctypes.sizeof(_C.struct_type(n)) for n in ("cnr_step_prologue", "cnr_step_tail", "cnr_field_train",
+                                                                                  "cnr_bg_backward_render", "cnr_bg_tail_sample"))
     assert ver == _C.ABI_VERSION
 
 

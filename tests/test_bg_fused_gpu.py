@@ -145,10 +145,45 @@ def test_fused_background_step_against_the_reference_vectors(dev, name):
     assert torch.equal(grad3, grad) and torch.equal(th3, th2) and st3.tolist() == [R, 1, 1]
 
 
-def test_fused_background_trainer_tracks_the_fp32_tier(dev):
-    """BackgroundStep(precision="fused") against precision="fp32" from the same initial parameters on the same sampled batches
-    (device cursor + in-kernel Philox: identical), 12 steps across a reshuffle, graph replay included."""
+def test_launch_fusions_of_the_background_step_change_no_bit(dev, monkeypatch):
+    """The fused step in its four launch layouts -- composite / losses inside the backward launch or as cnr_render_loss, the next
+    step's sampler inside the last launch or as every step's first -- over 14 steps (three reshuffles, eager steps and graph
+    replays): the same parameters, optimiser moments, loss values and step state, bit for bit."""
     import cnr_amd as cnr
+
+    def run(fuse_render, sample_in_tail):
+        monkeypatch.setenv("CNR_BG_FUSE_RENDER", str(fuse_render))
+        monkeypatch.setenv("CNR_BG_SAMPLE_IN_TAIL", str(sample_in_tail))
+        cfg = cnr.cfg.synthetic_config(device=str(dev), latent_dim=32, n_bins_cam2surface=4, n_bins=9)
+        cfg.hidden_feature_size_bg, cfg.n_bins_cam2surface_bg = 128, 5
+        torch.manual_seed(3)
+        pool = cnr.scene_cateogries.synthetic_pool(6 * 300, 1, torch.Generator().manual_seed(12), "cpu")
+        bg = cnr.background.BackgroundStep(cfg, pool, 300, dev, seed=5, precision="fused")
+        assert bg.fuse_render == bool(fuse_render) and bg.sample_in_tail == bool(sample_in_tail)
+        losses = []
+        for _ in range(14):
+            bg.step()
+            losses.append(bg.losses.clone())
+        torch.cuda.synchronize()
+        return bg.flat.clone(), bg.exp_avg.clone(), bg.exp_avg_sq.clone(), torch.stack(losses), bg.d_state.clone()
+    ref = run(0, 0)
+    assert float(ref[3].abs().sum()) > 0
+    for fr, st in ((1, 0), (0, 1), (1, 1)):
+        got = run(fr, st)
+        for k, (x, y) in enumerate(zip(ref, got)):
+            if k == 3 and fr:      # the loss VALUES are summed over other blocks (per backward block instead of per render block)
+                assert rel_l2(y, x) < 1e-6
+            else:
+                assert torch.equal(x, y), (fr, st, k)
+
+
+def test_fused_background_trainer_tracks_the_fp32_tier(dev, monkeypatch):
+    """BackgroundStep(precision="fused") against precision="fp32" from the same initial parameters on the same sampled batches
+    (device cursor + in-kernel Philox: identical), 12 steps across a reshuffle, graph replay included.  (With the sampler as every
+    step's first launch, so that after a step both tiers' buffers hold THAT step's batch; the default layout -- the next step's
+    batch drawn by the step's last launch -- is bit-equal to it: test_launch_fusions_of_the_background_step_change_no_bit.)"""
+    import cnr_amd as cnr
+    monkeypatch.setenv("CNR_BG_SAMPLE_IN_TAIL", "0")
 
     def make(prec):
         cfg = cnr.cfg.synthetic_config(device=str(dev), latent_dim=32, n_bins_cam2surface=4, n_bins=9)
@@ -205,13 +240,14 @@ def test_whole_iteration_run_in_multi_iteration_graphs_equals_single_steps(dev):
     assert torch.equal(a.bg.d_state, b.bg.d_state)
 
 
-def test_fused_background_forward_on_trained_weights(dev):
+def test_fused_background_forward_on_trained_weights(dev, monkeypatch):
     """The fused background forward against the fp32 oracle ON TRAINED WEIGHTS (the category kernel's occupancy left the 1e-3
     bar after training with plain f16 operands, tests/test_trained_parity_gpu.py; the background kernel has the three-product
     geometry branch from the start): 1500 steps of the fused trainer on a learnable pool, then the kernel's per-sample
     occupancy / colour and the four renders against oracle.ref_cpu on the same weights and the same samples."""
     import cnr_amd as cnr
     from oracle import ref_cpu as O
+    monkeypatch.setenv("CNR_BG_SAMPLE_IN_TAIL", "0")     # after a step the sample buffers then hold THAT step's batch
     import sys, os
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     cfg = cnr.cfg.synthetic_config(device=str(dev), latent_dim=32, n_bins_cam2surface=4, n_bins=9)

@@ -18,7 +18,7 @@ torch.cuda.synchronize()
 print(prec, "background step %.1f us" % ((time.perf_counter() - t0) / n * 1e6), "losses", [round(float(v), 4) for v in bg.losses])
 if prec == "fused":
     names = ["cnr_sample_maxdepth", "cnr_sample_rays", "cnr_bg_pack", "cnr_bg_forward", "cnr_render_loss", "cnr_render_loss_finish",
-             "cnr_bg_backward", "cnr_bg_backward_render", "cnr_bg_dw", "cnr_bg_tail"]
+             "cnr_bg_backward", "cnr_bg_backward_render", "cnr_bg_dw", "cnr_bg_tail", "cnr_bg_tail_sample"]
     cnr_amd._C.enable_kernel_timing(names)
     for _ in range(30):
         bg.step(use_graph=False)
