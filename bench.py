@@ -513,7 +513,8 @@ def main():
             d3 = time.perf_counter() - t0
             out["extra_legs"]["full_iteration_bg_plus_category"] = {
                 "workload": f"background 1200 rays x 14 samples (OccupancyMap(128), fused f16 step: csrc/bg_fused.hip) + 1 category x {R} "
-                            f"rays x {S} samples, both chains as forked branches of one hipGraph, up to eight iterations per graph launch", "steps": 500, "ms_per_step": d3 / 500 * 1e3,
+                            f"rays x {S} samples, the two chains of up to eight iterations as two free-running branches of one hipGraph (joined once per "
+                            f"graph launch), the background step in four launches", "steps": 500, "ms_per_step": d3 / 500 * 1e3,
                 "category_rays_per_s": R * 500 / d3, "all_rays_per_s": (R + 1200) * 500 / d3}
         except Exception as e:
             out["extra_legs"]["full_iteration_bg_plus_category"] = f"failed: {e}"

@@ -682,20 +682,22 @@ extern "C" int cnr_step_prologue(const cnr_step_prologue_args* a, void* stream) 
     return CNR_E_ARG;
   if (((uintptr_t)a->packed & 15) != 0 || ((uintptr_t)a->zero_buf & 15) != 0 || ((uintptr_t)a->packed_lo & 15) != 0)
     return CNR_E_ALIGN;
-  if (!a->rgbs || !a->depth || !a->dirs_c || !a->T || !a->max_bound || !a->z || !a->pts || !a->gt_rgb || !a->depth_mask ||
-      !a->labels)
-    return CNR_E_ARG;
-  if (R <= 0 || n1 < 0 || n2 <= 0) return CNR_E_ARG;
-  if (n2 > 128) return CNR_E_SHAPE;
-  if ((a->u == nullptr) != (a->g == nullptr)) return CNR_E_ARG;
-  if (a->pool_rows < 0 || (a->pool_rows > 0 && (!a->d_state || a->pool_rows < R))) return CNR_E_ARG;
-  if (a->ray_row && !a->pool_indices) return CNR_E_ARG;
-  if (a->perm && a->pool_rows == 0) return CNR_E_ARG;
+  const bool sample = a->rgbs != nullptr;   // rgbs = NULL: the parameter-only jobs, no sampler blocks (the rays come from elsewhere)
+  if (sample) {
+    if (!a->depth || !a->dirs_c || !a->T || !a->max_bound || !a->z || !a->pts || !a->gt_rgb || !a->depth_mask || !a->labels)
+      return CNR_E_ARG;
+    if (R <= 0 || n1 < 0 || n2 <= 0) return CNR_E_ARG;
+    if (n2 > 128) return CNR_E_SHAPE;
+    if ((a->u == nullptr) != (a->g == nullptr)) return CNR_E_ARG;
+    if (a->pool_rows < 0 || (a->pool_rows > 0 && (!a->d_state || a->pool_rows < R))) return CNR_E_ARG;
+    if (a->ray_row && !a->pool_indices) return CNR_E_ARG;
+    if (a->perm && a->pool_rows == 0) return CNR_E_ARG;
+  }
   cnr::FlatLayout lay{a->class_stride, a->off_latW, a->off_latb, a->off_shape, a->off_tex, L, n_obj};
   int nzero = a->zero_count > 0 ? (int)((a->zero_count / 4 + 256 * 8 - 1) / (256 * 8) / C) : 0;
   if (a->zero_count > 0 && nzero < 1) nzero = 1;
   if (nzero > 256) nzero = 256;
-  const int nsample = (R + 3) / 4;
+  const int nsample = sample ? (R + 3) / 4 : 0;
   cnr_sample::SampleArgs sa{a->rgbs, a->depth, a->dirs_c, a->T, a->u, a->g, a->seed, a->offset, a->d_state, a->pool_rows,
                             a->max_bound, a->world_frame, C, R, n1, n2, a->eps, a->stop_eps, a->min_bound, a->z, a->pts,
                             a->origins, a->dirs_o, a->gt_rgb, a->gt_depth, a->depth_mask, a->labels, a->pool_indices, n_obj,

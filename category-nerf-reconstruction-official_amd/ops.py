@@ -271,11 +271,12 @@ def sample_rays(rgbs, depth, dirs_c, T, n1, n2, eps, stop_eps, min_bound=0.0, wo
 
 def step_prologue(theta, lay, L, n_obj, packed, zl, brows, zero_buf, rgbs, depth, dirs_c, T, n1, n2, eps, stop_eps,
                   min_bound, seed, d_state, rays, out, max_bound, pool_indices, perm, max_bound_slices=0,
-                  rng=(0, 0, 0, 0), packed_lo=None):
+                  rng=(0, 0, 0, 0), packed_lo=None, sample=True):
     """cnr_step_prologue: the parameter-only jobs (pack | latent rows | gradient zero fill) and the sampler of one
     fused-trainer step in ONE launch.  Same outputs dict as :func:`sample_rays` (device pools, device cursor).
     max_bound: (C,) max depth of this step's slice, or with max_bound_slices = k > 1 a (C, k) table over the epoch's
-    slices (cnr_slice_maxdepth), indexed on the device by cursor / rays."""
+    slices (cnr_slice_maxdepth), indexed on the device by cursor / rays.  sample=False: the parameter-only jobs, the ray buffers
+    of ``out`` are left as they are (the caller samples elsewhere)."""
     C, R, S = depth.shape[0], int(rays), n1 + n2
     dev = depth.device
     def buf(name, shape, dtype=torch.float32):
@@ -289,7 +290,8 @@ def step_prologue(theta, lay, L, n_obj, packed, zl, brows, zero_buf, rgbs, depth
     _C.call_struct("cnr_step_prologue", theta=theta, class_stride=lay.total, off_trunk=lay.trunk[0], off_latW=lay.latW[0],
                    off_latb=lay.latb[0], off_shape=lay.shape[0], off_tex=lay.tex[0], L=L, n_obj=n_obj, C=C, packed=packed,
                    packed_lo=packed_lo, zl=zl, biasrows=brows, zero_buf=zero_buf, zero_count=zero_buf.numel(),
-                   rgbs=rgbs, depth=depth, dirs_c=dirs_c, T=T, u=None, g=None, seed=int(seed), offset=0, d_state=d_state,
+                   rgbs=rgbs if sample else None, depth=depth, dirs_c=dirs_c, T=T, u=None, g=None, seed=int(seed), offset=0,
+                   d_state=d_state,
                    pool_rows=depth.shape[1], max_bound=max_bound, world_frame=0, R=R, n1=n1, n2=n2, eps=float(eps),
                    stop_eps=float(stop_eps), min_bound=float(min_bound), z=z, pts=pts, origins=None, dirs_o=None, gt_rgb=gt,
                    gt_depth=gd, depth_mask=dm, labels=lab, pool_indices=pool_indices, ray_row=rr, perm=perm,

@@ -306,7 +306,8 @@ int cnr_slice_maxdepth(const float* depth, const int* perm, int64_t pool_rows, i
 /* cnr_param_prep and cnr_sample_rays side by side in ONE launch (max_bound must be given here, max_bound_slices = 0 or 1
  * for the per-class form): the sampler needs the ray pool and the step state only, so the first node of the fused
  * trainer's step runs it beside the parameter-only jobs instead of after them.  packed_lo (optional,
- * (C, cnr_pack_lo_bytes())): the residual image of the geometry branch (cnr_pack_weights_lo) is built in the same launch. */
+ * (C, cnr_pack_lo_bytes())): the residual image of the geometry branch (cnr_pack_weights_lo) is built in the same launch.
+ * rgbs = NULL: the parameter-only jobs without the sampler blocks (a host that samples elsewhere, e.g. on another stream). */
 typedef struct cnr_step_prologue_args {
   uint32_t struct_size;
   uint32_t abi_version;
