@@ -16,7 +16,7 @@ bg = cnr_amd.background.BackgroundStep(cfg_bg, cnr_amd.scene_cateogries.syntheti
 full = cnr_amd.background.FullStepTrainer(tr3, bg, concurrent=bool(conc))
 for _ in range(10):
     full.step()
-full.run(64)
+full.run(64, unroll=int(os.environ.get('CNR_FULL_UNROLL', '8')))
 torch.cuda.synchronize()
 ts = []
 for _ in range(5):
@@ -25,7 +25,7 @@ for _ in range(5):
         for _ in range(500):
             full.step()
     else:
-        full.run(500)
+        full.run(500, unroll=int(os.environ.get('CNR_FULL_UNROLL', '8')))
     torch.cuda.synchronize()
     ts.append((time.perf_counter() - t0) / 500)
 print(f"concurrent {conc} R {R} S {S}: whole iteration {sorted(ts)[2] * 1e6:.1f} us (min {min(ts) * 1e6:.1f}); category losses {[round(float(v), 4) for v in tr3.losses.flatten()]} bg {[round(float(v), 4) for v in bg.losses]}")
