@@ -687,7 +687,9 @@ constexpr int BG_BWD_LDS = 3 * XIMG + TS * (BE1P + BE2P) * 4 + TS * ST_OC + TS *
 // [32 w, 32 w + 32) with ALL of the layer's 32-wide input blocks (+ one "ones" block whose column 0 is the bias gradient):
 // up to eight accumulators, kept for the whole chunk and written out by the wave itself -- every input row is read from
 // memory once per chunk (a block per (layer, output block) read it four times: the kernel was bound by those reads).
-// (Two tiles' loads in flight instead of one -- a second register set, 407 registers -- measured 21.9 against 19.5 us eager.)
+// (Two tiles' loads in flight instead of one -- a second register set, 407 registers -- measured 21.9 against 19.5 us eager.  The
+//  five layers of a chunk dealt to ONE XCD, so that the three readers of the chunk's PE rows share an L2 copy: no change, 79.2
+//  against 79.2 us per step -- what this kernel re-reads comes out of the memory-side cache either way.)
 // ------------------------------------------------------------------------------------------------------------------------
 typedef short s4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ h8 tr_frag_b(const unsigned char* img, int stride, int col0, int s, int lane) {
