@@ -16,6 +16,10 @@ import os
 import sys
 import time
 
+# dmabuf IPC: RCCL across the ranks of one node needs it on this driver; it must be in the environment before the HIP runtime
+# starts, also when the ranks are started by somebody else's torch.distributed.run
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
