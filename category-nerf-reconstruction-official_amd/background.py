@@ -171,8 +171,9 @@ class BackgroundStep:
         self._loss = v
 
     def _body_fused(self):
-        """sample -> forward -> composite + losses + their gradient -> backward -> weight gradients -> reduce + AdamW + fragment
-        refresh + loss values: six launches, nothing under autograd (train.py:113-121,172-184 for the background)."""
+        """forward -> composite + losses + their gradient + backward -> weight gradients -> reduce + AdamW + fragment refresh + loss
+        values + the NEXT step's sampler: four launches, nothing under autograd (train.py:113-121,172-184 for the background; six
+        launches with CNR_BG_FUSE_RENDER=0 CNR_BG_SAMPLE_IN_TAIL=0, bit-equal)."""
         cfg, o = self.cfg, self.fb
         b = self.bufs if self.sample_in_tail else self._sample()      # (in the tail: drawn by the previous step, or by _reshuffle)
         scale, M = float(self.trainer.pe._scale), self.M
