@@ -51,6 +51,7 @@ SIGNATURES = {
     "cnr_dense_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i64, _i, _f, _vp],
     "cnr_dense_bwd_workspace_bytes": [_i, _i, _i],
     "cnr_step_prologue": [_vp, _vp],          # (const cnr_step_prologue_args*, stream): STRUCTS below
+    "cnr_epoch_perm": [_vp, _i64, _i, _u64, _u64, _vp, _vp, _i64, _vp],
     "cnr_slice_maskcounts": [_vp, _vp, _vp, _i64, _i, _i, _i, _f, _vp, _vp],
     "cnr_slice_maxdepth": [_vp, _vp, _i64, _i, _i, _i, _vp, _vp],
     "cnr_adamw_epilogue": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64,

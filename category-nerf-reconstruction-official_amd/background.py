@@ -41,6 +41,9 @@ class BackgroundStep:
         self.perm = torch.empty(1, self.pool_rows, device=dev, dtype=torch.int32)
         self._perm_gen = torch.Generator(device=dev)
         self._perm_gen.manual_seed(0xB6 + 7919 * int(seed))
+        # epoch shuffle: cnr_epoch_perm (one launch) unless CNR_EPOCH_PERM=torch asks for torch.randperm (a dozen launches)
+        self._torch_perm = __import__("os").environ.get("CNR_EPOCH_PERM", "kernel") == "torch"
+        self._perm_seed, self._epoch = 0xB6 + 7919 * int(seed), 0
         self.d_state = torch.zeros(3, device=dev, dtype=torch.int64)
         self._zero = torch.zeros(1, device=dev, dtype=torch.int64)
         self.seed = int(seed) + 101
@@ -78,8 +81,12 @@ class BackgroundStep:
     def _reshuffle(self):
         """src/scene_cateogries.py:439-449 as a new permutation; cursor back to 0.  Fused tier: the max depth of every slice of
         the epoch in one launch (cnr_slice_maxdepth; src/scene_cateogries.py:486 needs it per batch), so that no step computes it."""
-        self.perm[0].copy_(torch.randperm(self.pool_rows, device=self.device, generator=self._perm_gen))
-        self.d_state[0:1].copy_(self._zero)
+        if self._torch_perm:
+            self.perm[0].copy_(torch.randperm(self.pool_rows, device=self.device, generator=self._perm_gen))
+            self.d_state[0:1].copy_(self._zero)
+        else:     # one launch: the keyed bijection of cnr_epoch_perm, and the cursor back to row 0
+            _C.call("cnr_epoch_perm", self.perm, self.pool_rows, 1, self._perm_seed, self._epoch, None, self.d_state, 0)
+            self._epoch += 1
         self.cursor = 0
         if self.precision == "fused":
             _C.call("cnr_slice_maxdepth", self.pool["depth"], self.perm, self.pool_rows, 1, self.R, self.n_slices, self.slice_max)

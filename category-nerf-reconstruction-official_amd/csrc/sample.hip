@@ -89,6 +89,40 @@ __global__ __launch_bounds__(256) void sample_kernel(cnr_sample::SampleArgs a) {
   if (ray >= (int64_t)a.C * a.R) return;
   cnr_sample::sample_ray(a, ray, lane);
 }
+// The epoch shuffle (src/scene_cateogries.py:439-449: a new random order of the pool) as ONE launch: perm[c][i] = P(i), P a keyed
+// pseudo-random BIJECTION of [0, n) -- a 6-round balanced Feistel network on the next even power of two above n (round keys
+// from Philox4x32 of (seed, epoch, global class id)), cycle-walked back into [0, n) (a value >= n is encrypted again: at most
+// four expected trips, the domain is < 4 n).  torch.randperm sorts random keys: a dozen launches and ~100 us of GPU time per
+// epoch end for 131 072 rows, which the 63 steps of an epoch each paid 1.5 us for; and every rank had to draw every class's
+// permutation from one generator to stay in step -- here a rank computes exactly its own classes'.
+__global__ __launch_bounds__(256) void epoch_perm_kernel(int* __restrict__ perm, int64_t n, int half_bits, uint64_t seed,
+                                                         uint64_t epoch, const int* __restrict__ class_ids,
+                                                         int64_t* __restrict__ state_cursor, int64_t cursor0) {
+  const int c = blockIdx.y;
+  if (state_cursor && blockIdx.x == 0 && c == 0 && threadIdx.x == 0) state_cursor[0] = cursor0;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t k0[4], k1[4];
+  const uint64_t gc = (uint64_t)(class_ids ? class_ids[c] : c);
+  cnr_sample::philox4(seed ^ 0x5851F42D4C957F2Dull, epoch, gc * 2 + 0, k0);
+  cnr_sample::philox4(seed ^ 0x5851F42D4C957F2Dull, epoch, gc * 2 + 1, k1);
+  const uint32_t key[6] = {k0[0], k0[1], k0[2], k0[3], k1[0], k1[1]};
+  const uint32_t mask = (1u << half_bits) - 1u;
+  uint32_t x = (uint32_t)i;
+  do {
+    uint32_t l = x >> half_bits, r = x & mask;
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+      uint32_t f = (r ^ key[t]) * 0x9E3779B1u;
+      f ^= f >> 15; f *= 0x85EBCA77u; f ^= f >> 13;
+      const uint32_t nl = r;
+      r = (l ^ f) & mask;
+      l = nl;
+    }
+    x = (l << half_bits) | r;
+  } while ((int64_t)x >= n);
+  perm[(size_t)c * n + i] = (int)x;
+}
 __global__ void advance_kernel(int64_t* state, int64_t add_rows) {
   if (threadIdx.x == 0) { state[0] += add_rows; state[1] += 1; state[2] += 1; }
 }
@@ -99,6 +133,17 @@ __global__ void advance_kernel(int64_t* state, int64_t add_rows) {
 extern "C" int cnr_step_advance(int64_t* d_state, int64_t add_rows, void* stream) {
   if (!d_state) return CNR_E_ARG;
   hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_state, add_rows);
+  CNR_LAUNCH_CHECK();
+  return CNR_OK;
+}
+
+extern "C" int cnr_epoch_perm(int* perm, int64_t pool_rows, int C, uint64_t seed, uint64_t epoch, const int* class_ids,
+                              int64_t* state_cursor, int64_t cursor0, void* stream) {
+  if (!perm || pool_rows <= 0 || pool_rows > (1ll << 30) || C <= 0) return CNR_E_ARG;
+  int bits = 2;
+  while ((1ll << bits) < pool_rows) bits += 2;           // even: two halves of bits / 2
+  hipLaunchKernelGGL(epoch_perm_kernel, dim3((unsigned)((pool_rows + 255) / 256), (unsigned)C), dim3(256), 0, (hipStream_t)stream,
+                     perm, pool_rows, bits / 2, seed, epoch, class_ids, state_cursor, cursor0);
   CNR_LAUNCH_CHECK();
   return CNR_OK;
 }

@@ -193,6 +193,11 @@ class FusedCategoryTrainer:
         self._perm_gen = torch.Generator(device=self.device)
         self._perm_gen.manual_seed(0x5EED + 7919 * int(seed))
         self._cursor0 = torch.tensor([self.ray_rank * self.R], device=self.device, dtype=torch.int64)
+        # epoch shuffle: cnr_epoch_perm (one launch; the order is a function of seed, epoch and global class id) unless
+        # CNR_EPOCH_PERM=torch asks for torch.randperm from one generator, as rounds 1-3 did (a dozen launches per epoch end)
+        self._torch_perm = os.environ.get("CNR_EPOCH_PERM", "kernel") == "torch"
+        self._perm_seed, self._epoch, self._cursor0_host = 0x5EED + 7919 * int(seed), 0, self.ray_rank * self.R
+        self._class_ids_dev = torch.tensor(self.class_ids, device=self.device, dtype=torch.int32)
         # per-epoch tables, one entry per LOCAL slice (index = device cursor / R): the max depth of the (global) slice
         # (scene_cateogries.py:486) and the mask counts + any-class-empty flags of the (global) slice
         # (render_rays.py:66-95) -- no step computes a maximum or counts a mask
@@ -605,22 +610,31 @@ class FusedCategoryTrainer:
         (cnr_slice_maskcounts), each entry repeated for the ray ranks that share the slice (the kernels index by their own
         cursor / R).  All on the device; the only communication is, with class shards, one all-reduce (MAX) of the
         (slices, 3) empty flags per epoch."""
-        for cg in range(self.n_cls_global):        # every rank draws every class's permutation: same epoch everywhere
-            p = torch.randperm(self.pool_rows, device=self.device, generator=self._perm_gen)
-            if cg in self.class_ids:
-                self.perm[self.class_ids.index(cg)].copy_(p)
-        self.cursor = 0
-        self.d_state2[self.parity, 0:1].copy_(self._cursor0)
         C, ng, w = self.C, self.n_gslices, self.ray_world
-        smax = torch.empty(C, ng, device=self.device)
+        if self._torch_perm:
+            for cg in range(self.n_cls_global):    # every rank draws every class's permutation: same epoch everywhere
+                p = torch.randperm(self.pool_rows, device=self.device, generator=self._perm_gen)
+                if cg in self.class_ids:
+                    self.perm[self.class_ids.index(cg)].copy_(p)
+            self.d_state2[self.parity, 0:1].copy_(self._cursor0)
+        else:
+            # one launch: a keyed bijection per (seed, epoch, GLOBAL class id) -- a rank computes its own classes' orders, every
+            # rank that holds a class gets the same one -- and the cursor of the current state copy back to this rank's first row
+            _C.call("cnr_epoch_perm", self.perm, self.pool_rows, C, self._perm_seed, self._epoch, self._class_ids_dev,
+                    self.d_state2[self.parity], int(self._cursor0_host))
+            self._epoch += 1
+        self.cursor = 0
+        direct = w == 1        # no ray shards: the tables go straight into the buffers the kernels read
+        smax = self.slice_max if direct else torch.empty(C, ng, device=self.device)
         _C.call("cnr_slice_maxdepth", self.pool["depth"], self.perm, self.pool_rows, C, self.Rg, ng, smax)
-        tab = torch.empty(ng, C + 1, 4, device=self.device)
+        tab = self.counts_tab if direct else torch.empty(ng, C + 1, 4, device=self.device)
         _C.call("cnr_slice_maskcounts", self.pool["rgbs"], self.pool["depth"], self.perm, self.pool_rows, C, self.Rg, ng,
                 float(self.cfg.min_depth), tab)
         if self.shard == "class" and self.pg is not None and self.world > 1:
             parallel.allreduce_any_(tab[:, C, :3], self.pg)
-        self.slice_max.copy_(smax.repeat_interleave(w, dim=1))
-        self.counts_tab.copy_(tab.repeat_interleave(w, dim=0))
+        if not direct:
+            self.slice_max.copy_(smax.repeat_interleave(w, dim=1))
+            self.counts_tab.copy_(tab.repeat_interleave(w, dim=0))
 
     # ---- reference-named export ------------------------------------------------------------------------
     def state_dicts(self, c=0):

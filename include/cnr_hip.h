@@ -288,6 +288,15 @@ int cnr_field_fwd_render(const float* pts, const float* B, const void* packed, c
 int cnr_slice_maskcounts(const uint8_t* rgbs, const float* depth, const int* perm, int64_t pool_rows, int C, int R,
                          int slices, float min_bound, float* out, void* stream);
 
+/* The epoch shuffle in one launch: perm (C, pool_rows) i32, perm[c] = a pseudo-random permutation of [0, pool_rows) that is a
+ * function of (seed, epoch, class id) only -- class id = class_ids[c] (device, C entries) or c when NULL -- so the ranks of a
+ * class-sharded run produce the same order for a class without drawing each other's (the reference reshuffles with
+ * torch.randperm, src/scene_cateogries.py:439-449; the order is not a parity target).  A keyed 6-round Feistel
+ * bijection, cycle-walked into range.  state_cursor != NULL: the launch also sets state_cursor[0] = cursor0 (the pool cursor of
+ * the device step state starts the epoch).  pool_rows <= 2^30. */
+int cnr_epoch_perm(int* perm, int64_t pool_rows, int C, uint64_t seed, uint64_t epoch, const int* class_ids,
+                   int64_t* state_cursor, int64_t cursor0, void* stream);
+
 /* Max depth of every slice of an epoch in one launch: out[c][s] = max over r < R of depth[c][perm[c][s R + r]]
  * (perm NULL: identity), s < slices, slices * R <= pool_rows.  cnr_step_prologue takes such a table as max_bound when
  * max_bound_slices = slices > 1 and indexes it with the device cursor / R -- the fused trainer fills it once per

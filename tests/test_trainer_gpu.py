@@ -391,7 +391,9 @@ def test_twenty_objects_per_class_train_bitwise_repeatably(cnr, dev):
     torch.cuda.synchronize()
     assert rel_l2(a.losses, b.losses) < 1e-4
     ga, gb = a.grad.double().flatten(), b.grad.double().flatten()
-    assert float(ga @ gb / (ga.norm() * gb.norm())) > 0.9999 and rel_l2(a.grad, b.grad) < 2e-2
+    # (two f16 backward forms on 256 rays: which units sit within rounding of a ReLU edge depends on the batch drawn -- 0.99985 on the
+    #  order cnr_epoch_perm gives this pool, 0.99992 on torch.randperm's; the full-size bar of tests/test_fullsize_gpu.py is 0.9995)
+    assert float(ga @ gb / (ga.norm() * gb.norm())) > 0.9995 and rel_l2(a.grad, b.grad) < 2e-2
 
 
 def test_code_tables_are_their_own_adamw_group(cnr, dev):
@@ -504,11 +506,18 @@ def test_one_launch_step_equals_forward_render_plus_backward(cnr, dev, C, R, n1,
     #  the scaled gradients turns into an f16 ulp here and there; rays that span tiles (S > 32): the one-launch kernel hands d e1 / d e2
     #  to the PE backward as f16, like every other pre-activation gradient of the chain, the two-launch form keeps them fp32: 1.2e-4
     #  on the whole gradient, all of it in dB)
-    assert rel_l2(a["grad"], b["grad"]) < (2e-2 if precise else 3e-4), rel_l2(a["grad"], b["grad"])
-    assert rel_l2(a["theta"], b["theta"]) < (4e-3 if precise else 1e-3)     # first AdamW step: +-lr per entry, the sign of a ~0 gradient entry is noise
+    # (a batch whose only live loss term is saturated -- the one-ray case can draw an "unknown" ray with opacity exactly 1: both
+    #  gradients are then f16 underflow noise of norm 1e-5, six orders under a real one -- has nothing to compare)
+    noise = float(b["grad"].double().norm()) < 1e-3
+    if noise:
+        assert float(a["grad"].double().norm()) < 1e-3       # ... i.e. both negligible
+    else:
+        assert rel_l2(a["grad"], b["grad"]) < (2e-2 if precise else 3e-4), rel_l2(a["grad"], b["grad"])
+        assert rel_l2(a["theta"], b["theta"]) < (4e-3 if precise else 1e-3)     # first AdamW step: +-lr per entry, the sign of a ~0 gradient entry is noise
     for s in range(3):   # still the same training run two steps later (AdamW's sign-like first steps amplify rounding)
         assert torch.isfinite(res["one"][s]["grad"]).all()
-        assert rel_l2(res["one"][s]["losses"], res["two"][s]["losses"]) < 4e-2
+        if not noise:     # (AdamW turns a noise gradient into +-lr per entry: two runs that start from one then differ for real)
+            assert rel_l2(res["one"][s]["losses"], res["two"][s]["losses"]) < 4e-2
 
 
 def test_classes_with_different_object_counts_and_a_single_object_class(cnr, dev):
@@ -604,3 +613,41 @@ def test_slice_mask_count_table_against_torch(cnr, dev, C, R, slices, perm_on):
         assert torch.equal(tab[s_].cpu(), want), s_
     if not perm_on:
         assert tab[0, C, 0] == 1 and tab[0, C, 1] == 1 and tab[slices - 1, C, 1] == 0
+
+
+def test_epoch_perm_is_a_keyed_bijection(dev):
+    """cnr_epoch_perm (the epoch shuffle in one launch): every row is a permutation of [0, n) for powers of two, their neighbours
+    and small n; a function of (seed, epoch, class id) only -- the same class id gives the same order wherever it sits in
+    class_ids, as class shards need --; different epochs / classes / seeds give different orders; no fixed structure (an epoch's
+    order is not the previous one shifted); the cursor of the step state is set by the same launch."""
+    import cnr_amd as cnr
+    _C = cnr._C
+    for n in (1, 2, 7, 64, 1000, 4096, 4097, 131072, 100003):
+        ids = torch.tensor([5, 0, 9], device=dev, dtype=torch.int32)
+        perm = torch.full((3, n), -1, device=dev, dtype=torch.int32)
+        state = torch.tensor([123, 4, 5], device=dev, dtype=torch.int64)
+        _C.call("cnr_epoch_perm", perm, n, 3, 77, 2, ids, state, 640)
+        torch.cuda.synchronize()
+        assert state.tolist() == [640, 4, 5]
+        ar = torch.arange(n, device=dev, dtype=torch.int32)
+        for c in range(3):
+            assert torch.equal(perm[c].sort().values, ar), (n, c)
+        if n >= 64:
+            assert not torch.equal(perm[0], perm[1]) and not torch.equal(perm[1], perm[2])
+            assert float((perm[0] == ar).float().mean()) < 0.2                     # not the identity
+        # class 0 alone, no id table (c = class id), other position: the same order as row 1 above
+        solo = torch.empty(1, n, device=dev, dtype=torch.int32)
+        _C.call("cnr_epoch_perm", solo, n, 1, 77, 2, None, None, 0)
+        assert torch.equal(solo[0], perm[1]), n
+        if n >= 1000:
+            other = torch.empty(1, n, device=dev, dtype=torch.int32)
+            _C.call("cnr_epoch_perm", other, n, 1, 77, 3, None, None, 0)           # next epoch
+            assert not torch.equal(other[0], solo[0])
+            assert float((other[0] == solo[0]).float().mean()) < 0.01
+            d = (other[0].long() - solo[0].long()) % n
+            assert int(d.unique().numel()) > n // 4                                  # not a rotation of the previous epoch
+            _C.call("cnr_epoch_perm", other, n, 1, 78, 2, None, None, 0)           # another seed
+            assert float((other[0] == solo[0]).float().mean()) < 0.01
+            # neighbours in index space land far apart: mean |perm[i + 1] - perm[i]| of a random order is n / 3
+            step = (solo[0][1:].long() - solo[0][:-1].long()).abs().float().mean()
+            assert 0.25 * n < float(step) < 0.42 * n, (n, float(step))
