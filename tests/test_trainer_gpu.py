@@ -120,7 +120,7 @@ def test_eager_one_graph_and_two_graphs_train_identically(cnr, dev):
         gen = torch.Generator().manual_seed(23)
         pools = [cnr.scene_cateogries.synthetic_pool(16 * 256, 4, gen, "cpu")]
         rng = torch.cuda.get_rng_state(dev)
-        torch.cuda.manual_seed(1234)               # the epoch reshuffle draws torch.randperm on the device
+        torch.cuda.manual_seed(1234)               # (CNR_EPOCH_PERM=torch: the epoch reshuffle then draws torch.randperm on the device)
         tr = cnr.fused.FusedCategoryTrainer(cfg, 1, 4, pools, 256, dev, seed=9, generator=gen, **kw)
         for _ in range(40):                        # 16 x 256 rows / 256 per step: crosses two epoch reshuffles
             tr.step()
