@@ -201,30 +201,169 @@ def fp8_leg(args):
                               "fragment where the f16 kernel needs one of the same rate"}))
 
 
-def launch_ranks(n, argv):
+def dropin_vmap_flow(cnr_amd, dev, C, R, n1, n2, L, n_obj, steps=30, warmup=5):
+    """ms per iteration of INTEGRATION.md section 1's flow: the reference's own loop (train.py:98-201) on the drop-in modules --
+    ``get_training_samples`` per category, ``nn.Embedding`` code lookups, ``vmap(pe_model)`` / ``vmap(fc_model)`` over the
+    ``update_vmap`` ensembles, ``loss.step_batch_loss`` + regulariser, ``backward``, ``torch.optim.AdamW.step``, the per-step
+    copy-back.  This is the exact-fp32 modular tier (one kernel per reference function), NOT the benchmarked fused step."""
+    from torch.func import vmap
+    cfg = cnr_amd.cfg.synthetic_config(device=str(dev), latent_dim=L, obj_scale=2.0 if L == 256 else 3.0,
+                                       n_bins_cam2surface=n1, n_bins=n2)
+    cls_dict = {}
+    opt = torch.optim.AdamW([torch.zeros(1, device=dev, requires_grad=True)], lr=cfg.learning_rate, weight_decay=cfg.weight_decay)
+    for c in range(C):
+        pool = cnr_amd.scene_cateogries.synthetic_pool(16 * R, n_obj, torch.Generator().manual_seed(4321 + c), "cpu")
+        sc = cnr_amd.scene_cateogries.sceneCategory.from_pool(cfg, c + 1, list(range(n_obj)), pool, seed=c)
+        cls_dict[c + 1] = sc
+        for params, lr, wd in ((sc.trainer.fc_occ_map.parameters(), cfg.learning_rate, cfg.weight_decay),
+                               (sc.trainer.pe.parameters(), cfg.learning_rate, cfg.weight_decay),
+                               (sc.trainer.shape_codes.parameters(), cfg.code_learning_rate, cfg.code_weight_decay),
+                               (sc.trainer.texture_codes.parameters(), cfg.code_learning_rate, cfg.code_weight_decay)):
+            opt.add_param_group({"params": params, "lr": lr, "weight_decay": wd})          # train.py:58-64
+    fc_model, fc_param, fc_buffer = cnr_amd.utils.update_vmap([k.trainer.fc_occ_map for k in cls_dict.values()], opt)
+    pe_model, pe_param, pe_buffer = cnr_amd.utils.update_vmap([k.trainer.pe for k in cls_dict.values()], opt)
+    cls_ids = torch.arange(C, device=dev)
+
+    def iteration():
+        acc = [[] for _ in range(9)]
+        for cls_k in cls_dict.values():
+            gt_rgb, gt_depth, depth_mask, obj_mask, pcs, z, indices = cls_k.get_training_samples(R)
+            for lst, v in zip(acc, (gt_depth, gt_rgb, depth_mask, obj_mask, pcs, z, indices,
+                                    cls_k.trainer.shape_codes(indices)[:, None, :], cls_k.trainer.texture_codes(indices)[:, None, :])):
+                lst.append(v)
+        gt_depth, gt_rgb, depth_mask, obj_mask, pcs, z, _, cs, ct = [torch.stack(a) for a in acc]
+        emb = vmap(pe_model)(pe_param, pe_buffer, pcs)
+        alpha, color = vmap(fc_model)(fc_param, fc_buffer, emb, cs, ct)
+        loss, _, _ = cnr_amd.loss.step_batch_loss(alpha, color, gt_depth.detach(), (gt_rgb / 255.).detach(), obj_mask.detach(),
+                                                  depth_mask.detach(), z.detach())
+        rs, rt = cnr_amd.loss.step_batch_loss_reg(cls_dict, cls_ids)
+        loss = loss + 0.0005 * (rs + rt).sum()
+        loss.backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        with torch.no_grad():                                                               # train.py:196-201
+            for m, cls_k in enumerate(cls_dict.values()):
+                for i, prm in enumerate(cls_k.trainer.fc_occ_map.parameters()):
+                    prm.copy_(fc_param[i][m])
+                for i, prm in enumerate(cls_k.trainer.pe.parameters()):
+                    prm.copy_(pe_param[i][m])
+    for _ in range(warmup):
+        iteration()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        iteration()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"workload": f"{C} categor{'y' if C == 1 else 'ies'} x {n_obj} objects, {R} rays x {n1 + n2} samples: the reference's loop "
+                        "(train.py:98-201: get_training_samples, vmap(pe), vmap(fc), step_batch_loss, backward, torch AdamW, copy-back) "
+                        "on the drop-in modules = the exact-fp32 modular tier, eager",
+            "steps": steps, "ms_per_step": dt * 1e3, "rays_per_s": C * R / dt}, cls_dict, cfg
+
+
+def dropin_from_scene(cnr_amd, cls_dict, cfg, R, steps=2000):
+    """... and the SAME sceneCategory objects handed to ``FullStepTrainer.from_scene``: the fused step behind the reference's
+    objects (their pools, their modules' parameters), ``sync_to_modules()`` instead of the per-step copy-back."""
+    full = cnr_amd.background.FullStepTrainer.from_scene(cls_dict, None, cfg, rays_per_step=R, seed=0)
+    full.run(8)
+    full.obj.prepare_graphs()
+    full.run(2 * full.obj.unroll + 2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    full.run(steps)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    t1 = time.perf_counter()
+    full.sync_to_modules()
+    torch.cuda.synchronize()
+    return {"workload": "FullStepTrainer.from_scene(cls_dict, None, cfg) on the sceneCategory objects of dropin_vmap_flow: the fused "
+                        "f16 step (3 launches, hipGraph) on their pools and parameters", "steps": steps, "ms_per_step": dt * 1e3,
+            "rays_per_s": len(cls_dict) * R / dt, "sync_to_modules_ms": (time.perf_counter() - t1) * 1e3}
+
+
+def strong_leg(cnr_amd, cfg, dev, pg, rank, world, n_cls, R, n_obj, steps, sync, timed_run):
+    """north_star's own target, readable from ONE driver line: BASELINE.json configs[2]'s shape -- `n_cls` categories in total,
+    whole categories per GPU, no gradient collective -- on all `world` ranks, and the same `n_cls` categories on rank 0's GPU alone,
+    measured in the same run.  Both are exactly `steps` steps between barriers; the N-rank time is the max over ranks."""
+    ids = cnr_amd.parallel.class_shard(n_cls, rank, world)
+    mk = lambda cids, group, shard: cnr_amd.fused.FusedCategoryTrainer(
+        cfg, len(cids), n_obj, [cnr_amd.scene_cateogries.synthetic_pool(64 * R, n_obj, torch.Generator().manual_seed(1234 + 17 * (c + 1)), "cpu")
+                                for c in cids], R, dev, seed=0, generator=torch.Generator().manual_seed(1234), process_group=group,
+        shard=shard, n_cls_global=n_cls if shard else None, class_ids=cids if shard else None)
+
+    def measure(tr):
+        tr.run(4)
+        tr.prepare_graphs()
+        tr.run(2 * tr.unroll + 3)
+        tr.run(max(steps // 2, 8))
+        return timed_run(tr, steps)
+    trN = mk(ids, pg, "class")
+    dtN = measure(trN)
+    del trN
+    torch.cuda.empty_cache()
+    dt1 = None
+    if rank == 0:                      # the single-GPU reference point: all categories on this rank's GPU, no process group
+        tr1 = mk(list(range(n_cls)), None, None)
+        tr1.run(4)
+        tr1.prepare_graphs()
+        tr1.run(2 * tr1.unroll + 3)
+        tr1.run(max(steps // 2, 8))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tr1.run(steps)
+        torch.cuda.synchronize()
+        dt1 = time.perf_counter() - t0
+        del tr1
+    sync()
+    rays = n_cls * R * steps
+    return {"workload": f"BASELINE.json configs[2] shape: {n_cls} categories x {n_obj} objects x {R} rays in total, whole categories per GPU, "
+                        f"no gradient collective; fixed global batch (strong scaling)", "classes_total": n_cls, "steps": steps,
+            "n_rank_ms_per_step": dtN / steps * 1e3, "n_rank_rays_per_s": rays / dtN,
+            "one_rank_ms_per_step": None if dt1 is None else dt1 / steps * 1e3,
+            "one_rank_rays_per_s": None if dt1 is None else rays / dt1,
+            "speedup_vs_one_rank_same_run": None if dt1 is None else dt1 / dtN}
+
+
+def launch_ranks(n, argv, timeout_s=900.0):
     """`python bench.py --gpus N` outside a launcher: start N ranks of this script as a FRESH child process tree
     (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>`), pass rank 0's JSON
     line through and exit with the children's code.  The parent has made no HIP call (it never replaces itself either: the
     children are ordinary subprocesses), so an N-rank line or a failure are the only outcomes -- never a 1-rank line
     that says N."""
-    import socket
     import subprocess
     if not os.environ.get("CNR_SINGLE_DEVICE_REHEARSAL") and os.environ.get("CNR_DIST_BACKEND", "nccl") == "nccl":
         have = torch.cuda.device_count()                 # counts devices without initialising one
         if have < n:
             raise SystemExit(f"bench.py --gpus {n}: this node shows {have} GPU(s)")
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    # The rendezvous port is picked by torch.distributed.run itself (--standalone: a c10d store on a free port, bound by the
+    # agent that uses it), not by a bind()/close() here that another process could win the race for.
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={n}", os.path.abspath(__file__)] + list(argv)
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
     env.setdefault("OMP_NUM_THREADS", "8")
-    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    # A child tree of its own (new session = new process group) with a deadline: RCCL bring-up or a collective that never
+    # returns must end in a message and a non-zero exit, not in a bench that blocks its driver forever.
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        stdout, _ = proc.communicate(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        import signal
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(proc.pid, sig)        # exactly the group this call created
+            except ProcessLookupError:
+                break
+            try:
+                proc.wait(timeout=10)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        raise SystemExit(f"bench.py --gpus {n}: the {n}-rank launch did not finish within {timeout_s:.0f} s "
+                         "(--launch-timeout); its process group was killed")
     line = None
-    for ln in proc.stdout.splitlines():
+    for ln in stdout.splitlines():
         if ln.startswith("{") and '"n_gpus"' in ln:
             line = ln
         else:
@@ -287,6 +426,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--long-seconds", type=float, default=2.0, help="length of the long_run leg reported beside the timed region")
+    ap.add_argument("--strong-classes", type=int, default=16,
+                    help="N > 1: categories in total of the strong_configs2 leg (BASELINE.json configs[2]'s stand-in count); 0 = skip")
+    ap.add_argument("--launch-timeout", type=float, default=900.0,
+                    help="seconds the self-started N-rank child tree may take before its process group is killed")
     ap.add_argument("--launch-check", action="store_true",
                     help="bring the ranks up, all-reduce a one over the process group and print the world size the "
                          "backend reports -- no kernel runs (a check of the launcher, not a benchmark)")
@@ -299,7 +443,7 @@ def main():
         raise SystemExit("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ:
         if args.gpus > 1:                      # not under a launcher yet: become one (nothing has touched the GPU)
-            return launch_ranks(args.gpus, sys.argv[1:])
+            return launch_ranks(args.gpus, sys.argv[1:], args.launch_timeout)
     elif int(os.environ["WORLD_SIZE"]) != args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={os.environ['WORLD_SIZE']}: "
                          "the two must agree (the line would claim a GPU count that did not run)")
@@ -366,10 +510,10 @@ def main():
             torch.distributed.barrier()
             torch.cuda.synchronize()
 
-    def timed(n_steps):
+    def timed_run(trainer, n_steps):
         sync()
         t0 = time.perf_counter()
-        tr.run(n_steps)        # = n_steps x tr.step(); groups of tr.unroll steps go out as one hipGraph launch each
+        trainer.run(n_steps)   # = n_steps x step(); groups of trainer.unroll steps go out as one hipGraph launch each
         sync()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -377,6 +521,8 @@ def main():
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             dt = float(t.item())
         return dt
+
+    timed = lambda n_steps: timed_run(tr, n_steps)
 
     dbg("trainer built")
     tr.run(4)                   # (the step's buffers exist after two steps)
@@ -393,9 +539,9 @@ def main():
     dbg("timed region done")
     ms_per_step = dt / args.steps * 1e3
     rays_per_s = rays_per_step_global * args.steps / dt
-    # the same measurement over >= 0.5 s of steps (a 20-step region at 0.08 ms per step is 1.6 ms long): reported beside
-    # it, never instead of it
-    n_long = max(args.steps, int(0.5 / max(dt / args.steps, 1e-6)) + 1)
+    # the same measurement over >= 2 s of steps (a 20-step region at 0.06 ms per step is 1.2 ms long -- shorter than any utilisation
+    # sampler's period): reported beside it, never instead of it
+    n_long = max(args.steps, int(args.long_seconds / max(dt / args.steps, 1e-6)) + 1)
     if world > 1:
         tl = torch.tensor([n_long], device=dev, dtype=torch.int64)
         torch.distributed.all_reduce(tl, op=torch.distributed.ReduceOp.MAX)
@@ -434,14 +580,14 @@ def main():
     # HBM bytes of that call from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc passes,
     # gfx950 corrections per MI355X_MICROARCH.md): measured offline on this shape, kept in profiles/
     traffic = None
-    for tname in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for tname in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", tname)
         if dom == bwd_name and (C, R, S) == (1, 2048, 64) and os.path.exists(tpath):
             traffic = json.load(open(tpath)).get(bwd_name + "_call_hbm_bytes")
             break
     roofline = {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_MFMA_F16_TFLOPS, "traffic": traffic,
-                "variant": cnr_amd.ops.FIELD_BWD_VARIANT,
+                "variant": "pipe8 (4 chain + 4 weight-gradient waves per workgroup)" if cnr_amd.ops.FIELD_BWD_VARIANT == "pipe4" else cnr_amd.ops.FIELD_BWD_VARIANT,
                 "kernel_ms": {k: round(v, 5) for k, v in avg.items()},
                 "kernel_ms_note": "HIP events on the launch stream; %s back to back, median of five batches of ten launches (one launch at a time in the "
                                   "eager step, gaps included: %.5f), the others one launch at a time" % (bwd_name, eager_bwd_ms),
@@ -468,6 +614,16 @@ def main():
                       "hipgraph": (f"{tr.unroll} steps per graph launch (halving group sizes down to single steps at epoch ends)" if not tr.grad_exchange else "two graphs around the all-reduce, per state parity") if not args.no_graph else False,
                       "n_cu": info["n_cu"]},
            "long_run": long_run, "roofline": roofline}
+    if world > 1:
+        ranks = torch.ones(1, device=dev if backend == "nccl" else "cpu")
+        torch.distributed.all_reduce(ranks)
+        out["world_size"], out["dist_backend"], out["ranks_answering"] = world, torch.distributed.get_backend(), int(ranks.item())
+        if args.strong_classes >= world and shard == "class":
+            try:
+                out["strong_configs2"] = strong_leg(cnr_amd, cfg, dev, pg, rank, world, args.strong_classes, args.rays, n_obj,
+                                                    max(args.steps, 20), sync, timed_run)
+            except Exception as e:          # never lose the main line over the extra leg
+                out["strong_configs2"] = f"failed: {type(e).__name__}: {e}"
     if world > 1 and shard == "ray":   # outside the timed region: every rank must hold bitwise identical parameters after the run
         try:
             out["config"]["params_in_sync"] = bool(cnr_amd.parallel.params_in_sync(tr.theta.contiguous(), pg))
@@ -522,6 +678,36 @@ def main():
                 "category_rays_per_s": R * 500 / d3, "all_rays_per_s": (R + 1200) * 500 / d3}
         except Exception as e:
             out["extra_legs"]["full_iteration_bg_plus_category"] = f"failed: {e}"
+    if world == 1 and not args.no_extra_legs:
+        # the two tiers behind the reference's call surface, side by side (VERDICT r03 row h): train.py's own loop on the drop-in
+        # modules, and the fused step built from the same sceneCategory objects
+        try:
+            leg, cls_dict_d, cfg_d = dropin_vmap_flow(cnr_amd, dev, C, R, n1, n2, L, n_obj)
+            out["extra_legs"]["dropin_vmap_flow"] = leg
+            out["extra_legs"]["dropin_from_scene"] = dropin_from_scene(cnr_amd, cls_dict_d, cfg_d, R)
+            del cls_dict_d
+        except Exception as e:
+            out["extra_legs"]["dropin_vmap_flow"] = f"failed: {type(e).__name__}: {e}"
+        # the ray-sharded step's structure on ONE GPU, no collective: two graphs + the gap where the all-reduce goes, three host
+        # calls per step -- what that form costs before any communication
+        try:
+            # (dp_world = 2 without a process group: rank 0 of a two-rank ray-sharded world whose gradient exchange is left out --
+            #  front graph = prologue + field_train + step_grad, back graph = tail without the latent blocks, as with RCCL)
+            trs = cnr_amd.fused.FusedCategoryTrainer(cfg, C, n_obj, pools, R, dev, seed=0, generator=torch.Generator().manual_seed(1234),
+                                                     shard="ray", dp_world=2, dp_rank=0)
+            trs.run(50)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            trs.run(1000)
+            torch.cuda.synchronize()
+            d4 = (time.perf_counter() - t0) / 1000
+            out["extra_legs"]["split_graph_step_1gpu"] = {
+                "workload": "rank 0 of a 2-rank ray-sharded step with the all-reduce left out: two hipGraphs per step (front: prologue + "
+                            "field_train + step_grad; back: tail), three host calls per step, same rays per rank as the main line", "steps": 1000, "ms_per_step": d4 * 1e3,
+                "rays_per_s": C * R / d4, "host_cost_vs_one_graph_ms": d4 * 1e3 - long_run["ms_per_step"]}
+            del trs
+        except Exception as e:
+            out["extra_legs"]["split_graph_step_1gpu"] = f"failed: {type(e).__name__}: {e}"
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline((C, R, n1, n2, L, n_obj), args.cpu_seconds)

@@ -15,15 +15,22 @@ from . import _C, loss as loss_mod, ops, trainer as trainer_mod
 
 
 class BackgroundStep:
-    def __init__(self, cfg, pool, rays_per_step=None, device=None, seed=0, precision="fp32"):
+    def __init__(self, cfg, pool, rays_per_step=None, device=None, seed=0, precision="fp32", trainer=None):
+        """``trainer``: an existing ``Trainer(cls_id=0)`` to train in place (``scene_bg.trainer`` of train.py:49-53) -- its
+        modules' parameters become views of this step's flat buffer, so whatever reads them afterwards (``save_checkpoints``,
+        ``eval_points``, meshing) sees the trained values with no copy-back.  Default: a fresh one."""
         import copy
         self.cfg = cfg
         self.device = torch.device(device or cfg.training_device)
         self.R = int(rays_per_step or cfg.n_per_optim_bg)
         self.n1, self.n2 = cfg.n_bins_cam2surface_bg, cfg.n_bins
-        tcfg = copy.copy(cfg)
-        tcfg.hidden_feature_size, tcfg.obj_scale, tcfg.training_device = cfg.hidden_feature_size_bg, cfg.bg_scale, str(self.device)
-        self.trainer = trainer_mod.Trainer(tcfg, 0, [0])                     # .pe, .fc_occ_map (src/trainer.py:23-25)
+        if trainer is None:
+            tcfg = copy.copy(cfg)
+            tcfg.hidden_feature_size, tcfg.obj_scale, tcfg.training_device = cfg.hidden_feature_size_bg, cfg.bg_scale, str(self.device)
+            trainer = trainer_mod.Trainer(tcfg, 0, [0])                      # .pe, .fc_occ_map (src/trainer.py:23-25)
+        else:
+            assert trainer.cls_id == 0 and next(trainer.fc_occ_map.parameters()).device == self.device
+        self.trainer = trainer
         assert precision in ("fp32", "f16", "fused")
         # "fp32": the exact tier -- one launch per layer (cnr_dense_*: fp32 MFMA) under torch autograd, pinned to the reference's
         #         bg_*.npz vectors at 2e-5 (the default of this class; the parity tier);
@@ -234,6 +241,12 @@ class BackgroundStep:
         _C.call("cnr_bg_pack", self.flat, self.fb["packed"])
         self._packed_for = self.flat._version
 
+    def reset_optimizer(self):
+        """a fresh AdamW (both moments zero, step counter 0) -- what the reference's resume amounts to (train.py:40,66-68)"""
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        self.d_state[2:3].zero_()
+
     def pre_step(self):
         if self.precision == "fused" and (self._packed_for is None or self._packed_for != self.flat._version):
             self.repack()
@@ -267,19 +280,118 @@ class FullStepTrainer:
 
     def __init__(self, categories, background, concurrent=None):
         """concurrent: capture the background step on a second stream (forked from / joined to the capturing stream), so that
-        the graph holds two independent chains -- the two branches share no parameter and no buffer.  Default: on."""
+        the graph holds two independent chains -- the two branches share no parameter and no buffer.  Default: on.
+        ``background`` may be None (a scene without a background model, train.py:113 ``if scene_bg is not None``): the iteration is
+        then the category step alone and ``run`` / ``step`` are the category trainer's."""
         import os
         self.obj, self.bg = categories, background
         assert not self.obj.grad_exchange, "ray-sharded category steps run a collective between their two graphs"
         self.graphs = {}
         self.steps_done = 0
         self.concurrent = bool(int(os.environ.get("CNR_FULLSTEP_CONCURRENT", "1"))) if concurrent is None else bool(concurrent)
+        self.concurrent = self.concurrent and background is not None
         self._side = torch.cuda.Stream(device=self.obj.device) if self.concurrent else None
         # run(): fork once per graph (True) or once per iteration (False: every iteration ends with a join of the two chains)
         self.free_chains = os.environ.get("CNR_FULLSTEP_FREE", "1") != "0"
+        self.categories, self.scene_bg = None, None        # the reference-side objects (from_scene)
+
+    # ---- behind the reference's objects (train.py:33-96 builds them, :98-201 is what this class replaces) -----------------------
+    @staticmethod
+    def pool_of(scene_category):
+        """the ``*_batch_all`` pool of a ``sceneCategory`` (src/scene_cateogries.py:211-249) as the fused trainers' pool dict"""
+        sc = scene_category
+        pool = dict(rgbs=sc.rgbs_batch_all, depth=sc.depth_batch_all, dirs=sc.ray_dirs_batch_all, indices=sc.batch_indices_all)
+        if sc.world_frame:           # background and single-object categories: world-frame rays (:374-386, :427-432)
+            pool["T_wc"] = sc.t_wc_batch_all
+        else:
+            pool["T_co"] = sc.t_co_batch_all
+        return pool
+
+    @staticmethod
+    def module_state(trainer):
+        """a ``Trainer``'s parameters in the checkpoint schema ``FusedCategoryTrainer.load_state_dicts`` reads"""
+        return dict(FC_state_dict=trainer.fc_occ_map.state_dict(), PE_state_dict=trainer.pe.state_dict(),
+                    shape_code_state_dict=trainer.shape_codes.state_dict(),
+                    texture_code_state_dict=trainer.texture_codes.state_dict())
+
+    @classmethod
+    def from_scene(cls, cls_dict, scene_bg, cfg, rays_per_step=None, seed=0, bg_precision="fused", concurrent=None, **trainer_kw):
+        """The fused iteration behind the objects the reference's ``train.py`` builds: ``cls_dict`` {cls_id: sceneCategory}
+        (object categories, train.py:55-64), ``scene_bg`` the background ``sceneCategory`` or None (train.py:50-53), ``cfg`` the
+        ``Config``.  Takes each category's ray pool as it stands (``*_batch_all``: any lengths, any object counts, world-frame
+        single-object categories), its ``trainer.fc_occ_map`` / ``pe`` / ``shape_codes`` / ``texture_codes`` as the initial
+        parameters, and the reference's batch size ``n_objs * cfg.n_per_optim // n_cls`` rays per category (train.py:92-96)
+        unless ``rays_per_step`` says otherwise.  The background model trains IN PLACE (its modules' parameters become views of
+        the step's flat buffer); the categories' modules are refreshed by :meth:`sync_to_modules` -- the copy-back of
+        train.py:196-201, needed only before something reads the modules (checkpoint, ``eval_points``, meshing), not per step.
+
+            full = FullStepTrainer.from_scene(cls_dict, scene_bg, cfg)
+            for it in range(start, cfg.max_iter, cfg.log_iter):
+                full.run(cfg.log_iter)                         # train.py:98-201, cfg.log_iter times
+                losses = full.loss_dict()                      # what train.py:186-192 logs
+                if it % cfg.save_iter == 0:
+                    full.sync_to_modules()
+                    for k in vis_dict.values(): k.save_checkpoints(ckpt_dir, it)
+        """
+        from . import fused
+        cats = list(cls_dict.values())
+        assert cats, "no object category"
+        dev = torch.device(cfg.training_device)
+        n_objs = [len(c.obj_ids) for c in cats]
+        R = int(rays_per_step) if rays_per_step else sum(n_objs) * cfg.n_per_optim // len(cats)
+        tr = fused.FusedCategoryTrainer(cfg, len(cats), n_objs, [cls.pool_of(c) for c in cats], R, dev, seed=seed,
+                                        world_frame=[bool(c.world_frame) for c in cats], **trainer_kw)
+        for k, c in enumerate(cats):
+            tr.load_state_dicts(cls.module_state(c.trainer), k, reset=None)
+        bg = None
+        if scene_bg is not None:
+            hidden = scene_bg.trainer.fc_occ_map.in_layer[0].out_features
+            prec = bg_precision if (bg_precision != "fused" or hidden == 128) else "fp32"   # the fused step is built for 128
+            bg = BackgroundStep(cfg, cls.pool_of(scene_bg), cfg.n_per_optim_bg, dev, seed=seed, precision=prec,
+                                trainer=scene_bg.trainer)
+        self = cls(tr, bg, concurrent=concurrent)
+        self.categories, self.scene_bg, self.cls_ids = cats, scene_bg, list(cls_dict.keys())
+        return self
+
+    def sync_to_modules(self):
+        """train.py:196-201: the trained values back into every category's ``trainer.fc_occ_map`` / ``trainer.pe`` -- and, since
+        the fused step owns the code tables too, ``shape_codes`` / ``texture_codes`` -- so that ``save_checkpoints``,
+        ``Trainer.eval_points`` and meshing read them.  The background's modules are views of the live buffer already."""
+        assert self.categories is not None, "built without the reference's objects: use state_dicts()"
+        with torch.no_grad():
+            for k, c in enumerate(self.categories):
+                sd, t = self.obj.state_dicts(k), c.trainer
+                t.fc_occ_map.load_state_dict(sd["FC_state_dict"])
+                t.pe.B_layer.weight.copy_(sd["PE_state_dict"]["B_layer.weight"])
+                t.shape_codes.weight.copy_(sd["shape_code_state_dict"]["weight"])
+                t.texture_codes.weight.copy_(sd["texture_code_state_dict"]["weight"])
+
+    def load_from_modules(self):
+        """the other direction: after ``sceneCategory.load_checkpoints`` (a resume, train.py:66-86) the modules' values become the
+        fused trainers' parameters; the optimiser starts afresh, as the reference's does"""
+        assert self.categories is not None
+        for k, c in enumerate(self.categories):
+            self.obj.load_state_dicts(self.module_state(c.trainer), k, reset=None)
+        self.obj.reset_optimizer()
+        if self.bg is not None:
+            self.bg.reset_optimizer()
+            if self.bg.precision == "fused":       # the modules are views of bg.flat: their new values need new fragment images
+                self.bg.repack()
+
+    def loss_dict(self):
+        """the last iteration's loss terms in the layout train.py:156-180 logs: {'depth','color','opacity': (C,)} for the
+        categories, 'background': the same three for the background model (device tensors, no sync)"""
+        l = self.obj.loss_values()
+        d = {"depth": l[0], "color": l[1], "opacity": l[2]}
+        if self.bg is not None:
+            b = self.bg.losses
+            d["background"] = {"depth": b[0:1], "color": b[1:2], "opacity": b[2:3]}
+        return d
 
     def _both(self):
         """background + categories, on one stream or forked onto two"""
+        if self.bg is None:
+            return self.obj._step_body()
         if not self.concurrent:
             self.bg._body()
             self.obj._step_body()
@@ -297,13 +409,18 @@ class FullStepTrainer:
         a group replays unchanged; it never crosses an epoch end of either pool (the reshuffles are host-launched).  Between two
         graph launches the GPU idles ~8 us: 5 % of a 0.15 ms iteration."""
         o, b = self.obj, self.bg
+        if b is None:
+            self.steps_done += n
+            return o.run(n, unroll)
+        # even group sizes only, like FusedCategoryTrainer.run: a group leaves the parameter / state ping-pong where it found it
+        unroll = max(2, int(unroll) // 2 * 2)
         while n > 0:
             o._pre_step()
             b.pre_step()
             left = min(-(-(o.pool_rows - o.Rg - o.cursor) // o.Rg), -(-(b.pool_rows - b.R - b.cursor) // b.R))
             U = 0
             if self.steps_done >= 3 and o.use_graph:
-                for u in o._group_sizes(min(int(unroll), o.unroll)):
+                for u in o._group_sizes(min(unroll, o.unroll)):
                     if u <= n and u <= left:
                         U = u
                         break
@@ -336,6 +453,7 @@ class FullStepTrainer:
                             o.parity ^= 1
                 o._out_slot, o.parity = None, par0
                 self.graphs[key] = g
+            assert U % 2 == 0
             self.graphs[key].replay()
             before = o.steps_done
             o._last_multi = U - 1
@@ -352,6 +470,9 @@ class FullStepTrainer:
 
     def step(self):
         o, b = self.obj, self.bg
+        if b is None:
+            self.steps_done += 1
+            return o.step()
         o._pre_step()
         b.pre_step()
         par = o.parity

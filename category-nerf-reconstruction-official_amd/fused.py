@@ -131,7 +131,12 @@ class FusedCategoryTrainer:
         else:
             self.n_cls_global, self.class_ids = n_cls, list(range(n_cls))
         theta_all, self.lay = init_params(self.n_cls_global, self.L, n_obj, generator, "cpu")
-        theta0 = theta_all[self.class_ids].contiguous().to(self.device)
+        theta0 = theta_all[self.class_ids].contiguous()
+        for c, k in enumerate(n_obj_list):          # code rows beyond a class's own objects: unused, kept at zero
+            v0 = self.lay.views(theta0)
+            v0["shape"][c, k:] = 0
+            v0["tex"][c, k:] = 0
+        theta0 = theta0.to(self.device)
         # parameters in two copies, like the step state: step k reads copy k & 1, its last launch (AdamW, out of place)
         # writes copy (k + 1) & 1 -- gradient kernels and the optimiser never touch the same copy in one launch
         self.theta2 = torch.stack([theta0, theta0.clone()])
@@ -167,12 +172,22 @@ class FusedCategoryTrainer:
         if world_frame is None:
             world_frame = [k == 1 and "T_wc" in p for k, p in zip(n_obj_list, pools)]
         self.world_frame = [bool(world_frame)] * n_cls if isinstance(world_frame, (bool, int)) else [bool(w) for w in world_frame]
-        st = lambda k: torch.stack([p[k] for p in pools]).to(self.device).contiguous()
-        T = torch.stack([torch.linalg.inv(p["T_wc"]) if wf else p["T_co"] for p, wf in zip(pools, self.world_frame)])
-        self.pool = dict(rgbs=st("rgbs"), depth=st("depth"), dirs=st("dirs"), T=T.to(self.device).contiguous(),
-                         indices=st("indices"))
-        self.pool_rows = self.pool["depth"].shape[1]
-        assert self.pool_rows >= 2 * self.Rg
+        # Pools of different lengths (every real scene: a category's pool is the sum of its instances' crop areas,
+        # src/scene_cateogries.py:164-260) are padded to the longest; a padding row is never referenced, because the step
+        # reaches the pool only through the permutation `perm`, which _reshuffle fills per class from the class's OWN rows
+        self.pool_rows_cls = [int(p["depth"].shape[0]) for p in pools]
+        self.pool_rows = max(self.pool_rows_cls)
+        self.ragged = min(self.pool_rows_cls) != self.pool_rows
+
+        def padded(t):
+            t = t.to(self.device)
+            if t.shape[0] == self.pool_rows:
+                return t
+            return torch.cat([t, t[:1].expand(self.pool_rows - t.shape[0], *t.shape[1:])])
+        st = lambda k: torch.stack([padded(p[k]) for p in pools]).contiguous()
+        T = torch.stack([padded(torch.linalg.inv(p["T_wc"]) if wf else p["T_co"]) for p, wf in zip(pools, self.world_frame)])
+        self.pool = dict(rgbs=st("rgbs"), depth=st("depth"), dirs=st("dirs"), T=T.contiguous(), indices=st("indices"))
+        assert min(self.pool_rows_cls) >= 2 * self.Rg, "every class's pool must hold two slices of rays"
         if self.shard == "class" and self.pg is not None and self.world > 1:
             # the per-epoch OR of the empty flags is a collective issued at every reshuffle: all ranks must reshuffle in the
             # same steps, i.e. hold pools of the same length and take the same rays per step -- checked here, where a
@@ -196,6 +211,12 @@ class FusedCategoryTrainer:
         # epoch shuffle: cnr_epoch_perm (one launch; the order is a function of seed, epoch and global class id) unless
         # CNR_EPOCH_PERM=torch asks for torch.randperm from one generator, as rounds 1-3 did (a dozen launches per epoch end)
         self._torch_perm = os.environ.get("CNR_EPOCH_PERM", "kernel") == "torch"
+        assert not (self.ragged and self._torch_perm), "pools of different lengths need the kernel permutation (cnr_epoch_perm)"
+        # ragged pools: each class walks its OWN epochs (a reshuffle whenever i_batch >= N_c - n, src/scene_cateogries.py:439-449);
+        # per class the epoch it is in and the slice of that epoch the next filled permutation row starts with
+        self._cls_epoch = [0] * n_cls
+        self._cls_slice = [0] * n_cls
+        self._perm_scratch = torch.empty(self.pool_rows, device=self.device, dtype=torch.int32) if self.ragged else None
         self._perm_seed, self._epoch, self._cursor0_host = 0x5EED + 7919 * int(seed), 0, self.ray_rank * self.R
         self._class_ids_dev = torch.tensor(self.class_ids, device=self.device, dtype=torch.int32)
         # per-epoch tables, one entry per LOCAL slice (index = device cursor / R): the max depth of the (global) slice
@@ -617,6 +638,8 @@ class FusedCategoryTrainer:
                 if cg in self.class_ids:
                     self.perm[self.class_ids.index(cg)].copy_(p)
             self.d_state2[self.parity, 0:1].copy_(self._cursor0)
+        elif self.ragged:
+            self._ragged_perm()
         else:
             # one launch: a keyed bijection per (seed, epoch, GLOBAL class id) -- a rank computes its own classes' orders, every
             # rank that holds a class gets the same one -- and the cursor of the current state copy back to this rank's first row
@@ -636,6 +659,31 @@ class FusedCategoryTrainer:
             self.slice_max.copy_(smax.repeat_interleave(w, dim=1))
             self.counts_tab.copy_(tab.repeat_interleave(w, dim=0))
 
+    def _ragged_perm(self):
+        """Pools of different lengths.  The reference gives every category its own cursor: class c takes slices of n rows and
+        reshuffles ITS pool when i_batch >= N_c - n (src/scene_cateogries.py:436-449), i.e. after k_c = ceil(N_c / n) - 1 slices.
+        The step's kernels share one device cursor, so the permutation row of class c is laid out as what that class will read
+        over the next K = max_c k_c steps: the rest of its current epoch's order, then as many further epochs of ITS OWN pool
+        (each a keyed bijection of (seed, class epoch, global class id) on [0, N_c): cnr_epoch_perm) as fit.  Where a class is
+        in its epoch carries over to the next call.  Host work per (longest-class) epoch, nothing per step."""
+        Rg = self.Rg
+        K = -(-self.pool_rows // Rg) - 1               # steps until the host reshuffles again (= the longest class's epoch)
+        for c, N in enumerate(self.pool_rows_cls):
+            k_c = -(-N // Rg) - 1                      # slices per epoch of this class
+            row, filled = self.perm[c], 0
+            while filled < K:
+                _C.call("cnr_epoch_perm", self._perm_scratch, N, 1, self._perm_seed, self._cls_epoch[c],
+                        self._class_ids_dev[c:c + 1], None, 0)
+                take = min(k_c - self._cls_slice[c], K - filled)
+                a = self._cls_slice[c] * Rg
+                row[filled * Rg:(filled + take) * Rg].copy_(self._perm_scratch[a:a + take * Rg])
+                filled += take
+                self._cls_slice[c] += take
+                if self._cls_slice[c] == k_c:
+                    self._cls_slice[c], self._cls_epoch[c] = 0, self._cls_epoch[c] + 1
+            row[K * Rg:].zero_()                       # never read (the host reshuffles after K slices); kept in range
+        self.d_state2[self.parity, 0:1].copy_(self._cursor0)
+
     # ---- reference-named export ------------------------------------------------------------------------
     def state_dicts(self, c=0):
         v = self.lay.views(self.theta)
@@ -650,10 +698,19 @@ class FusedCategoryTrainer:
                     shape_code_state_dict={"weight": v["shape"][c, :self.n_obj_list[c]].clone()},
                     texture_code_state_dict={"weight": v["tex"][c, :self.n_obj_list[c]].clone()}, obj_scale=self.scale)
 
-    def load_state_dicts(self, d, c=0):
+    def load_state_dicts(self, d, c=0, reset="class"):
         """Inverse of :meth:`state_dicts` for local class ``c``: a checkpoint dict in the reference's key schema
         (src/scene_cateogries.py:548-571: FC_state_dict, PE_state_dict, shape_code_state_dict, texture_code_state_dict)
-        goes into BOTH parameter copies, and the optimiser starts afresh for all classes (see reset_optimizer)."""
+        goes into BOTH parameter copies.  ``reset``: what happens to the optimiser --
+
+        * ``"class"`` (default): the AdamW moments of class ``c`` alone are zeroed; the other classes keep their history (a class
+          replaced or hot-loaded in the middle of training does not disturb its neighbours).  The optimiser step counter is one
+          per trainer and keeps running.
+        * ``"all"``: :meth:`reset_optimizer` -- a fresh AdamW for every class, step counter back to 0.  This is the reference's
+          resume (it stores no optimiser state and builds a new AdamW, train.py:40,66-68): load every class, the last one
+          with ``reset="all"`` (or call ``reset_optimizer()`` yourself).
+        * ``None``: the optimiser state is left alone."""
+        assert reset in ("class", "all", None)
         fc = d["FC_state_dict"]
         for th in (self.theta2[0], self.theta2[1]):
             v = self.lay.views(th)
@@ -667,13 +724,17 @@ class FusedCategoryTrainer:
             v["B"][c].copy_(d["PE_state_dict"]["B_layer.weight"])
             v["shape"][c, :self.n_obj_list[c]].copy_(d["shape_code_state_dict"]["weight"])
             v["tex"][c, :self.n_obj_list[c]].copy_(d["texture_code_state_dict"]["weight"])
-        self.reset_optimizer()
+        if reset == "all":
+            self.reset_optimizer()
+        elif reset == "class":
+            self.exp_avg[c].zero_()
+            self.exp_avg_sq[c].zero_()
 
     def reset_optimizer(self):
         """A fresh AdamW for EVERY class: both moments zero and the device-side optimiser step counter back to 0 (the counter
-        is one per trainer: bias correction with a large step on zeroed moments would shrink the first updates after a resume).
-        The reference saves no optimiser state and builds a new AdamW for all classes when it resumes (train.py:40,66-68);
-        load_state_dicts() therefore calls this -- loading one class restarts the optimiser of all of them."""
+        is one per trainer: bias correction with a large step on zeroed moments would mis-scale the first updates after a
+        resume).  The reference saves no optimiser state and builds a new AdamW for all classes when it resumes
+        (train.py:40,66-68)."""
         self.exp_avg.zero_()
         self.exp_avg_sq.zero_()
         self.d_state2[:, 2] = 0

@@ -49,3 +49,14 @@ def test_nccl_launch_refused_without_enough_gpus():
         return
     p = _run(["--gpus", "2", "--launch-check"], env_extra={"CNR_DIST_BACKEND": "nccl"})
     assert p.returncode != 0 and "GPU(s)" in p.stderr
+
+
+def test_launch_timeout_kills_the_child_tree():
+    """a rank bring-up or collective that never returns must end the bench with a message and a non-zero exit.
+    One second is less than two ranks need to import torch: the deadline fires, the child process group is killed."""
+    import time
+    t0 = time.time()
+    p = _run(["--gpus", "2", "--launch-check", "--launch-timeout", "1"])
+    assert p.returncode != 0 and "did not finish within" in p.stderr, p.stderr[-1000:]
+    assert time.time() - t0 < 60
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]

@@ -67,10 +67,11 @@ def _grad_tensors(cnr, tr, flat):
     return out
 
 
-@pytest.mark.parametrize("C,R,n1,n2,L", [(1, 2048, 8, 56, 256), (2, 4096, 16, 112, 32)])
+@pytest.mark.parametrize("C,R,n1,n2,L", [(1, 2048, 8, 56, 256), (2, 4096, 16, 112, 32), (1, 8192, 16, 112, 256)])
 def test_full_size_train_step_against_oracle(cnr, dev, C, R, n1, n2, L):
-    """configs[1] (1 x 2048 x 64, L = 256) and the ScanNet shape (2 x 4096 x 128, L = 32): ONE step of the benchmarked
-    trainer; losses, every gradient tensor and the AdamW update against the oracle on the batch the kernels sampled."""
+    """configs[1] (1 x 2048 x 64, L = 256), the ScanNet shape (2 x 4096 x 128, L = 32) and configs[4]'s shape (8192 x 128, L = 256;
+    f16 operands -- there is no fp8 train step): ONE step of the benchmarked trainer; losses, every gradient tensor and the AdamW
+    update against the oracle on the batch the kernels sampled."""
     torch.manual_seed(4321)
     cfg = cnr.cfg.synthetic_config(device=str(dev), latent_dim=L, n_bins_cam2surface=n1, n_bins=n2,
                                    obj_scale=2.0 if L == 256 else 3.0)

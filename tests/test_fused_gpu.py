@@ -290,17 +290,21 @@ def test_fused_backward_vs_fp32_reference(cnr, dev, name, bwd_variant):
     assert rel_l2(out["loss"], g.t("loss")) < 2e-3
     mlp_ref = {k[5:]: g.t(k) for k in g.z.files if k.startswith("grad.")}
     off, dot, n1, n2 = 0, 0.0, 0.0, 0.0
+    worst, BAR = (0.0, ""), 0.15
     for n, o, i in cnr.ops.TRUNK_LAYERS:
         for kind, cnt, shp in (("weight", o * i, (g.C, o, i)), ("bias", o, (g.C, o))):
             got = out["trunk"].grad[:, off:off + cnt].reshape(shp).double()
             ref = mlp_ref[n + "." + kind].double()
-            assert rel_l2(got, ref) < 0.15, (n, kind, rel_l2(got, ref))
+            worst = max(worst, (rel_l2(got, ref), n + "." + kind))
+            assert rel_l2(got, ref) < BAR, (n, kind, rel_l2(got, ref))
             dot += float((got * ref).sum()); n1 += float(got.pow(2).sum()); n2 += float(ref.pow(2).sum())
             off += cnt
+    others = {k: rel_l2(out[k].grad, g.t(r)) for k, r in (("B", "grad_B"), ("shape", "grad_shape_codes"), ("tex", "grad_texture_codes"))}
+    print(f"[bars] {name} {bwd_variant}: worst trunk tensor {worst[1]} {worst[0]:.4f}, cosine {dot / (n1 * n2) ** 0.5:.6f}, "
+          + ", ".join(f"{k} {v:.4f}" for k, v in others.items()))
     assert dot / (n1 * n2) ** 0.5 > 0.995
-    assert rel_l2(out["B"].grad, g.t("grad_B")) < 0.15
-    assert rel_l2(out["shape"].grad, g.t("grad_shape_codes")) < 0.15
-    assert rel_l2(out["tex"].grad, g.t("grad_texture_codes")) < 0.15
+    for k, v in others.items():
+        assert v < BAR, (k, v)
 
 
 @pytest.mark.parametrize("C,R,S,L", [(1, 2048, 64, 256), (2, 333, 32, 32), (1, 500, 128, 256), (1, 64, 96, 32), (2, 128, 64, 32),

@@ -570,7 +570,13 @@ def test_classes_with_different_object_counts_and_a_single_object_class(cnr, dev
     assert not torch.equal(tr2.theta[1], tr.theta[1])
     for _ in range(5):          # an optimiser with history: moments and a step count of 5
         tr2.step()
+    # default: the loaded class alone starts afresh -- class 0 keeps its AdamW history and the step counter keeps running
+    m0, s0 = tr2.exp_avg[0].clone(), tr2.d_state2[:, 2].tolist()
     tr2.load_state_dicts(sd, 1)
+    assert float(tr2.exp_avg[1].abs().max()) == 0.0 and float(tr2.exp_avg_sq[1].abs().max()) == 0.0
+    assert torch.equal(tr2.exp_avg[0], m0) and float(m0.abs().max()) > 0.0 and tr2.d_state2[:, 2].tolist() == s0
+    # reset="all": the reference's resume (a new AdamW for every class, train.py:40,66-68)
+    tr2.load_state_dicts(sd, 1, reset="all")
     v1, v2 = tr.lay.views(tr.theta), tr2.lay.views(tr2.theta)
     for k in ("trunk", "latW", "latb", "B"):
         assert torch.equal(v1[k][1], v2[k][1]), k
