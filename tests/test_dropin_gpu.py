@@ -100,6 +100,7 @@ def test_ragged_pools_walk_each_class_through_its_own_epochs(cnr, dev):
     K = -(-tr.pool_rows // Rg) - 1
     seq = [[] for _ in range(tr.C)]
     for epoch in range(5):                               # five host epochs of K steps each
+        tr._pre_step()                                   # (the reshuffle is lazy: it happens in front of the epoch's first step)
         p = tr.perm.cpu()
         for c in range(tr.C):
             seq[c].append(p[c, :K * Rg].clone())

@@ -283,14 +283,21 @@ def test_fused_backward_vs_emulated_f16(cnr, dev, name, bwd_variant):
 def test_fused_backward_vs_fp32_reference(cnr, dev, name, bwd_variant):
     """Against the reference's fp32 autograd gradients.  The f16 forward (1e-3) flips the ReLU mask of the
     ~0.1 % of units whose pre-activation is within 1e-3 of zero; each flip toggles a whole contribution, so the
-    gradient differs by ~sqrt(1e-3) = 3 % in relative L2 while pointing the same way.  Bars: 0.15 relative L2
-    per tensor, cosine similarity of the full trunk gradient > 0.995, loss within 2e-3."""
+    gradient differs by ~sqrt(1e-3) = 3 % in relative L2 while pointing the same way.  Bars are what was MEASURED on
+    MI355X (round 4, printed below as "[bars]") plus a margin: 0.06 relative L2 per tensor on the regular fixtures (measured
+    worst 0.042 trunk / 0.034 B / 0.032 codes) -- a dropped bias-gradient sign or a mis-indexed row is a 100 % error of its
+    tensor -- and three named exceptions whose small batches put a handful of flipped units into one tensor: two classes x 64
+    rays at L = 32 (0.080 texture codes, 0.057 viewdir), one object in the world frame (0.091 viewdir weight, 0.083 texture
+    codes) and the empty-mask fixture, where two of the three loss terms are zero by the any-class-empty rule and the whole
+    gradient rides on the remaining term (0.139 B, 0.086 xyz weight).  Cosine of the full trunk gradient > 0.9995 (measured
+    worst 0.99965, that same fixture), loss within 2e-3."""
     g = Golden(name, dev)
     out = _fused_step(cnr, g, dev, grad_scale=float(2 ** 10))
     assert rel_l2(out["loss"], g.t("loss")) < 2e-3
     mlp_ref = {k[5:]: g.t(k) for k in g.z.files if k.startswith("grad.")}
     off, dot, n1, n2 = 0, 0.0, 0.0, 0.0
-    worst, BAR = (0.0, ""), 0.15
+    worst = (0.0, "")
+    BAR = {"edge_empty_mask": 0.15, "edge_single_obj_W": 0.10, "s0_c2_r64_s16_l32": 0.09}.get(name, 0.06)
     for n, o, i in cnr.ops.TRUNK_LAYERS:
         for kind, cnt, shp in (("weight", o * i, (g.C, o, i)), ("bias", o, (g.C, o))):
             got = out["trunk"].grad[:, off:off + cnt].reshape(shp).double()
@@ -302,7 +309,7 @@ def test_fused_backward_vs_fp32_reference(cnr, dev, name, bwd_variant):
     others = {k: rel_l2(out[k].grad, g.t(r)) for k, r in (("B", "grad_B"), ("shape", "grad_shape_codes"), ("tex", "grad_texture_codes"))}
     print(f"[bars] {name} {bwd_variant}: worst trunk tensor {worst[1]} {worst[0]:.4f}, cosine {dot / (n1 * n2) ** 0.5:.6f}, "
           + ", ".join(f"{k} {v:.4f}" for k, v in others.items()))
-    assert dot / (n1 * n2) ** 0.5 > 0.995
+    assert dot / (n1 * n2) ** 0.5 > 0.9995
     for k, v in others.items():
         assert v < BAR, (k, v)
 
