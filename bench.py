@@ -551,7 +551,7 @@ def main():
                 "value": rays_per_step_global * n_long / dt_long}
 
     # ---- roofline leg: the dominant kernel (fused backward) timed with HIP events on its launch stream ----
-    bwd_name = "cnr_field_bwd" if cnr_amd.ops.FIELD_BWD_VARIANT == "split" else "cnr_field_bwd_pipe"
+    bwd_name = "cnr_field_bwd_pipe"
     names = [bwd_name, "cnr_field_train", "cnr_field_fwd", "cnr_field_fwd_render", "cnr_step_prologue", "cnr_render_loss",
              "cnr_step_tail", "cnr_step_grad"]
     tr.use_graph = False                                           # eager so that events bracket single launches
@@ -587,7 +587,7 @@ def main():
             break
     roofline = {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_MFMA_F16_TFLOPS, "traffic": traffic,
-                "variant": "pipe8 (4 chain + 4 weight-gradient waves per workgroup)" if cnr_amd.ops.FIELD_BWD_VARIANT == "pipe4" else cnr_amd.ops.FIELD_BWD_VARIANT,
+                "variant": "pipe8 (4 chain + 4 weight-gradient waves per workgroup, two per SIMD)",
                 "kernel_ms": {k: round(v, 5) for k, v in avg.items()},
                 "kernel_ms_note": "HIP events on the launch stream; %s back to back, median of five batches of ten launches (one launch at a time in the "
                                   "eager step, gaps included: %.5f), the others one launch at a time" % (bwd_name, eager_bwd_ms),

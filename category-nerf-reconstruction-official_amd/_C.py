@@ -40,11 +40,8 @@ SIGNATURES = {
     "cnr_field_fwd": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i64, _vp, _vp],
     "cnr_pack_lo_bytes": [],
     "cnr_pack_weights_lo": [_vp, _vp, _i, _vp],
-    "cnr_field_bwd": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i64, _i64, _i64,
-                      _i64, _vp],
-    "cnr_field_bwd_pipe": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i64, _i64, _i64, _i64, _vp, _i, _vp, _vp],
+    "cnr_field_bwd_pipe": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i64, _i64, _i64, _i64, _vp, _i, _vp, _vp],
     "cnr_field_bwd_workspace_bytes": [_i, _i],
-    "cnr_field_bwd_rows_table_bytes": [_i64],
     "cnr_field_bwd_pipe_blocks": [_i, _i, _i, _i],
     "cnr_gather_pool": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "cnr_dense_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
@@ -65,8 +62,8 @@ SIGNATURES = {
     "cnr_pack_fp8_bytes": [_i],
     "cnr_pack_weights_fp8": [_vp, _vp, _i, _i, _vp],
     "cnr_field_fwd_fp8": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i64, _i, _vp],
-    "cnr_field_train_blocks": [_i, _i, _i],
-    "cnr_field_train_workspace_bytes": [_i, _i, _i, _i],
+    "cnr_field_train_blocks": [_i, _i, _i, _i],
+    "cnr_field_train_workspace_bytes": [_i, _i, _i, _i, _i],
     "cnr_field_train": [_vp, _vp],
     "cnr_param_prep": [_vp, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp],
     "cnr_render_loss_workspace_bytes": [_i, _i],
@@ -144,7 +141,7 @@ def struct_type(name):
     return _struct_types[name]
 
 
-_RESTYPE64 = {"cnr_pack_bytes", "cnr_pack_lo_bytes", "cnr_field_bwd_workspace_bytes", "cnr_field_bwd_rows_table_bytes", "cnr_render_loss_workspace_bytes",
+_RESTYPE64 = {"cnr_pack_bytes", "cnr_pack_lo_bytes", "cnr_field_bwd_workspace_bytes", "cnr_render_loss_workspace_bytes",
               "cnr_dense_bwd_workspace_bytes", "cnr_field_fwd_render_workspace_bytes", "cnr_field_train_workspace_bytes", "cnr_pack_fp8_bytes", "cnr_bg_pack_bytes", "cnr_bg_backward_render_workspace_bytes"}
 
 _lib = None
@@ -271,11 +268,9 @@ def pack_bytes():
     return int(load().cnr_pack_bytes())
 
 
-def field_bwd_workspace_bytes(C, max_blocks, table_rows=0):
-    """records of the field backward + (table_rows > 0) the fixed-point table of per-row bias sums behind them: pass the total
-    rows of ``biasrows`` when they do not fit the kernels' LDS tables (no ray_row, or more than four rows per class)"""
-    lib = load()
-    return int(lib.cnr_field_bwd_workspace_bytes(int(C), int(max_blocks))) + int(lib.cnr_field_bwd_rows_table_bytes(int(table_rows)))
+def field_bwd_workspace_bytes(C, max_blocks):
+    """bytes of the per-workgroup gradient records of cnr_field_bwd_pipe / cnr_field_train"""
+    return int(load().cnr_field_bwd_workspace_bytes(int(C), int(max_blocks)))
 
 
 def render_loss_workspace_bytes(C, R):

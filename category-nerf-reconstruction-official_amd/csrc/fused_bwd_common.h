@@ -1,6 +1,6 @@
-// Shared pieces of the fused backward kernels (fused_bwd.hip: two-launch block split; fused_bwd_pipe8.hip:
-// chain / dW wave pipeline): LDS image formats, transposing operand reads, the dW block -> parameter map, the
-// per-workgroup record format and its fixed-order reduction.
+// Shared pieces of the fused backward kernel's translation units (fused_bwd_pipe8*.hip: chain / dW wave pipeline): LDS image
+// formats, transposing operand reads, the dW block -> parameter map, the per-workgroup record format and its fixed-order
+// reduction.
 #pragma once
 #include "fused_common.h"
 #include "records_common.h"
@@ -13,39 +13,10 @@ typedef short s4v __attribute__((ext_vector_type(4)));
 enum BlockKind { BK_R2, BK_R0, BK_T1, BK_VD_Y, BK_VD_E0, BK_VD_E1, BK_ES, BK_S2, BK_CAT_Y, BK_CAT_E0, BK_CAT_E1,
                  BK_CAT_E2, BK_S1, BK_XYZ_E0, BK_XYZ_E1, BK_XYZ_E2, NBLOCKS };
 
-constexpr int ST_H = 72;    // [32 samples][32 features] f16, 64 B + 8 B pad per row
 constexpr int ST_E1 = 208;  // [32][half0: 48 slots | half1: 48 slots] = 192 B + 16 B pad
 constexpr int ST_E2 = 112;  // [32][half0: 24 | half1: 24] = 96 B + 16 B pad
-constexpr int E1IMG_BYTES = 32 * ST_E1 + 128;
-constexpr int E2IMG_BYTES = 32 * ST_E2 + 128;
-constexpr int HIMG_BYTES = 32 * ST_H + 64;
-using cnr_rec::ROWS_LDS;
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  // also a scheduling fence: without it the pre-RA scheduler hoists the next layers' LDS loads across layer
-  // boundaries and the live set outgrows the register file (hundreds of scratch spills)
-  // __builtin_amdgcn_sched_barrier(0);
-}
-
-// [sample][feature] image of an accumulator-layout tile held as two f16 fragments
-__device__ __forceinline__ void stage_h(unsigned char* img, const h8& f0, const h8& f1, int col, int h) {
-  unsigned char* base = img + col * ST_H + h * 8;
-  *reinterpret_cast<h4*>(base + 0) = f0.lo;
-  *reinterpret_cast<h4*>(base + 16) = f0.hi;
-  *reinterpret_cast<h4*>(base + 32) = f1.lo;
-  *reinterpret_cast<h4*>(base + 48) = f1.hi;
-}
-// this lane's own two fragments back from such an image
-__device__ __forceinline__ void load_h(const unsigned char* img, h8& f0, h8& f1, int col, int h) {
-  const unsigned char* base = img + col * ST_H + h * 8;
-  f0.lo = *reinterpret_cast<const h4*>(base + 0);
-  f0.hi = *reinterpret_cast<const h4*>(base + 16);
-  f1.lo = *reinterpret_cast<const h4*>(base + 32);
-  f1.hi = *reinterpret_cast<const h4*>(base + 48);
-}
-// Swizzled form of the same image for the 8-wave kernels: unpadded 64-byte rows, the 8-byte chunk c of row r stored at
+// [sample][feature] image of an accumulator-layout tile held as two f16 fragments, swizzled: unpadded 64-byte rows, the 8-byte
+// chunk c of row r stored at
 // chunk c ^ ((r >> 1) & 7).  A transposing read's 32-lane half covers 4 consecutive rows x 64 B = all 64 banks once
 // (the padded form wraps after 3.5 rows: 2-way), and a ds_write_b64's 16-lane group (16 rows, one logical chunk)
 // lands on 16 different bank pairs of the 32 store banks.
@@ -238,19 +209,6 @@ __device__ __forceinline__ float low_half_to_both(float v) {
   const unsigned x = __builtin_bit_cast(unsigned, v);
   const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
   return __builtin_bit_cast(float, (unsigned)r[0]);
-}
-
-// For every trunk parameter: where its gradient sits in the two-region LDS image of the 16 dW blocks
-// ((kind << 10) | (row << 5) | col), or -1 when it does not come from a block.  Built once per process.
-__device__ int g_param_src[TRUNK];
-__global__ void build_param_src_kernel() {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < TRUNK; i += gridDim.x * blockDim.x) g_param_src[i] = -1;
-}
-__global__ void fill_param_src_kernel() {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < NBLOCKS * 1024; i += gridDim.x * blockDim.x) {
-    const int idx = block_index(i >> 10, (i >> 5) & 31, i & 31);
-    if (idx >= 0) g_param_src[idx] = i;
-  }
 }
 
 // Fixed-order sum of the per-workgroup records into the (accumulated) outputs.  256 threads = 64 record entries x

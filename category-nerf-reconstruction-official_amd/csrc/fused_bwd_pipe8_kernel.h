@@ -112,8 +112,10 @@ template <> __host__ __device__ constexpr int local8<4>(int kind) {
 // row-sum block holds row 4 w + s for chain wave w's tile and latent slot s (A operand: all ones in that row) and rows 16, 17
 // for the two plain biases; after every iteration its owner adds rows 0..15 to the fixed-point table at the four tiles' object
 // rows (integer atomics: order-free, bitwise reproducible) and clears them.  No one-hot table, bias rows from global memory.
-// GEO (one-launch form only): the forward's geometry branch as three products per fragment with the residual weight image
-// packed_lo (fused_common.h, NKK_GEO) -- what keeps the occupancy within 1e-3 of fp32 for trained weights.
+// GEO: the forward's geometry branch as three products per fragment with the residual weight image packed_lo (fused_common.h,
+// NKK_GEO) -- what keeps the occupancy within 1e-3 of fp32 for trained weights.  The stand-alone backward (KR = 0) takes it too:
+// it must recompute the activations and ReLU masks of the forward that was rendered (cnr_field_fwd / cnr_field_fwd_render with
+// the same image), or it is the gradient of a different function.
 template <int NCH, int NDW, int WIDE, int KR, bool TWO, bool PAD, bool GEO>
 __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
     const float* __restrict__ pts, const float* __restrict__ Bdir, const unsigned char* __restrict__ packed,
@@ -124,7 +126,6 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
   static_assert(KR == 0 || KR == 1 || KR == 2 || KR == 4, "tiles per ray");
   static_assert(!TWO || KR == 1, "two rays per tile only with one tile per ray");
   static_assert(!TWO || PAD, "16-slot rays are the padded form");   // PAD = false: S == SP exactly (the plain index arithmetic)
-  static_assert(!GEO || KR > 0, "the precise geometry branch belongs to the one-launch form (the forward that is rendered)");
   static_assert(WIDE != 3 || (KR > 0 && !TWO), "per-tile object rows need a whole ray per tile group");
   constexpr int L8_BL = l8_bl(GEO), L8_BR = l8_br(GEO), L8_CHAIN = l8_chain(WIDE, GEO), C8_BYTES = c8_bytes(WIDE),
                 K8_SMALL_BYTES = k8_small(WIDE);

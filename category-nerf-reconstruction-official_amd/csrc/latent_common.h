@@ -362,7 +362,14 @@ __host__ __device__ inline bool latent_local_ok(int L, int n_obj) {
   if (L <= 0 || n_obj <= 0) return false;
   if (!(256 % L == 0 || L % 256 == 0)) return false;      // rows / objects per block: a whole number, block-aligned
   const int per = L >= 256 ? 1 : 256 / L;
-  return n_obj <= 32 && per * n_obj <= 256 && per <= 8;
+  return n_obj <= 128 && per <= 8;     // (up to cnr_rec::ROWS_TILE_MAX objects: object loops in chunks of 32, d pre entries in passes)
+}
+// floats of dynamic LDS a block of latent_bwd_block_local needs
+__host__ __device__ inline int latent_local_lds_floats(int L, int n_obj) {
+  const int per = L >= 256 ? 1 : 256 / L;
+  const int wblk = 2 * n_obj * 32 + per * n_obj;          // weight block: <= 2 latent slots of table rows + its rows' d pre
+  const int cblk = 2 * per * 96 + per;                    // code block: its objects' rows + d pre + norms
+  return wblk > cblk ? wblk : cblk;
 }
 __host__ __device__ inline int latent_local_blocks(int L, int n_obj) {
   return (128 * L + 255) / 256 + 2 * ((n_obj * L + 255) / 256);
@@ -405,19 +412,24 @@ __device__ __forceinline__ void latent_bwd_block_local(const float* __restrict__
       const int kk = rr / (n_obj * 32), ob = (rr / 32) % n_obj, o_ = rr & 31;
       row_entry((ob * 4 + k_lo + kk) * 32 + o_, fx[sl]);
     }
-    // (b) the d pre entry this thread forms: q = row_local * n_obj + ob  (np * n_obj <= 256)
-    const int q = tid, qrow = q / n_obj, qob = q - qrow * n_obj;
-    const bool qon = q < np * n_obj;
-    const int qp = p_lo + (qon ? qrow : 0), qk = qp >> 5, qo = qp & 31;
-    float wq[32], zq;
-    {
+    // (b) the d pre entries this thread forms: q = row_local * n_obj + ob, q = tid, tid + 256, ..  (np * n_obj entries; the first
+    //     one's operands are requested here with everything else, later passes -- more than 256 / np objects -- fetch their own)
+    const int nq = np * n_obj;
+    auto dpre_operands = [&](int q, float (&wq_)[32], float& zq_, int& qk_, int& qob_) {
+      const int qq = q < nq ? q : 0, qrow = qq / n_obj;
+      qob_ = qq - qrow * n_obj;
+      const int qp = p_lo + qrow, qo = qp & 31;
+      qk_ = qp >> 5;
       int w_off, b_off, ld;
-      latent_target(qk, w_off, b_off, ld);
+      latent_target(qk_, w_off, b_off, ld);
 #pragma unroll
-      for (int o_ = 0; o_ < 32; ++o_) wq[o_] = th[w_off + o_ * ld + qo];
-      zq = z[((qon ? qob : 0) * 4 + qk) * 32 + qo];
-    }
-    // (c) this thread's element: code entries of every object at its l
+      for (int o_ = 0; o_ < 32; ++o_) wq_[o_] = th[w_off + o_ * ld + qo];
+      zq_ = z[(qob_ * 4 + qk_) * 32 + qo];
+    };
+    float wq[32], zq;
+    int qk, qob;
+    dpre_operands(tid, wq, zq, qk, qob);
+    // (c) this thread's element: code entries of every object at its l (the first 32 objects' here, further chunks below)
     const int ee = live ? e : 0, ep = ee / L, el = ee - ep * L, ek = ep >> 5;
     const float* cbase = th + (ek == 3 ? lay.tex : lay.shape) + el;
     float cv[32];
@@ -430,7 +442,7 @@ __device__ __forceinline__ void latent_bwd_block_local(const float* __restrict__
       const int r = tid + 256 * sl;
       if (r < nrow) rowsL[r] = row_value(fx[sl]);
     }
-    for (int r = tid + 1024; r < nrow; r += 256) {     // (more than 32 objects' worth of rows: not reached with n_obj <= 32, nk <= 1)
+    for (int r = tid + 1024; r < nrow; r += 256) {     // (more than 32 objects' worth of rows: further passes, one round trip each)
       const int kk = r / (n_obj * 32), ob = (r / 32) % n_obj, o_ = r & 31;
       long long f[8];
       row_entry((ob * 4 + k_lo + kk) * 32 + o_, f);
@@ -438,7 +450,8 @@ __device__ __forceinline__ void latent_bwd_block_local(const float* __restrict__
     }
     __syncthreads();
     // ---- d pre of the block's rows ----
-    if (qon) {
+    for (int q = tid; q < nq; q += 256) {
+      if (q != tid) dpre_operands(q, wq, zq, qk, qob);
       const float* rr = rowsL + ((qk - k_lo) * n_obj + qob) * 32;
       float s_ = 0.0f;
 #pragma unroll
@@ -453,6 +466,13 @@ __device__ __forceinline__ void latent_bwd_block_local(const float* __restrict__
 #pragma unroll
       for (int u = 0; u < 32; ++u)
         if (u < n_obj) s_ = fmaf(dp[u], cv[u], s_);
+      for (int u0 = 32; u0 < n_obj; u0 += 32) {   // objects 32 .. : the same chain, 32 code entries in flight at a time
+#pragma unroll
+        for (int u = 0; u < 32; ++u) cv[u] = u0 + u < n_obj ? cbase[(int64_t)(u0 + u) * L] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 32; ++u)
+          if (u0 + u < n_obj) s_ = fmaf(dp[u0 + u], cv[u], s_);
+      }
       sink.latent_set(lay.latW + e, s_);
       if (el == 0) {
         sink.prefetch(lay.latb + ep);

@@ -5,14 +5,15 @@
 
 namespace cnr_rec {
 using namespace cnr;
-constexpr int ROWS_LDS = 4;  // rows_per_class <= 4: what the 4-wave and block-split kernels keep in their LDS row tables
 // rows_per_class <= 15: per-object bias-row sums travel in the record / the fixed-point table (the 8-wave kernel's
 // row-sum blocks have 32 rows each: one block of 4 latent slots x <= 7 objects + 2 bias rows, or two blocks of
 // 2 latent slots x <= 15 objects, the first with the 2 bias rows)
 constexpr int ROWS_MAX = 15;
-// rows_per_class <= 32 on the one-launch path with one object per tile (fused_bwd_pipe8.hip, WIDE = 3): the sums go to the
-// fixed-point table only, the record carries none
-constexpr int ROWS_TILE_MAX = 32;
+// rows_per_class <= 128 on the one-launch path with one object per tile (fused_bwd_pipe8.hip, WIDE = 3): the sums go to the
+// fixed-point table only, the record carries none.  (The reference caps a scene at n_models = 100 categories + instances,
+// configs/Replica/config_replica_room0.json:15; nothing in the kernels depends on the count any more -- the tail launch's latent
+// blocks read only the rows they need, latent_common.h.)
+constexpr int ROWS_TILE_MAX = 128;
 constexpr int REC_FLOATS = ((TRUNK + 126 + ROWS_MAX * 128 + 255) / 256) * 256;  // one workgroup's record
 constexpr double ROWS_FIX_SCALE = 1099511627776.0;  // 2^40: bias-row sums as int64 fixed point (order-free atomics)
 #ifndef CNR_TAIL_EPB

@@ -107,6 +107,28 @@ __device__ __forceinline__ void load_rows_fix(const TailArgs& a, int c, float* d
   __syncthreads();
 }
 
+// ... and straight to the float rows in global memory (no staging: the row count is not bounded by the block's LDS)
+__device__ __forceinline__ void publish_rows_fix(const TailArgs& a, int c) {
+  const int n = a.lay.n_obj * 128;
+  for (int i0 = threadIdx.x; i0 < n; i0 += 4 * 256) {
+    long long f[4][cnr_rec::ROWS_FIX_COPIES];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + 256 * u;
+#pragma unroll
+      for (int k = 0; k < cnr_rec::ROWS_FIX_COPIES; ++k) f[u][k] = i < n ? a.rows_fix[((size_t)k * a.C + c) * n + i] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + 256 * u;
+      long long t = 0;
+#pragma unroll
+      for (int k = 0; k < cnr_rec::ROWS_FIX_COPIES; ++k) t += f[u][k];
+      if (i < n) a.dbiasrows[(int64_t)c * n + i] = (float)((double)t * (1.0 / cnr_rec::ROWS_FIX_SCALE));
+    }
+  }
+}
+
 #ifdef CNR_TAIL_STAMPS  // tools/exp only
 __device__ unsigned long long g_tail_t[8];  // [type 0..2][min start, max end], [6] = min start over all
 #define TAIL_T0() const unsigned long long tt0 = __builtin_amdgcn_s_memrealtime(); \
@@ -160,11 +182,7 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
       latent_bwd_block_local(a.theta_in + (int64_t)c * P, a.lay, a.zl + (int64_t)c * n, a.rows_fix + (size_t)c * n,
                              (int64_t)a.C * n, cnr_rec::ROWS_FIX_COPIES, 1.0 / cnr_rec::ROWS_FIX_SCALE, reg_c, sm, sink, blk,
                              n_real);
-      if (a.grad_only && blk == 0 && a.dbiasrows) {   // (no epilogue blocks in the gradient-only launch)
-        __syncthreads();
-        load_rows_fix(a, c, sm);
-        for (int i = threadIdx.x; i < n; i += 256) a.dbiasrows[(int64_t)c * n + i] = sm[i];
-      }
+      if (a.grad_only && blk == 0 && a.dbiasrows) publish_rows_fix(a, c);   // (no epilogue blocks in the gradient-only launch)
       TAIL_T1(0);
       return;
     }
@@ -289,11 +307,8 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
   // ---- epilogue of class b: loss values + flags, next slice's max depth, next step state (class 0)
   const int c = b, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   float* red = sm;
-  if (a.local_latent && a.rows_fix && a.dbiasrows) {   // the class's bias-row gradient as floats (the latent blocks no longer walk the whole table)
-    load_rows_fix(a, c, sm);
-    for (int i = threadIdx.x; i < a.lay.n_obj * 128; i += 256) a.dbiasrows[(int64_t)c * a.lay.n_obj * 128 + i] = sm[i];
-    __syncthreads();
-  }
+  if (a.local_latent && a.rows_fix && a.dbiasrows)     // the class's bias-row gradient as floats (the latent blocks no longer walk the
+    publish_rows_fix(a, c);                            // whole table): table -> registers -> global, any number of objects
   const int64_t cursor = a.state_cur[0] + a.add_rows;
   if (wv == 0) {
     cnr_rl::finish_class(a.partials, a.nb, a.losses, a.flags, C, c, lane);
@@ -329,6 +344,16 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
 }
 }  // namespace
 
+// dynamic LDS of a tail block: the reducing blocks' three partial arrays (768 floats), the general latent blocks' two whole
+// (n_obj, 4, 32) tables + norms, or the per-block form's own rows (latent_local_lds_floats) -- which is what lets a class hold up to
+// ROWS_TILE_MAX objects: 100 objects need 29 KB there, where the whole tables would need 103 KB and one block per CU
+static size_t tail_lds_bytes(int do_latent, int local_latent, int L, int n_obj) {
+  const int general = 2 * n_obj * 128 + 2 * n_obj + 520;
+  const int local = latent_local_lds_floats(L, n_obj) + 8;
+  const int need = !do_latent ? 776 : local_latent ? (local > 776 ? local : 776) : general;
+  return (size_t)need * sizeof(float);
+}
+
 extern "C" int cnr_step_tail(const cnr_step_tail_args* args, void* stream) {
   if (!args || args->struct_size != sizeof(cnr_step_tail_args) || args->abi_version != CNR_ABI_VERSION) return CNR_E_ARG;
   const float* theta_in = args->theta_in; float* theta_out = args->theta_out; float* grad = args->grad;
@@ -354,7 +379,8 @@ extern "C" int cnr_step_tail(const cnr_step_tail_args* args, void* stream) {
   //  one-object-per-tile form)
   if (records && (!do_latent || !rows_fix || nwg <= 0 || n_obj > cnr_rec::ROWS_TILE_MAX)) return CNR_E_ARG;
   if (rows_fix && !do_latent) return CNR_E_ARG;
-  if (n_obj > 64) return CNR_E_SHAPE;
+  if (n_obj > cnr_rec::ROWS_TILE_MAX) return CNR_E_SHAPE;
+  if (n_obj > 32 && do_latent && !(rows_fix && latent_local_ok(L, n_obj))) return CNR_E_SHAPE;   // the general latent blocks keep whole tables in LDS
   if (next_max_bound && (!depth || pool_rows < R)) return CNR_E_ARG;
   TailArgs a{};
   a.theta_in = theta_in; a.theta_out = theta_out; a.grad = grad; a.m = exp_avg; a.v = exp_avg_sq;
@@ -384,7 +410,7 @@ extern "C" int cnr_step_tail(const cnr_step_tail_args* args, void* stream) {
   a.records = (const float*)records; a.nwg = nwg; a.rows_fix = rows_fix; a.NR = cnr_rec::REC_FLOATS / cnr_rec::TAIL_EPB;
   a.clamp_flags = clamp_flags;
   const unsigned grid = (unsigned)((a.do_latent ? a.NL * C : 0) + (records ? a.NR * C : a.NA) + C);
-  const size_t lds = (size_t)(2 * n_obj * 128 + 2 * n_obj + 520) * sizeof(float);
+  const size_t lds = tail_lds_bytes(a.do_latent, a.local_latent, L, n_obj);
   hipLaunchKernelGGL(tail_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
   CNR_LAUNCH_CHECK();
   return CNR_OK;
@@ -414,7 +440,8 @@ extern "C" int cnr_step_grad(const float* theta, float* grad, int64_t class_stri
   if (a.local_latent) a.NL = latent_local_blocks(L, n_obj);
   a.records = (const float*)records; a.nwg = nwg; a.rows_fix = rows_fix; a.NR = cnr_rec::REC_FLOATS / cnr_rec::TAIL_EPB;
   const unsigned grid = (unsigned)(a.NL * C + a.NR * C);
-  const size_t lds = (size_t)(2 * n_obj * 128 + 2 * n_obj + 520) * sizeof(float);
+  if (n_obj > 32 && !a.local_latent) return CNR_E_SHAPE;
+  const size_t lds = tail_lds_bytes(1, a.local_latent, L, n_obj);
   hipLaunchKernelGGL(tail_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
   CNR_LAUNCH_CHECK();
   return CNR_OK;

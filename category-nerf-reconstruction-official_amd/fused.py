@@ -154,15 +154,22 @@ class FusedCategoryTrainer:
         # 77-128), else two calls, whose extra forward costs less than the dead lanes would.  CNR_ONE_LAUNCH=0 keeps the two calls.
         one = bool(int(os.environ.get("CNR_ONE_LAUNCH", "1"))) if one_launch is None else bool(one_launch)
         slots = 16 if self.S <= 16 else 32 if self.S <= 32 else 64 if self.S <= 64 else 128
-        one = one and fuse_render and self.S <= 128 and self.S >= 0.6 * slots and ops.FIELD_BWD_VARIANT == "pipe4"
-        # per-object bias-row sums: up to 15 objects per class in the kernel's row-sum blocks; 16 .. 32 on the one-launch path
-        # when a tile lies inside one ray (>= 32 slots per ray: one object per tile, sums straight to the fixed-point table)
-        self.use_records = ops.FIELD_BWD_VARIANT == "pipe4" and (n_obj <= 15 or (one and slots >= 32 and n_obj <= 32))
+        # per-object bias-row sums: up to 15 objects per class in the kernel's row-sum blocks (any path); 16 .. 128 on the one-launch
+        # path only, with a whole ray per tile group (>= 32 slots per ray: one object per tile, sums straight to the fixed-point
+        # table) -- such a class takes that path whatever its slot fill (the reference allows 100 instances, n_models)
+        if n_obj > 15:
+            if not (fuse_render and self.S <= 128 and n_obj <= 128):
+                raise ValueError(f"a class of {n_obj} objects trains on the one-launch step body: at most 128 objects, at most 128 "
+                                 f"samples per ray (got S = {self.S}, fuse_render = {fuse_render})")
+            one = True              # (rays of up to 16 samples get a 32-slot tile of their own there: cnr_field_train_blocks)
+        else:
+            one = one and fuse_render and self.S <= 128 and self.S >= 0.6 * slots
+        self.use_records = True
         self.grad_exchange = self.shard == "ray" and self.world > 1
         self.fused_tail = not self.grad_exchange and self.use_records
         fix_off = (n_th + n_db + 3) // 4 * 4                      # 16-byte aligned
-        self._gbuf = torch.zeros(fix_off + (2 * 8 * n_db if self.use_records else 0), device=self.device)  # 8 copies
-        self.rows_fix = self._gbuf[fix_off:].view(torch.int64) if self.use_records else None
+        self._gbuf = torch.zeros(fix_off + 2 * 8 * n_db, device=self.device)  # 8 copies
+        self.rows_fix = self._gbuf[fix_off:].view(torch.int64)
         self.grad = self._gbuf[:self.theta.numel()].view_as(self.theta)
         self.exp_avg = torch.zeros_like(self.theta)
         self.exp_avg_sq = torch.zeros_like(self.theta)
@@ -249,8 +256,7 @@ class FusedCategoryTrainer:
         self._out_slot = None       # capture of a multi-step graph: which history slot the step being recorded writes
         self._last_multi = 0        # steps in the last launch that left their values in the history slots
         self.dbias = self._gbuf[n_th:n_th + n_db].view(n_cls * n_obj, 4, 32)
-        self._nwg = int(_C.load().cnr_field_bwd_pipe_blocks(self.R, self.S, 4, self.bwd_blocks)) \
-            if self.use_records else 0
+        self._nwg = int(_C.load().cnr_field_bwd_pipe_blocks(self.R, self.S, 4, self.bwd_blocks))
         # Precise geometry branch (default ON): the layers between the sample and the x10 occupancy logit as three f16
         # products per fragment, Wh xh + Wl xh + Wh xl (include/cnr_hip.h, cnr_pack_weights_lo).  Plain f16 operands hold
         # north_star's 1e-3 on the occupancy only at initialisation (6.7e-4); after 400 / 5000 training steps they give
@@ -266,8 +272,7 @@ class FusedCategoryTrainer:
         self._rl_blocks = int(_C.load().cnr_field_fwd_render_blocks(self.R, self.S)) if fuse_render else 0
         # ... and forward + render / loss + the whole backward in ONE launch (``one``, decided above): no second forward, no
         # d sigma / d colour round trip
-        self._ft_blocks = int(_C.load().cnr_field_train_blocks(self.R, self.S, self.bwd_blocks)) \
-            if (one and fuse_render and self.use_records and ops.FIELD_BWD_VARIANT == "pipe4") else 0
+        self._ft_blocks = int(_C.load().cnr_field_train_blocks(self.R, self.S, self.bwd_blocks, n_obj)) if (one and fuse_render) else 0
         if self._ft_blocks:
             self._nwg = self._ft_blocks
         self.use_graph = use_graph
@@ -314,9 +319,9 @@ class FusedCategoryTrainer:
                 o[name] = torch.empty(*shape, **kw)
             o["rl_ws"] = torch.zeros(max(_C.render_loss_workspace_bytes(C, R),
                                          int(_C.load().cnr_field_fwd_render_workspace_bytes(C, R, S)),
-                                         int(_C.load().cnr_field_train_workspace_bytes(C, R, S, self.bwd_blocks))),
+                                         int(_C.load().cnr_field_train_workspace_bytes(C, R, S, self.bwd_blocks, n_obj))),
                                      device=self.device, dtype=torch.uint8)
-            o["bwd_ws"] = torch.empty(_C.field_bwd_workspace_bytes(C, self.bwd_blocks, C * n_obj), device=self.device,
+            o["bwd_ws"] = torch.empty(_C.field_bwd_workspace_bytes(C, self.bwd_blocks), device=self.device,
                                       dtype=torch.uint8)
         zl, brows, packed = o["zl"], o["brows"], o["packed"]
         lat_args = (lay.total, lay.latW[0], lay.latb[0], lay.shape[0], lay.tex[0], L, n_obj, C)
@@ -362,16 +367,14 @@ class FusedCategoryTrainer:
         if not self._ft_blocks:
             ops.field_bwd(b["pts"], Bc, packed, brows, ray_row, self.scale, o["dsig"], o["drgb"], self.grad_scale,
                           g_trunk, g_B, self.dbias, C, R, S, n_obj, self.bwd_blocks, o["bwd_ws"],
-                          B_stride=P, dtrunk_stride=P, dB_stride=P, rows_fix=self.rows_fix, skip_reduce=self.use_records,
-                          clamp_flags=self.clamp)
+                          B_stride=P, dtrunk_stride=P, dB_stride=P, rows_fix=self.rows_fix, skip_reduce=True,
+                          clamp_flags=self.clamp, packed_lo=lo)
         self._reg = 0.0005 / self.ray_world      # code regulariser scale: loss.py:5-15, train.py:165-167
         if self.grad_exchange:                   # ray shards: the all-reduce needs the complete gradient first
-            if self.use_records:                 # record reduction + latent backward in one launch, gradient only
-                _C.call("cnr_step_grad", self.theta, self.grad, lay.total, lay.B[0], lay.latW[0], lay.latb[0],
-                        lay.shape[0], lay.tex[0], L, n_obj, C, zl, self.dbias, self._reg, o["bwd_ws"], self._nwg,
-                        self.rows_fix, self.n_obj_cls)
-            else:
-                _C.call("cnr_latent_bwd", self.theta, *lat_args, zl, self.dbias, self._reg, self.grad, self.n_obj_cls)
+            # record reduction + latent backward in one launch, gradient only
+            _C.call("cnr_step_grad", self.theta, self.grad, lay.total, lay.B[0], lay.latW[0], lay.latb[0],
+                    lay.shape[0], lay.tex[0], L, n_obj, C, zl, self.dbias, self._reg, o["bwd_ws"], self._nwg,
+                    self.rows_fix, self.n_obj_cls)
 
     def _field_train_args(self, b, o, Bc, st, loss_scale, rows_fix, clamp):
         """the argument block of cnr_field_train on the live buffers of a step (include/cnr_hip.h, cnr_field_train_args)"""
@@ -614,7 +617,8 @@ class FusedCategoryTrainer:
         kw = dict(device=self.device, dtype=torch.float32)
         dtrunk, dB, dbias = torch.zeros(C, TRUNK_PARAMS, **kw), torch.zeros(C, 21, 3, **kw), torch.zeros_like(self.dbias)
         run = lambda: ops.field_bwd(b["pts"], Bc, o["packed"], o["brows"], b["ray_row"], self.scale, o["dsig"], o["drgb"],
-                                    self.grad_scale, dtrunk, dB, dbias, C, R, S, n_obj, self.bwd_blocks, o["bwd_ws"])
+                                    self.grad_scale, dtrunk, dB, dbias, C, R, S, n_obj, self.bwd_blocks, o["bwd_ws"],
+                                    packed_lo=o["packed_lo"])
         for _ in range(3):
             run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

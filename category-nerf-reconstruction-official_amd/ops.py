@@ -382,28 +382,15 @@ class DenseFn(Function):
         return (dx.reshape(ctx.xshape) if dx is not None else None), dW, db, None, None, None
 
 
-# cnr_field_bwd variants: "pipe4" = the pipelined launch, 4 chain + 4 weight-gradient waves per workgroup, two per SIMD
-# (csrc/fused_bwd_pipe8.hip; records, bitwise repeatable, up to 15 objects per class); "split" = two block-split launches
-# (csrc/fused_bwd.hip: the fallback for per-ray rows or more objects).  Same results contract.  (The 4-wave pipelines
-# "pipe2" / "pipe3" of rounds 1-2 are gone.)
-FIELD_BWD_VARIANT = os.environ.get("CNR_FIELD_BWD", "pipe4")
-
-
 def field_bwd(pts, B, packed, biasrows, ray_row, scale, d_sig, d_rgb, grad_scale, dtrunk, dB, dbiasrows, C, R, S,
-              rows_per_class, max_blocks, workspace, variant=None, B_stride=0, dtrunk_stride=0, dB_stride=0,
-              rows_fix=None, skip_reduce=False, clamp_flags=None):
-    """strides (floats, 0 = dense): B / dtrunk / dB may be views into a flat (C, P) buffer, see cnr_hip.h"""
-    v = variant or FIELD_BWD_VARIANT
-    if v == "split":
-        _C.call("cnr_field_bwd", pts, B, packed, biasrows, ray_row, scale, d_sig, d_rgb, grad_scale, dtrunk, dB,
-                dbiasrows, C, R, S, rows_per_class, max_blocks, workspace, workspace.numel(), int(B_stride),
-                int(dtrunk_stride), int(dB_stride))
-    elif v == "pipe4":
-        _C.call("cnr_field_bwd_pipe", pts, B, packed, biasrows, ray_row, scale, d_sig, d_rgb, grad_scale, dtrunk,
-                dB, dbiasrows, C, R, S, rows_per_class, max_blocks, int(v[-1]), workspace, workspace.numel(), int(B_stride),
-                int(dtrunk_stride), int(dB_stride), rows_fix, int(bool(skip_reduce)), clamp_flags)
-    else:
-        raise ValueError(f"unknown cnr_field_bwd variant {v!r}")
+              rows_per_class, max_blocks, workspace, B_stride=0, dtrunk_stride=0, dB_stride=0,
+              rows_fix=None, skip_reduce=False, clamp_flags=None, packed_lo=None):
+    """cnr_field_bwd_pipe: the stand-alone field backward (8-wave pipelined kernel + record reduction).  strides (floats, 0 =
+    dense): B / dtrunk / dB may be views into a flat (C, P) buffer, see cnr_hip.h.  packed_lo: the residual image the forward
+    ran with -- the recompute must form that forward's activations."""
+    _C.call("cnr_field_bwd_pipe", pts, B, packed, packed_lo, biasrows, ray_row, scale, d_sig, d_rgb, grad_scale, dtrunk,
+            dB, dbiasrows, C, R, S, rows_per_class, max_blocks, 4, workspace, workspace.numel(), int(B_stride),
+            int(dtrunk_stride), int(dB_stride), rows_fix, int(bool(skip_reduce)), clamp_flags)
 
 
 def pack_weights_lo(trunk):
@@ -440,33 +427,34 @@ def field_fwd_fp8(pts, B, trunk, packed, biasrows, ray_row, scale, terms=1):
 
 class FusedFieldFn(Function):
     """pts (C,R,S,3), B (C,21,3), trunk (C,13892), biasrows (C*rows,4,32) -> sigmas (C,R,S), rgbs (C,R,S,3)
-    on the f16-MFMA kernels; backward = cnr_field_bwd (recompute).  ray_row (C,R) int32 or None,
-    rows_per_class = rows of biasrows per class, grad_scale = power-of-two loss scale for the f16 chain."""
+    on the f16-MFMA kernels; backward = cnr_field_bwd_pipe (recompute).  ray_row (C,R) int32: the bias row of every ray,
+    class-major, rows_per_class (1 .. 15) rows per class; grad_scale = power-of-two loss scale for the f16 chain;
+    precise: the geometry branch as three f16 products per fragment, forward AND recompute (include/cnr_hip.h)."""
 
     @staticmethod
-    def forward(pts, B, trunk, biasrows, ray_row, scale, rows_per_class, grad_scale, max_blocks):
+    def forward(pts, B, trunk, biasrows, ray_row, scale, rows_per_class, grad_scale, max_blocks, precise=False):
         packed = pack_weights(trunk)
-        sig, rgb = field_fwd(pts, B, packed, biasrows, ray_row, scale)
-        return sig, rgb, packed
+        lo = pack_weights_lo(trunk) if precise else None
+        sig, rgb = field_fwd(pts, B, packed, biasrows, ray_row, scale, packed_lo=lo)
+        return sig, rgb, packed, (lo if precise else packed.new_empty(0))
 
     @staticmethod
     def setup_context(ctx, inputs, output):
-        pts, B, trunk, biasrows, ray_row, scale, rows_per_class, grad_scale, max_blocks = inputs
-        ctx.save_for_backward(pts, B, biasrows, output[2])
+        pts, B, trunk, biasrows, ray_row, scale, rows_per_class, grad_scale, max_blocks = inputs[:9]
+        ctx.save_for_backward(pts, B, biasrows, output[2], output[3])
         ctx.ray_row, ctx.scale, ctx.rpc, ctx.gs, ctx.mb = ray_row, float(scale), int(rows_per_class), float(grad_scale), int(max_blocks)
         ctx.trunk_shape = trunk.shape
-        ctx.mark_non_differentiable(output[2])
+        ctx.mark_non_differentiable(output[2], output[3])
 
     @staticmethod
-    def backward(ctx, d_sig, d_rgb, _):
-        pts, B, biasrows, packed = ctx.saved_tensors
+    def backward(ctx, d_sig, d_rgb, _, _lo):
+        pts, B, biasrows, packed, lo = ctx.saved_tensors
         C, R, S, _3 = pts.shape
         dtrunk = torch.zeros(ctx.trunk_shape, device=pts.device, dtype=torch.float32)
         dB = torch.zeros_like(B, memory_format=torch.contiguous_format)
         dbr = torch.zeros_like(biasrows, memory_format=torch.contiguous_format)
-        wsb = _C.field_bwd_workspace_bytes(C, ctx.mb, biasrows.shape[0])   # (+ the fixed-point row table: used when rows are per ray / > 4 per class)
-        wsp = torch.empty(wsb, device=pts.device, dtype=torch.uint8)
+        wsp = torch.empty(_C.field_bwd_workspace_bytes(C, ctx.mb), device=pts.device, dtype=torch.uint8)
         field_bwd(pts.contiguous(), B.contiguous(), packed, biasrows.contiguous(), ctx.ray_row,
                   ctx.scale, d_sig.contiguous(), d_rgb.contiguous(), ctx.gs, dtrunk, dB, dbr, C, R, S, ctx.rpc, ctx.mb,
-                  wsp)
-        return None, dB, dtrunk, dbr, None, None, None, None, None
+                  wsp, packed_lo=lo if lo.numel() else None)
+        return None, dB, dtrunk, dbr, None, None, None, None, None, None

@@ -198,30 +198,9 @@ int cnr_field_fwd(const float* pts, const float* B, const void* packed, const fl
                   int64_t B_stride, const void* packed_lo,
                   void* stream);
 
-/* Backward of cnr_field_fwd (recomputes the forward per tile): d_sigma (C,R,S) = dL/dsigmas,
- * d_rgb (C,R,S,3) -> dtrunk (C,13892), dB (C,21,3), dbiasrows (rows,4,32); all three ACCUMULATED
- * (zero them first).  dtrunk receives no bias gradient for the four latent-conditioned layers: those
- * biases reach the kernel only through biasrows, whose gradient the caller back-propagates (PyTorch).
- * grad_scale: power-of-two loss scale applied to d_sigma / d_rgb on load and removed on store (the
- * data-gradient chain runs on f16 MFMA operands); scaled d_sigma is clamped to +-8192.
- * rows_per_class: rows of biasrows per class when rows are laid out class-major and ray_row != NULL
- * (<= 4 enables the in-LDS row accumulation); pass R when ray_row == NULL.  S <= 240.
- * max_blocks: workgroups per class (0 = 256).
- * workspace: caller-allocated, 16-B aligned, contents irrelevant, >= cnr_field_bwd_workspace_bytes(C, max_blocks)
- * bytes -- every workgroup stores one record of partial sums into it with plain stores and a last small kernel sums
- * the records in a fixed order -- PLUS cnr_field_bwd_rows_table_bytes(total rows of biasrows) bytes when the rows do
- * not fit the kernels' LDS tables (ray_row == NULL, or rows_per_class > 4): their sums go through a 2^-40 fixed-point
- * table behind the records (cleared on `stream`, integer atomics, added to dbiasrows by a last small kernel).  No
- * float atomic on a shared address anywhere: the gradient is bitwise reproducible for every row layout (round 3;
- * the per-ray / many-object path used float atomics before).  A workspace without room for the table: CNR_E_ARG.
- * Three to five launches on `stream`; capturable into a hipGraph. */
+/* Backward of cnr_field_fwd: cnr_field_bwd_pipe, declared below beside the one-launch step body it shares its kernel with
+ * (the block-split cnr_field_bwd of rounds 1-3 is gone).  Size of its per-workgroup records: */
 int64_t cnr_field_bwd_workspace_bytes(int C, int max_blocks);
-int64_t cnr_field_bwd_rows_table_bytes(int64_t total_rows);
-int cnr_field_bwd(const float* pts, const float* B, const void* packed, const float* biasrows,
-                  const int* ray_row, float scale, const float* d_sigma, const float* d_rgb,
-                  float grad_scale, float* dtrunk, float* dB, float* dbiasrows, int C, int R, int S,
-                  int rows_per_class, int max_blocks, void* workspace, int64_t workspace_bytes, int64_t B_stride,
-                  int64_t dtrunk_stride, int64_t dB_stride, void* stream);
 
 /* ---- dense layers of the background model, OccupancyMap (src/model.py:86-155) -----------------
  * y (M,N) = act(x (M,K) W^T + b), W (N,K) row-major as torch.nn.Linear stores it, relu != 0: act = ReLU.
@@ -492,18 +471,27 @@ int cnr_step_grad(const float* theta, float* grad, int64_t class_stride, int64_t
                   float* dbiasrows, float reg_scale, const void* records, int nwg, const long long* rows_fix,
                   const int* n_obj_cls, void* stream);
 
-/* Same contract and results as cnr_field_bwd, ONE field kernel + the record reduction: a workgroup is four chain waves that
- * run forward recompute + data-gradient chain + PE backward for one 32-sample tile each, plus four waves that own the
- * weight-gradient accumulators and consume the chain waves' per-layer images behind a workgroup barrier -- eight waves, two
- * per SIMD (csrc/fused_bwd_pipe8_kernel.h).  chain_waves must be 4 (the 4-wave pipelines with 2 / 3 chain waves of rounds 1-2 are
- * gone; the parameter stays in the signature).  max_blocks / workspace as above.
- * Class-major rows, up to 15 per class, stay on this path -- their bias-row sums travel in the records (and in rows_fix);
- * anything else (no ray_row, more rows) is handed to cnr_field_bwd (rows_fix / skip_reduce must then be NULL / 0). */
+/* Backward of cnr_field_fwd (recomputes the forward per tile): d_sigma (C,R,S) = dL/dsigmas, d_rgb (C,R,S,3) -> dtrunk
+ * (C,13892), dB (C,21,3), dbiasrows (rows,4,32); all three ACCUMULATED (zero them first).  dtrunk receives no bias gradient for
+ * the four latent-conditioned layers: those biases reach the kernel only through biasrows, whose gradient the caller
+ * back-propagates (cnr_latent_bwd / cnr_step_tail).  grad_scale: power-of-two loss scale applied to d_sigma / d_rgb on load and
+ * removed on store (the data-gradient chain runs on f16 MFMA operands); scaled d_sigma is clamped to +-8192.  S <= 240.
+ * ONE field kernel + the record reduction: a workgroup is four chain waves that run forward recompute + data-gradient chain + PE
+ * backward for one 32-sample tile each, plus four waves that own the weight-gradient accumulators and consume the chain waves'
+ * per-layer images behind a workgroup barrier -- eight waves, two per SIMD (csrc/fused_bwd_pipe8_kernel.h).  chain_waves must be
+ * 4 (kept in the signature).  max_blocks: workgroups per class (0 = 256).  workspace: caller-allocated, 16-B aligned, contents
+ * irrelevant, >= cnr_field_bwd_workspace_bytes(C, max_blocks) bytes: every workgroup stores one record of partial sums into it
+ * with plain stores and a last small kernel sums the records in a fixed order -- no float atomic anywhere, bitwise reproducible.
+ * packed_lo (optional): the residual image the FORWARD ran with (cnr_field_fwd / cnr_field_fwd_render, precise geometry branch):
+ * the recompute then forms the same activations and ReLU masks as that forward -- without it the backward of a precise forward
+ * would be the gradient of the plain-f16 function.
+ * Rows: ray_row REQUIRED, class-major, 1 .. 15 per class (their bias-row sums travel in the records and in rows_fix);
+ * CNR_E_SHAPE otherwise -- larger classes (up to 128 objects) train on cnr_field_train, one object per tile. */
 /* rows_fix (optional): per-object bias-row sums also accumulated as 2^-40 fixed point into this (8, C, n_obj, 4, 32)
  * int64 table (8 copies, a workgroup uses copy index & 7, to shorten the same-address atomic queues; caller zeroes it); skip_reduce != 0: stop after the field kernel, the caller reduces the nwg =
  * cnr_field_bwd_pipe_blocks(R, S, chain_waves, max_blocks) records per class in `workspace` itself (cnr_step_tail). */
 int cnr_field_bwd_pipe_blocks(int R, int S, int chain_waves, int max_blocks);
-int cnr_field_bwd_pipe(const float* pts, const float* B, const void* packed, const float* biasrows,
+int cnr_field_bwd_pipe(const float* pts, const float* B, const void* packed, const void* packed_lo, const float* biasrows,
                        const int* ray_row, float scale, const float* d_sigma, const float* d_rgb,
                        float grad_scale, float* dtrunk, float* dB, float* dbiasrows, int C, int R, int S,
                        int rows_per_class, int max_blocks, int chain_waves, void* workspace,
@@ -544,8 +532,10 @@ int cnr_field_fwd_fp8(const float* pts, const float* B, const void* packed, cons
  * once per workgroup iteration); the records carry no row sums then and cnr_step_tail / cnr_step_grad take all of them from
  * the table.  Returns CNR_E_SHAPE for S > 128, for more than 32 rows per class, and for more than 15 with S <= 16 or without
  * rows_fix (use the two calls). */
-int cnr_field_train_blocks(int R, int S, int max_blocks);
-int64_t cnr_field_train_workspace_bytes(int C, int R, int S, int max_blocks);
+int cnr_field_train_blocks(int R, int S, int max_blocks, int rows_per_class);
+int64_t cnr_field_train_workspace_bytes(int C, int R, int S, int max_blocks, int rows_per_class);
+/* (rows_per_class: more than 15 object rows per class need one object per tile, so rays of up to 16 samples -- otherwise two
+ *  to a tile -- are padded to a 32-slot tile of their own there: the block count depends on it) */
 /* packed_lo (optional, (C, cnr_pack_lo_bytes()) from cnr_pack_weights_lo / cnr_step_prologue): the forward's geometry
  * branch as three products per fragment (see cnr_pack_weights_lo) -- the trainer's default; NULL: plain f16 operands. */
 typedef struct cnr_field_train_args {

@@ -34,7 +34,7 @@ def test_header_declares_the_hot_path():
     fns = declared_functions()
     for name in ("cnr_sample_rays", "cnr_pe_fwd", "cnr_pe_bwd", "cnr_mlp_fwd_f32", "cnr_mlp_bwd_f32",
                  "cnr_composite_fwd", "cnr_composite_bwd", "cnr_loss_fwd_bwd", "cnr_adamw_step", "cnr_pack_weights",
-                 "cnr_field_fwd", "cnr_field_bwd", "cnr_field_bwd_pipe", "cnr_render_loss", "cnr_render_loss_finish", "cnr_step_epilogue", "cnr_param_prep", "cnr_step_prologue", "cnr_adamw_epilogue", "cnr_step_tail", "cnr_slice_maxdepth", "cnr_step_grad", "cnr_field_fwd_render", "cnr_gather_pool", "cnr_dense_fwd", "cnr_dense_bwd", "cnr_latent_fwd", "cnr_latent_bwd", "cnr_step_advance", "cnr_field_train", "cnr_slice_maskcounts", "cnr_field_fwd_fp8",
+                 "cnr_field_fwd", "cnr_field_bwd_pipe", "cnr_render_loss", "cnr_render_loss_finish", "cnr_step_epilogue", "cnr_param_prep", "cnr_step_prologue", "cnr_adamw_epilogue", "cnr_step_tail", "cnr_slice_maxdepth", "cnr_step_grad", "cnr_field_fwd_render", "cnr_gather_pool", "cnr_dense_fwd", "cnr_dense_bwd", "cnr_latent_fwd", "cnr_latent_bwd", "cnr_step_advance", "cnr_field_train", "cnr_slice_maskcounts", "cnr_field_fwd_fp8",
                  "cnr_pack_weights_fp8"):
         assert name in fns, name
 

@@ -132,14 +132,14 @@ def test_fused_forward_full_size(cnr, dev, C, R, S, L, wscale):
 
 
 # ---- fused backward ----------------------------------------------------------------------------------
-@pytest.fixture(params=["split", "pipe4"])
-def bwd_variant(request, cnr, monkeypatch):
-    """every cnr_field_bwd implementation must meet the same bars (ops.field_bwd dispatches on this)."""
-    monkeypatch.setattr(cnr.ops, "FIELD_BWD_VARIANT", request.param)
+@pytest.fixture(params=["plain_f16", "precise_geometry"])
+def bwd_variant(request):
+    """the stand-alone backward recomputes the forward it differentiates: plain f16 operands, or the precise geometry branch
+    (three products per fragment) when the forward ran with the residual image -- both must meet the same bars"""
     return request.param
 
 
-def _fused_step(cnr, g, dev, grad_scale, max_blocks=0):
+def _fused_step(cnr, g, dev, grad_scale, max_blocks=0, precise=False):
     """Full train-step graph on the fused kernels: torch holds the flat trunk, latent layers and codes."""
     mlp = g.mlp()
     C, n_obj = g.C, g.n_obj
@@ -156,7 +156,8 @@ def _fused_step(cnr, g, dev, grad_scale, max_blocks=0):
     zlat = torch.stack(zl, dim=2)                                   # (C, n_obj, 4, 32)
     brows = cnr.ops.bias_rows(trunk, zlat).reshape(C * n_obj, 4, 32)
     ray_row = (g.t("indices") + torch.arange(C, device=dev)[:, None] * n_obj).to(torch.int32).contiguous()
-    sig, rgb, _ = cnr.ops.FusedFieldFn.apply(g.t("pts"), B, trunk, brows, ray_row, g.scale, n_obj, grad_scale, max_blocks)
+    sig, rgb, _, _ = cnr.ops.FusedFieldFn.apply(g.t("pts"), B, trunk, brows, ray_row, g.scale, n_obj, grad_scale, max_blocks,
+                                                precise)
     _term, depth, var, rgbr, opa = cnr.ops.CompositeFn.apply(sig, rgb, g.t("z"))
     losses, flags, _, _, _ = cnr.ops.RenderLossFn.apply(depth, var, rgbr, opa, g.t("gt_depth"), g.t("gt_rgb"),
                                                         g.t("labels"), g.t("depth_mask").to(torch.uint8))
@@ -252,6 +253,9 @@ def test_fused_backward_vs_emulated_f16(cnr, dev, name, bwd_variant):
     pre-activation is ~1e-6 can still flip between MFMA and torch.matmul summation order: 1.5e-2 on the
     texture branch of the 120x10 fixture, tools/debug_fused_grads.py); the rest is f16 rounding of dPre."""
     g = Golden(name, dev)
+    if bwd_variant == "precise_geometry":
+        pytest.skip("the emulation restates the PLAIN f16 pipeline; the precise recompute is pinned against the fp32 reference below "
+                    "and against the one-launch step (tests/test_trainer_gpu.py)")
     out = _fused_step(cnr, g, dev, grad_scale=float(2 ** 10))
     P, B, shape, tex, sig, rgb = _emulated_f16_step(cnr, g, dev)
     loss = _torch_loss(sig, rgb, g)
@@ -259,8 +263,9 @@ def test_fused_backward_vs_emulated_f16(cnr, dev, name, bwd_variant):
         loss = loss + 0.0005 * sum(torch.norm(shape[c], dim=-1).sum() + torch.norm(tex[c], dim=-1).sum() for c in range(g.C))
     loss.backward()
     assert rel_l2(out["loss"], loss) < 1e-4
-    TOL = 5e-2      # per tensor on 64-ray fixtures: a handful of ReLU units within an f16 ulp of zero decide it (3.3e-2 on
-    # texture_layer_1 of one fixture); the whole-trunk bar below (5e-3) is the tight one
+    TOL = 3e-2      # per tensor on 64-ray fixtures: a unit whose pre-activation is ~1e-6 can flip between MFMA and torch.matmul
+    # summation order (measured worst, round 4: 2.3e-2 on encoding_viewdir.0.weight of one fixture, 1.5e-2 on the texture branch of the
+    # 120 x 10 one); the whole-trunk bar below (5e-3) is the tight one
     zg = lambda p: torch.zeros_like(p) if p.grad is None else p.grad
     off, num, den = 0, 0.0, 0.0
     for n, o, i in cnr.ops.TRUNK_LAYERS:
@@ -292,7 +297,7 @@ def test_fused_backward_vs_fp32_reference(cnr, dev, name, bwd_variant):
     gradient rides on the remaining term (0.139 B, 0.086 xyz weight).  Cosine of the full trunk gradient > 0.9995 (measured
     worst 0.99965, that same fixture), loss within 2e-3."""
     g = Golden(name, dev)
-    out = _fused_step(cnr, g, dev, grad_scale=float(2 ** 10))
+    out = _fused_step(cnr, g, dev, grad_scale=float(2 ** 10), precise=bwd_variant == "precise_geometry")
     assert rel_l2(out["loss"], g.t("loss")) < 2e-3
     mlp_ref = {k[5:]: g.t(k) for k in g.z.files if k.startswith("grad.")}
     off, dot, n1, n2 = 0, 0.0, 0.0, 0.0
@@ -382,33 +387,33 @@ def test_field_bwd_full_size_all_variants_agree_and_repeat(cnr, dev, C, R, S, n_
     ray_row = (torch.randint(0, n_obj, (C, R), device=dev) + torch.arange(C, device=dev)[:, None] * n_obj).to(torch.int32)
     dsig = torch.randn(C, R, S, device=dev) * 1e-3
     drgb = torch.randn(C, R, S, 3, device=dev) * 1e-3
-    wsp = torch.empty(_C.field_bwd_workspace_bytes(C, 0, C * n_obj), device=dev, dtype=torch.uint8)
+    wsp = torch.empty(_C.field_bwd_workspace_bytes(C, 0), device=dev, dtype=torch.uint8)
+    lo = ops.pack_weights_lo(v["trunk"].contiguous())
 
-    def run(variant):
+    def run(packed_lo):
         dtrunk = torch.zeros(C, 13892, device=dev); dB = torch.zeros(C, 21, 3, device=dev); dbr = torch.zeros_like(brows)
         ops.field_bwd(pts, B, packed, brows, ray_row, 2.0, dsig, drgb, 2048.0, dtrunk, dB, dbr, C, R, S, n_obj, 0, wsp,
-                      variant=variant)
+                      packed_lo=packed_lo)
         torch.cuda.synchronize()
         return dtrunk, dB, dbr
 
-    ref = run("split")
-    for variant in ("pipe4",):
-        first = run(variant)
-        # (the 8-wave kernel sums cat_layer's e1 products before its y products -- one accumulator of their own, started
-        #  right behind encoding_xyz --, the older kernels after: same arithmetic in another fp32 order, and the handful of
-        #  units it moves across zero flip their ReLU masks: 1e-5 .. 4e-4 on the gradient instead of 1e-5 among themselves, 1.6e-3 at 2 x 1000 x 96)
-        tol = 3e-3
-        for name, a, b in zip(("dtrunk", "dB", "dbiasrows"), first, ref):
-            assert rel_l2(a, b) < tol, (variant, name, rel_l2(a, b))
+    plain = run(None)
+    for packed_lo in (None, lo):
+        first = run(packed_lo)
+        # the precise recompute differs from the plain one by the forward's f16 operand error: the units it moves across zero flip
+        # their ReLU masks -- 1.0e-2 .. 2.4e-2 on the gradient of these random-weight, random-upstream cases (measured), the distance
+        # of an f16 forward's gradient from the fp32 one; which is why the backward must recompute the forward that was rendered
+        for name, a, b in zip(("dtrunk", "dB", "dbiasrows"), first, plain):
+            assert rel_l2(a, b) < 5e-2, (name, rel_l2(a, b))
         for rep in range(3):
-            again = run(variant)
+            again = run(packed_lo)
             for name, a, b in zip(("dtrunk", "dB", "dbiasrows"), again, first):
-                assert torch.equal(a, b), (variant, name, rep, float((a - b).abs().max()))
+                assert torch.equal(a, b), (name, rep, float((a - b).abs().max()))
 
 
 def test_field_bwd_pipe_refuses_more_than_240_samples(cnr, dev):
-    """The pipelined kernels divide by S with a 16-bit reciprocal that is exact up to S = 240 (sizes above are the
-    block-split kernels' job): a larger S is an error, not a wrong gradient."""
+    """The kernel divides by S with a 16-bit reciprocal that is exact up to S = 240: a larger S is an error, not a wrong
+    gradient."""
     ops, _C = cnr.ops, cnr._C
     C, R, S, n_obj = 1, 8, 241, 4
     theta, lay = cnr.fused.init_params(C, 32, n_obj, torch.Generator().manual_seed(0), dev)
@@ -416,11 +421,17 @@ def test_field_bwd_pipe_refuses_more_than_240_samples(cnr, dev):
     packed = ops.pack_weights(v["trunk"].contiguous())
     z = lambda *s: torch.zeros(*s, device=dev)
     brows, ray_row = z(C * n_obj, 4, 32), torch.zeros(C, R, device=dev, dtype=torch.int32)
-    wsp = torch.empty(_C.field_bwd_workspace_bytes(C, 0, C * n_obj), device=dev, dtype=torch.uint8)
-    for variant in ("pipe4",):
+    wsp = torch.empty(_C.field_bwd_workspace_bytes(C, 0), device=dev, dtype=torch.uint8)
+    with pytest.raises(_C.CnrError):
+        ops.field_bwd(z(C, R, S, 3), v["B"].contiguous(), packed, brows, ray_row, 2.0, z(C, R, S), z(C, R, S, 3), 1.0,
+                      z(C, 13892), z(C, 21, 3), z(C * n_obj, 4, 32), C, R, S, n_obj, 0, wsp)
+    # ... and so are rows the kernel's row-sum blocks cannot hold: more than 15 per class, or none (one row per ray): those
+    # classes train on cnr_field_train (one object per tile, up to 128)
+    S = 32
+    for rows, rr in ((16, ray_row), (R, None)):
         with pytest.raises(_C.CnrError):
-            ops.field_bwd(z(C, R, S, 3), v["B"].contiguous(), packed, brows, ray_row, 2.0, z(C, R, S), z(C, R, S, 3), 1.0,
-                          z(C, 13892), z(C, 21, 3), z(C * n_obj, 4, 32), C, R, S, n_obj, 0, wsp, variant=variant)
+            ops.field_bwd(z(C, R, S, 3), v["B"].contiguous(), packed, z(C * rows, 4, 32), rr, 2.0, z(C, R, S), z(C, R, S, 3), 1.0,
+                          z(C, 13892), z(C, 21, 3), z(C * rows, 4, 32), C, R, S, rows, 0, wsp)
 
 
 @pytest.mark.parametrize("C,R,S", [(1, 2048, 64), (2, 4096, 128)])
@@ -439,7 +450,7 @@ def test_field_bwd_is_linear_in_the_upstream_gradients(cnr, dev, C, R, S):
     pts = torch.rand(C, R, S, 3, device=dev) * 2 - 1
     brows = torch.randn(C * n_obj, 4, 32, device=dev) * 0.1
     ray_row = (torch.randint(0, n_obj, (C, R), device=dev) + torch.arange(C, device=dev)[:, None] * n_obj).to(torch.int32)
-    wsp = torch.empty(_C.field_bwd_workspace_bytes(C, 0, C * n_obj), device=dev, dtype=torch.uint8)
+    wsp = torch.empty(_C.field_bwd_workspace_bytes(C, 0), device=dev, dtype=torch.uint8)
 
     def run(dsig, drgb):
         dtrunk = torch.zeros(C, 13892, device=dev); dB = torch.zeros(C, 21, 3, device=dev); dbr = torch.zeros_like(brows)
@@ -468,7 +479,7 @@ def test_loss_scale_clamp_is_reported(cnr, dev):
     pts = torch.rand(C, R, S, 3, device=dev) * 2 - 1
     brows = torch.randn(C * n_obj, 4, 32, device=dev) * 0.1
     ray_row = (torch.randint(0, n_obj, (C, R), device=dev) + torch.arange(C, device=dev)[:, None] * n_obj).to(torch.int32)
-    wsp = torch.empty(_C.field_bwd_workspace_bytes(C, 0, C * n_obj), device=dev, dtype=torch.uint8)
+    wsp = torch.empty(_C.field_bwd_workspace_bytes(C, 0), device=dev, dtype=torch.uint8)
     z = lambda *s_: torch.zeros(*s_, device=dev)
     for big_class in (None, 1):
         dsig = torch.randn(C, R, S, device=dev) * 1e-3
@@ -476,50 +487,9 @@ def test_loss_scale_clamp_is_reported(cnr, dev):
             dsig[big_class, 5, 7] = 9.0                       # x 2048 = 18432 > 8192
         clamp = torch.zeros(C, device=dev, dtype=torch.int32)
         ops.field_bwd(pts, B, packed, brows, ray_row, 2.0, dsig, z(C, R, S, 3), 2048.0, z(C, 13892), z(C, 21, 3),
-                      z(C * n_obj, 4, 32), C, R, S, n_obj, 0, wsp, variant="pipe4", clamp_flags=clamp)
+                      z(C * n_obj, 4, 32), C, R, S, n_obj, 0, wsp, clamp_flags=clamp)
         torch.cuda.synchronize()
         want = [0, 0] if big_class is None else [0, 16]
         assert clamp.tolist() == want, clamp.tolist()
 
 
-@pytest.mark.gpu
-def test_backward_many_objects_is_bitwise_repeatable(cnr, dev):
-    """More than 15 objects per class (or one bias row per ray) take the block-split kernels, whose per-row bias sums do not fit an
-    LDS table.  They go through a 2^-40 fixed-point table with integer atomics (round 3; float atomics before: repeatable to
-    rounding only): two runs agree bit for bit, and the per-object sums equal the per-ray sums added up per object."""
-    ops, _C = cnr.ops, cnr._C
-    C, R, S, n_obj, L = 2, 1024, 32, 20, 32
-    theta, lay = cnr.fused.init_params(C, L, n_obj, torch.Generator().manual_seed(5), dev)
-    v = lay.views(theta)
-    packed = ops.pack_weights(v["trunk"].contiguous())
-    B = v["B"].contiguous()
-    g = torch.Generator(device=dev).manual_seed(11)
-    pts = torch.rand(C, R, S, 3, device=dev, generator=g) * 2 - 1
-    brows = torch.randn(C * n_obj, 4, 32, device=dev, generator=g) * 0.1
-    obj = torch.randint(0, n_obj, (C, R), device=dev, generator=g)
-    ray_row = (obj + torch.arange(C, device=dev)[:, None] * n_obj).to(torch.int32)
-    dsig = torch.randn(C, R, S, device=dev, generator=g) * 1e-3
-    drgb = torch.randn(C, R, S, 3, device=dev, generator=g) * 1e-3
-
-    def run(rows, rr, n_rows):
-        wsp = torch.empty(_C.field_bwd_workspace_bytes(C, 0, rows.shape[0]), device=dev, dtype=torch.uint8)
-        dtrunk = torch.zeros(C, 13892, device=dev); dB = torch.zeros(C, 21, 3, device=dev); dbr = torch.zeros_like(rows)
-        ops.field_bwd(pts, B, packed, rows, rr, 2.0, dsig, drgb, 2048.0, dtrunk, dB, dbr, C, R, S, n_rows, 0, wsp)
-        torch.cuda.synchronize()
-        return dtrunk, dB, dbr
-
-    a, b = run(brows, ray_row, n_obj), run(brows, ray_row, n_obj)
-    for x, y in zip(a, b):
-        assert torch.equal(x, y)
-    assert a[2].abs().sum() > 0
-    # one row per ray with the same values: same trunk gradient, and its row sums add up to the per-object ones
-    per_ray = brows[ray_row.long().flatten()].contiguous()
-    c = run(per_ray, None, R)
-    assert rel_l2(c[0], a[0]) < 1e-6 and rel_l2(c[1], a[1]) < 1e-6
-    agg = torch.zeros_like(brows).index_add_(0, ray_row.long().flatten(), c[2])
-    assert rel_l2(agg, a[2]) < 1e-5, rel_l2(agg, a[2])
-    # a workspace without room for the table is refused, not overrun
-    small = torch.empty(_C.field_bwd_workspace_bytes(C, 0), device=dev, dtype=torch.uint8)
-    with pytest.raises(_C.CnrError):
-        ops.field_bwd(pts, B, packed, brows, ray_row, 2.0, dsig, drgb, 2048.0, torch.zeros(C, 13892, device=dev),
-                      torch.zeros(C, 21, 3, device=dev), torch.zeros_like(brows), C, R, S, n_obj, 0, small)
