@@ -103,7 +103,9 @@ __device__ __forceinline__ int block_index(int kind, int o, int c) {
   }
 }
 
-using cnr_rec::REC_FLOATS;
+using cnr_rec::REC_ENTRIES;
+using cnr_rec::rec_t;
+using cnr_rec::rec_pack;
 using cnr_rec::rec_entry_written;
 
 // sum over the 32 lanes of each wave half with DPP row operations (6 VALU ops; __shfl_xor lowers to
@@ -215,7 +217,7 @@ __device__ __forceinline__ float low_half_to_both(float v) {
 // 4 quarters of the workgroup range; each quarter keeps 8 loads in flight, the quarters are combined through LDS in
 // a fixed order.  Entries no launch writes (latent-layer biases, padding, unused row sums) are skipped, so the
 // workspace needs no clearing.
-__global__ __launch_bounds__(256) void reduce_records_kernel(const float* __restrict__ records, int nwg,
+__global__ __launch_bounds__(256) void reduce_records_kernel(const rec_t* __restrict__ records, int nwg,
                                                              float* __restrict__ dtrunk, float* __restrict__ dB,
                                                              float* __restrict__ dbiasrows, int rows_per_class,
                                                              int64_t st_trunk, int64_t st_B) {
@@ -223,11 +225,11 @@ __global__ __launch_bounds__(256) void reduce_records_kernel(const float* __rest
   const int c = blockIdx.y;
   const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + e;
-  const bool live = i < REC_FLOATS && rec_entry_written(i, rows_per_class);
+  const bool live = i < REC_ENTRIES && rec_entry_written(i, rows_per_class);
   float s = 0.0f;
   if (live) {
     const int per = (nwg + 3) / 4, w0 = q * per, w1 = min(nwg, w0 + per);
-    const float* r = records + (size_t)c * nwg * REC_FLOATS + i;
+    const rec_t* r = records + (size_t)c * nwg * REC_ENTRIES + i;
     s = cnr_rec::record_range_sum(r, w0, w1);
   }
   part[q][e] = s;

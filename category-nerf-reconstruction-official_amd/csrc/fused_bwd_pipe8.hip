@@ -34,7 +34,7 @@ static int cnr_field_bwd_pipe8_launch(const float* pts, const float* B, const vo
 //  one-launch path, cnr_field_train, which takes up to 128.)
 extern "C" int64_t cnr_field_bwd_workspace_bytes(int C, int max_blocks) {
   const int64_t cap = max_blocks > 0 ? max_blocks : 256;
-  return (int64_t)C * cap * REC_FLOATS * (int64_t)sizeof(float);
+  return (int64_t)C * cap * REC_ENTRIES * (int64_t)sizeof(rec_t);
 }
 extern "C" int cnr_field_bwd_pipe_blocks(int R, int S, int chain_waves, int max_blocks) {
   if (R <= 0 || S <= 0 || chain_waves != 4) return 0;
@@ -63,13 +63,13 @@ extern "C" int cnr_field_bwd_pipe(const float* pts, const float* B, const void* 
   const int64_t N = (int64_t)R * S;
   if (N > (int64_t)0x7fffff00) return CNR_E_SHAPE;  // tile and sample indices are 32-bit inside the kernel
   const int blocks = cnr_field_bwd_pipe_blocks(R, S, 4, max_blocks);
-  if (workspace_bytes < (int64_t)C * blocks * REC_FLOATS * (int64_t)sizeof(float)) return CNR_E_ARG;
+  if (workspace_bytes < (int64_t)C * blocks * REC_ENTRIES * (int64_t)sizeof(rec_t)) return CNR_E_ARG;
   const int rc = cnr_field_bwd_pipe8_launch(pts, B, packed, packed_lo, biasrows, ray_row, scale, d_sigma, d_rgb, grad_scale, C, R, S,
                                             rows_per_class, blocks, workspace, B_stride, rows_fix, clamp_flags, stream);
   if (rc != CNR_OK) return rc;
   if (skip_reduce) return CNR_OK;   // the caller reduces the records itself (cnr_step_tail / cnr_step_grad)
-  hipLaunchKernelGGL(reduce_records_kernel, dim3(REC_FLOATS / 64, (unsigned)C), dim3(256), 0, (hipStream_t)stream,
-                     (const float*)workspace, blocks, dtrunk, dB, dbiasrows, rows_per_class,
+  hipLaunchKernelGGL(reduce_records_kernel, dim3(REC_ENTRIES / 64, (unsigned)C), dim3(256), 0, (hipStream_t)stream,
+                     (const rec_t*)workspace, blocks, dtrunk, dB, dbiasrows, rows_per_class,
                      dtrunk_stride > 0 ? dtrunk_stride : (int64_t)TRUNK, dB_stride > 0 ? dB_stride : (int64_t)63);
   CNR_LAUNCH_CHECK();
   return CNR_OK;
@@ -112,7 +112,7 @@ extern "C" int cnr_field_train(const cnr_field_train_args* a, void* stream) {
   if (((uintptr_t)a->packed & 15) != 0 || ((uintptr_t)a->records & 15) != 0 || ((uintptr_t)a->packed_lo & 15) != 0 ||
       ((uintptr_t)a->biasrows & 15) != 0)
     return CNR_E_ALIGN;
-  if (a->records_bytes < (int64_t)C * blocks * REC_FLOATS * (int64_t)sizeof(float) ||
+  if (a->records_bytes < (int64_t)C * blocks * REC_ENTRIES * (int64_t)sizeof(rec_t) ||
       a->loss_workspace_bytes < cnr_field_train_workspace_bytes(C, R, S, a->max_blocks, rows_per_class))
     return CNR_E_ARG;
   const bool pad = S != sp;   // exact fit: the plain index arithmetic (2 % faster at configs[1] than the padded form)

@@ -120,7 +120,7 @@ template <int NCH, int NDW, int WIDE, int KR, bool TWO, bool PAD, bool GEO>
 __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
     const float* __restrict__ pts, const float* __restrict__ Bdir, const unsigned char* __restrict__ packed,
     const unsigned char* __restrict__ packed_lo, const float* __restrict__ biasrows, const int* __restrict__ ray_row, float inv_scale,
-    const float* __restrict__ d_sigma, const float* __restrict__ d_rgb, float gscale, float* __restrict__ records,
+    const float* __restrict__ d_sigma, const float* __restrict__ d_rgb, float gscale, rec_t* __restrict__ records,
     int N, int S, int R, int rows_per_class, int64_t B_stride, long long* __restrict__ rows_fix,
     int* __restrict__ clamp_flags, TrainArgs ta) {
   static_assert(KR == 0 || KR == 1 || KR == 2 || KR == 4, "tiles per ray");
@@ -1124,14 +1124,14 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
     else if (dwid == 2) dw_loop(IC<2>{});
     else dw_loop(IC<3>{});
     // ---- this wave's blocks -> the workgroup's record, straight from the accumulators -------------------------
-    float* rec = records + ((size_t)c * gridDim.x + blockIdx.x) * REC_FLOATS;
+    rec_t* rec = records + ((size_t)c * gridDim.x + blockIdx.x) * REC_ENTRIES;
 #define CNR_PSTORE8(KIND, NROWS)                                                               \
   if (owner8<NDW>(KIND) == dwid) {                                                             \
     constexpr int li = local8<NDW>(KIND);                                                      \
     if (bi0[li] >= 0) {                                                                        \
       _Pragma("unroll") for (int reg = 0; reg < 16; ++reg) {                                   \
         const int o = acc_row(reg, h);                                                         \
-        if (o < (NROWS)) rec[bi0[li] + o * bst[li]] = Wacc[li][reg] * inv_gs;                  \
+        if (o < (NROWS)) rec[bi0[li] + o * bst[li]] = rec_pack(Wacc[li][reg] * inv_gs);        \
       }                                                                                        \
     }                                                                                          \
   }
@@ -1145,7 +1145,7 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int o = acc_row(reg, h) - 16;
-        if (o >= 0 && o < 3) rec[r2i0 + o * r2st] = Wacc[li][reg] * inv_gs;
+        if (o >= 0 && o < 3) rec[r2i0 + o * r2st] = rec_pack(Wacc[li][reg] * inv_gs);
       }
     }
     if (dwid == owner8<NDW>(BK_RS)) {  // the row-sum block: [m][feature], m = rows_per_class * latent slot + object row | then the two biases
@@ -1155,12 +1155,12 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
       for (int reg = 0; reg < 16; ++reg) {
         const int m = acc_row(reg, h);
         const float v = (blk ? Wacc[LI_RS2][reg] : Wacc[LI_RS][reg]) * inv_gs;
-        if (blk == 0 && m == nlat_rows) rec[OFF_ES_B + col] = v;
-        else if (blk == 0 && m == nlat_rows + 1) { if (col < 16) rec[OFF_R0_B + col] = v; }
+        if (blk == 0 && m == nlat_rows) rec[OFF_ES_B + col] = rec_pack(v);
+        else if (blk == 0 && m == nlat_rows + 1) { if (col < 16) rec[OFF_R0_B + col] = rec_pack(v); }
         else if (!ROWTILE && m < nlat_rows && m - ((m * rpc_inv) >> 16) * rs < rows_per_class) {   // (ROWTILE: flushed every iteration)
           const int slot = 2 * blk + ((m * rpc_inv) >> 16);
           const int i = (m - ((m * rpc_inv) >> 16) * rs) * 128 + slot * 32 + col;  // dbiasrows [row][latent slot][feature]
-          rec[TRUNK + 126 + i] = v;
+          rec[TRUNK + 126 + i] = rec_pack(v);
           if (rows_fix)
             atomicAdd(reinterpret_cast<unsigned long long*>(
                           rows_fix + ((size_t)(blockIdx.x % cnr_rec::ROWS_FIX_COPIES) * gridDim.y + c) * rows_per_class * 128 + i),
@@ -1181,7 +1181,7 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
 
   // ========================================= flush ====================================================
   // (the dW waves have written their blocks above; what is left are the chain waves' partial sums)
-  float* rec = records + ((size_t)c * gridDim.x + blockIdx.x) * REC_FLOATS;
+  rec_t* rec = records + ((size_t)c * gridDim.x + blockIdx.x) * REC_ENTRIES;
   __syncthreads();
   P8PHASE(2);
   {
@@ -1199,9 +1199,9 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
       }
       return v;
     };
-    for (int i = threadIdx.x; i < 63; i += NTHR) { rec[TRUNK + i] = (sum_chain(64 + i) + sum_dw(i)) * inv_gs; rec[TRUNK + 63 + i] = 0.0f; }
-    for (int i = threadIdx.x; i < 32; i += NTHR) rec[OFF_SG_W + i] = sum_chain(i) * inv_gs;
-    if (threadIdx.x == 0) rec[OFF_SG_B] = sum_chain(32) * inv_gs;
+    for (int i = threadIdx.x; i < 63; i += NTHR) { rec[TRUNK + i] = rec_pack((sum_chain(64 + i) + sum_dw(i)) * inv_gs); rec[TRUNK + 63 + i] = 0; }
+    for (int i = threadIdx.x; i < 32; i += NTHR) rec[OFF_SG_W + i] = rec_pack(sum_chain(i) * inv_gs);
+    if (threadIdx.x == 0) rec[OFF_SG_B] = rec_pack(sum_chain(32) * inv_gs);
     if constexpr (KR > 0) {   // per-block loss partials + the class header, the format of cnr_field_fwd_render
       const int nb = gridDim.x, Cn = gridDim.y;
       if (threadIdx.x < 3) ta.partials[((size_t)c * nb + blockIdx.x) * 3 + threadIdx.x] = sum_chain(40 + threadIdx.x);
@@ -1230,7 +1230,7 @@ static int launch_p8(const float* pts, const float* B, const void* packed, const
   const int64_t N = (int64_t)R * S;
   hipLaunchKernelGGL((field_bwd_pipe8_kernel<4, 4, WIDE, KR, TWO, PAD, GEO>), dim3((unsigned)blocks, (unsigned)C), dim3(512), LDS,
                      (hipStream_t)stream, pts, B, (const unsigned char*)packed, (const unsigned char*)packed_lo, biasrows,
-                     ray_row, 1.0f / scale, d_sigma, d_rgb, grad_scale, (float*)workspace, (int)N, S, R, rows_per_class,
+                     ray_row, 1.0f / scale, d_sigma, d_rgb, grad_scale, (rec_t*)workspace, (int)N, S, R, rows_per_class,
                      B_stride > 0 ? B_stride : (int64_t)63, rows_fix, clamp_flags, ta);
   CNR_LAUNCH_CHECK();
   return CNR_OK;

@@ -14,7 +14,16 @@ constexpr int ROWS_MAX = 15;
 // configs/Replica/config_replica_room0.json:15; nothing in the kernels depends on the count any more -- the tail launch's latent
 // blocks read only the rows they need, latent_common.h.)
 constexpr int ROWS_TILE_MAX = 128;
-constexpr int REC_FLOATS = ((TRUNK + 126 + ROWS_MAX * 128 + 255) / 256) * 256;  // one workgroup's record
+constexpr int REC_ENTRIES = ((TRUNK + 126 + ROWS_MAX * 128 + 255) / 256) * 256;  // one workgroup's record
+// A record entry is a bf16 (round 4; fp32 before): 256 records x 64.5 KB written by the field kernel and read once by the step's
+// last launch were 15 of the 21 MB the step body moves at configs[1].  Each workgroup's partial sum is rounded once (2^-9
+// relative, unbiased); the fixed-order sum over the records stays fp32, so the summed gradient carries ~2^-9 / sqrt(records) =
+// 1e-4 of rounding noise -- under the f16 forward's own (tests/test_fullsize_gpu.py bars unchanged).  bf16, not f16: a workgroup's
+// share of a small gradient entry sits far below f16's 6e-8.  The per-object bias-row sums of the step go through the int64
+// fixed-point table as before (exact).
+typedef unsigned short rec_t;
+__device__ __forceinline__ rec_t rec_pack(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }   // v_cvt_pk_bf16_f32: RNE
+__device__ __forceinline__ float rec_unpack(rec_t b) { return __builtin_bit_cast(float, (unsigned int)b << 16); }
 constexpr double ROWS_FIX_SCALE = 1099511627776.0;  // 2^40: bias-row sums as int64 fixed point (order-free atomics)
 #ifndef CNR_TAIL_EPB
 #define CNR_TAIL_EPB 64
@@ -35,7 +44,7 @@ __device__ __forceinline__ bool rec_entry_written(int i, int rows_per_class) {
 // sum of entry i over records [w0, w1) of one class (r = that class's first record + i).  32 loads in flight per
 // thread: the reducing kernels run a few waves per CU, so the loads in flight per thread are what hides the memory
 // latency (8 in flight: 64 records = 8 round trips = 8 us; 32: 2 round trips).  Fixed order -> reproducible bits.
-__device__ __forceinline__ float record_range_sum(const float* __restrict__ r, int w0, int w1) {
+__device__ __forceinline__ float record_range_sum(const rec_t* __restrict__ r, int w0, int w1) {
   constexpr int U = 32;
   float a[U];
 #pragma unroll
@@ -44,20 +53,20 @@ __device__ __forceinline__ float record_range_sum(const float* __restrict__ r, i
   // (loads into their own registers, a scheduling barrier, then the adds: written as a[u] += r[..] the compiler is free to
   //  serialise load -> wait -> add per record, and without the SLP vectoriser it does: 19 instead of 5 us per reduction)
   for (; w + U - 1 < w1; w += U) {
-    float v[U];
+    rec_t v[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) v[u] = r[(size_t)(w + u) * REC_FLOATS];
+    for (int u = 0; u < U; ++u) v[u] = r[(size_t)(w + u) * REC_ENTRIES];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int u = 0; u < U; ++u) a[u] += v[u];
+    for (int u = 0; u < U; ++u) a[u] += rec_unpack(v[u]);
   }
   {
-    float v[U];
+    rec_t v[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) v[u] = (w + u < w1) ? r[(size_t)(w + u) * REC_FLOATS] : 0.0f;   // the rest (< U records), issued together
+    for (int u = 0; u < U; ++u) v[u] = (w + u < w1) ? r[(size_t)(w + u) * REC_ENTRIES] : (rec_t)0;   // the rest (< U records), issued together
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int u = 0; u < U; ++u) a[u] += v[u];
+    for (int u = 0; u < U; ++u) a[u] += rec_unpack(v[u]);
   }
 #pragma unroll
   for (int st = U / 2; st >= 1; st >>= 1) {

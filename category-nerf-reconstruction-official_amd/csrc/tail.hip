@@ -13,7 +13,7 @@
 //     per-object bias-row sums, from a fixed-point table the field backward filled with integer atomics (order-free,
 //     hence still bitwise reproducible) instead of waiting for that reduction.
 // grid: [ do_latent ? NL latent blocks per class : 0 ] [ NA AdamW blocks over the flat (C, P) buffer, or with records
-//        NR = REC_FLOATS / TAIL_EPB reduce-and-update blocks per class ] [ C epilogue ].
+//        NR = REC_ENTRIES / TAIL_EPB reduce-and-update blocks per class ] [ C epilogue ].
 // With do_latent = 0 (the gradient was completed by cnr_latent_bwd, e.g. before a multi-GPU all-reduce) the AdamW
 // blocks cover every parameter and nothing else changes.
 #include "adamw_common.h"
@@ -37,7 +37,7 @@ struct TailArgs {
   int local_latent;   // latent blocks in the per-block form of latent_bwd_block_local (more than four objects, rows from the table)
   // optional: the field backward's per-workgroup records (nwg per class) are reduced HERE, and the per-object
   // bias-row sums come from the fixed-point table the field backward accumulated with integer atomics
-  const float* records; int nwg; const long long* rows_fix; int NR;
+  const cnr_rec::rec_t* records; int nwg; const long long* rows_fix; int NR;
   // grad_only: stop at the finished gradient (no AdamW, no epilogue blocks): the multi-GPU step all-reduces it first
   int grad_only;
   const int* n_obj_cls;  // optional (C,): objects each class really has (<= lay.n_obj; the rest of its rows are padding)
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
       if (q == 0 && owner && !a.grad_only) { p0 = a.theta_in[idx]; m0 = a.m[idx]; v0 = a.v[idx]; }   // in flight under the record sum
       if (owner) {
         const int per = (a.nwg + NQ - 1) / NQ, w0 = q * per, w1 = min(a.nwg, w0 + per);
-        const float* r = a.records + (size_t)c * a.nwg * cnr_rec::REC_FLOATS + i;
+        const cnr_rec::rec_t* r = a.records + (size_t)c * a.nwg * cnr_rec::REC_ENTRIES + i;
         if (cnr_rec::rec_entry_written(i, a.lay.n_obj)) s0 = cnr_rec::record_range_sum(r, w0, w1);
         if (i >= TRUNK) s1 = cnr_rec::record_range_sum(r + 63, w0, w1);
       }
@@ -407,7 +407,7 @@ extern "C" int cnr_step_tail(const cnr_step_tail_args* args, void* stream) {
   int64_t na = (n + 255) / 256;
   if (na > 2048) na = 2048;
   a.NA = (int)na;
-  a.records = (const float*)records; a.nwg = nwg; a.rows_fix = rows_fix; a.NR = cnr_rec::REC_FLOATS / cnr_rec::TAIL_EPB;
+  a.records = (const cnr_rec::rec_t*)records; a.nwg = nwg; a.rows_fix = rows_fix; a.NR = cnr_rec::REC_ENTRIES / cnr_rec::TAIL_EPB;
   a.clamp_flags = clamp_flags;
   const unsigned grid = (unsigned)((a.do_latent ? a.NL * C : 0) + (records ? a.NR * C : a.NA) + C);
   const size_t lds = tail_lds_bytes(a.do_latent, a.local_latent, L, n_obj);
@@ -438,7 +438,7 @@ extern "C" int cnr_step_grad(const float* theta, float* grad, int64_t class_stri
   if (a.NL > 256) a.NL = 256;
   a.local_latent = (n_obj >= CNR_LOCAL_MIN_OBJ && latent_local_ok(L, n_obj)) ? 1 : 0;
   if (a.local_latent) a.NL = latent_local_blocks(L, n_obj);
-  a.records = (const float*)records; a.nwg = nwg; a.rows_fix = rows_fix; a.NR = cnr_rec::REC_FLOATS / cnr_rec::TAIL_EPB;
+  a.records = (const cnr_rec::rec_t*)records; a.nwg = nwg; a.rows_fix = rows_fix; a.NR = cnr_rec::REC_ENTRIES / cnr_rec::TAIL_EPB;
   const unsigned grid = (unsigned)(a.NL * C + a.NR * C);
   if (n_obj > 32 && !a.local_latent) return CNR_E_SHAPE;
   const size_t lds = tail_lds_bytes(1, a.local_latent, L, n_obj);

@@ -481,7 +481,8 @@ int cnr_step_grad(const float* theta, float* grad, int64_t class_stride, int64_t
  * per-layer images behind a workgroup barrier -- eight waves, two per SIMD (csrc/fused_bwd_pipe8_kernel.h).  chain_waves must be
  * 4 (kept in the signature).  max_blocks: workgroups per class (0 = 256).  workspace: caller-allocated, 16-B aligned, contents
  * irrelevant, >= cnr_field_bwd_workspace_bytes(C, max_blocks) bytes: every workgroup stores one record of partial sums into it
- * with plain stores and a last small kernel sums the records in a fixed order -- no float atomic anywhere, bitwise reproducible.
+ * with plain stores -- 16 128 bf16 entries, each the workgroup's fp32 sum rounded once -- and a last small kernel sums the records
+ * in fp32, in a fixed order: no float atomic anywhere, bitwise reproducible.
  * packed_lo (optional): the residual image the FORWARD ran with (cnr_field_fwd / cnr_field_fwd_render, precise geometry branch):
  * the recompute then forms the same activations and ReLU masks as that forward -- without it the backward of a precise forward
  * would be the gradient of the plain-f16 function.

@@ -160,8 +160,8 @@ def test_argument_errors_are_return_codes(lib):
     assert lib.cnr_composite_fwd(None, None, None, None, None, None, None, None, 4, 8, 0, None) == -1
     assert lib.cnr_adamw_step(None, None, None, None, 10, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, 1.0, None, None) == -1
     assert lib.cnr_step_advance(None, 1, None) == -1
-    rec_floats = (13892 + 126 + 15 * 128 + 255) // 256 * 256     # trunk | two dB halves | up to 15 object rows x 128
-    assert lib.cnr_field_bwd_workspace_bytes(2, 0) == 2 * 256 * rec_floats * 4
+    rec_entries = (13892 + 126 + 15 * 128 + 255) // 256 * 256     # trunk | two dB halves | up to 15 object rows x 128
+    assert lib.cnr_field_bwd_workspace_bytes(2, 0) == 2 * 256 * rec_entries * 2       # bf16 entries
 
 
 def test_missing_library_fails_loudly(monkeypatch):

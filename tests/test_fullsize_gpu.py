@@ -229,11 +229,12 @@ def test_step_grad_and_tail_reduce_records_and_fixed_point_rows(cnr, dev, C, n_o
     args = (lay.total, lay.latW[0], lay.latb[0], lay.shape[0], lay.tex[0], L, n_obj, C)
     zl, br = torch.empty(C * n_obj, 4, 32, device=dev), torch.empty(C * n_obj, 4, 32, device=dev)
     _C.call("cnr_latent_fwd", theta, *args, zl, br)
-    rec_floats = _C.field_bwd_workspace_bytes(1, 1) // 4            # one record
+    rec_floats = _C.field_bwd_workspace_bytes(1, 1) // 2            # entries of one record (bf16 each since round 4)
     TR = 13892
-    recs = (torch.randn(C, nwg, rec_floats, generator=gen) * 1e-2).to(dev)
-    ws = torch.zeros(_C.field_bwd_workspace_bytes(C, nwg) // 4, device=dev)
-    ws[: recs.numel()] = recs.reshape(-1)
+    recs = (torch.randn(C, nwg, rec_floats, generator=gen) * 1e-2).to(torch.bfloat16)
+    ws = torch.zeros(_C.field_bwd_workspace_bytes(C, nwg) // 2, device=dev, dtype=torch.bfloat16)
+    ws[: recs.numel()] = recs.reshape(-1).to(dev)
+    recs = recs.float()                                              # (the expectation below sums exactly what the records hold)
     rows = torch.randn(C * n_obj, 4, 32, generator=gen, dtype=torch.float64) * 0.3
     parts = torch.rand(8, *rows.shape, generator=gen, dtype=torch.float64)
     parts = parts / parts.sum(0, keepdim=True) * rows                # eight addends per entry
@@ -259,7 +260,7 @@ def test_step_grad_and_tail_reduce_records_and_fixed_point_rows(cnr, dev, C, n_o
         obj = obj + reg * (torch.norm(v["shape"], dim=-1).sum() + torch.norm(v["tex"], dim=-1).sum())
     obj.backward()
     want = th.grad.clone()
-    rs = recs.double().sum(1)                                        # (C, rec_floats)
+    rs = recs.double().sum(1).to(want.device)                        # (C, rec_floats)
     wv = lay.views(want)
     trunk_rec = rs[:, :TR].clone()
     for off in (3840, 8736, 4896, 13281):                            # biases of the latent-conditioned layers: rows only

@@ -54,12 +54,14 @@ def test_ray_shards_add_up_to_the_single_gpu_step(cnr, dev, world):
             sl = slice(r * R, (r + 1) * R)
             for k in ("z", "pts", "gt_rgb", "gt_depth", "labels", "depth_mask", "ray_row"):
                 assert torch.equal(tr.bufs[k], one.bufs[k][:, sl]), (step, r, k)
-        # same parameters, same samples: the two gradients differ by fp32 summation order only
-        assert rel_l2(g, one.grad) < 2e-5, (step, rel_l2(g, one.grad))
+        # same parameters, same samples: the two gradients differ by fp32 summation order and -- since round 4 -- by the bf16
+        # rounding of the per-workgroup records, independent in every launch (2^-9 per entry over these shapes' 8 .. 32 records:
+        # measured 1.3e-3; 2e-5 with fp32 records).  Rank-local normalisation, the error this test exists for, is a 1 - 1/N effect.
+        assert rel_l2(g, one.grad) < 4e-3, (step, rel_l2(g, one.grad))
         assert rel_l2(sum(tr.losses for tr in ranks), one.losses) < 1e-5
         for tr in ranks:
             assert torch.equal(tr.theta, ranks[0].theta)    # replicas bitwise identical
-        assert rel_l2(ranks[0].theta, one.theta) < 3e-4, (step, rel_l2(ranks[0].theta, one.theta))
+        assert rel_l2(ranks[0].theta, one.theta) < 1e-3, (step, rel_l2(ranks[0].theta, one.theta))
         assert int(ranks[1].d_state[0]) == int(one.d_state[0]) + R
 
 

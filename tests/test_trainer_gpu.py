@@ -479,7 +479,10 @@ def test_one_launch_step_equals_forward_render_plus_backward(cnr, dev, C, R, n1,
     16 / 32 / 64 / 128 sample slots (dead lanes; two 16-slot rays per tile for S <= 16).
     Both modes run ONE arithmetic end to end on either path -- the stand-alone backward takes the residual image and recomputes the
     precise forward's activations and ReLU masks (round 4; before, it recomputed plain f16 and the bar for the default mode had to
-    be 2e-2) -- so the gradient bar is 3e-4 for plain_f16 and precise_geometry alike."""
+    be 2e-2) -- so one gradient bar serves plain_f16 and precise_geometry alike.  It is 4e-3, not the 3e-4 the arithmetic alone
+    would hold (measured 1e-5 .. 1.2e-4 with fp32 records): the two paths leave their partial sums in per-workgroup records whose
+    entries are bf16 since round 4 (2^-9 each, independent in the two launches; these small shapes have 1 .. 32 records, where
+    configs[1] has 256) -- measured 4e-4 .. 2.2e-3.  A mis-indexed row or a dropped layer is a 1e-1 effect."""
     res = {}
     for name, one in (("two", False), ("one", True)):
         cfg = cnr.cfg.synthetic_config(device=str(dev), latent_dim=L, n_bins_cam2surface=n1, n_bins=n2)
@@ -511,7 +514,7 @@ def test_one_launch_step_equals_forward_render_plus_backward(cnr, dev, C, R, n1,
     if noise:
         assert float(a["grad"].double().norm()) < 1e-3       # ... i.e. both negligible
     else:
-        assert rel_l2(a["grad"], b["grad"]) < 3e-4, rel_l2(a["grad"], b["grad"])
+        assert rel_l2(a["grad"], b["grad"]) < 4e-3, rel_l2(a["grad"], b["grad"])
         assert rel_l2(a["theta"], b["theta"]) < 1e-3     # first AdamW step: +-lr per entry, the sign of a ~0 gradient entry is noise
     for s in range(3):   # still the same training run two steps later (AdamW's sign-like first steps amplify rounding)
         assert torch.isfinite(res["one"][s]["grad"]).all()
