@@ -135,10 +135,7 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
   // lane as f16 through LDS that is free at that point (the E2 image after step VD, three slot images after step XYZ); the
   // partner needs a barrier between its reads and the chain wave's next writes there, which the composite exchange of rays
   // that span tiles (KR > 1) provides.  Measured bound (PE backward deleted): 40.4 -> 36.9 us at 2048 x 64, 259 -> 228 at 8192 x 128.
-#ifndef CNR_PEDW
-#define CNR_PEDW 1   // 0: tools/exp A/B arm (PE backward on the chain wave, as for KR <= 1)
-#endif
-  constexpr bool PEDW = CNR_PEDW && KR > 1;
+  constexpr bool PEDW = KR > 1;
   constexpr int SP = TWO ? 16 : (KR > 0 ? 32 * KR : 32);   // padded sample slots per ray (one-launch form)
   constexpr int NCHW = NCH, NTHR = (NCH + NDW) * 64, NACC = 5, LI_RS = local8<NDW>(BK_RS), LI_RS2 = local8<NDW>(BK_RS2);
   constexpr int RS_ROWS = WIDE == 2 ? cnr_rec::ROWS_MAX : WIDE == 1 ? 7 : 4;  // most object rows this instance takes (WIDE = 3: unused)
@@ -1034,12 +1031,10 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
         };
 #pragma unroll
         for (int w = 0; w < NCHW; ++w) load_tile(w);
-#ifndef CNR_P8_NO_SCHED_BARRIER
         // every read of the step is in flight before the first MFMA: left alone, the scheduler sinks the later tiles' reads
         // between the MFMAs (fewer live registers, which this role has to spare) and the wave then waits out one LDS
         // latency per tile instead of one per step
         __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
         for (int w = 0; w < NCHW; ++w) {
           if constexpr (OWN0) mma_blk(w, IC<K0>{}, IC<SL0>{});

@@ -191,29 +191,12 @@ __device__ __forceinline__ void pe_slots(const float (&Bh)[33], float t0, float 
   for (int d = 0; d < 11; ++d) {
     const float p = Bh[3 * d] * t0 + Bh[3 * d + 1] * t1 + Bh[3 * d + 2] * t2;
     // sin(pi 2^b p) = v_sin(2^(b-1) p)  (hardware sine takes revolutions)
-#ifdef CNR_PE_RECURRENCE
-    // A/B arm only (tools/exp/build_variant.sh ... -DCNR_PE_RECURRENCE): band 0 from the hardware sine / cosine, bands 1..5 by
-    // the double-angle recurrence s' = 2 s c, c' = 1 - 2 s^2 (three full-rate operations per band against one quarter-rate
-    // sine + its argument product).  Measured and not kept: DESIGN.md section 3.2.1.
-    float s = __builtin_amdgcn_sinf(p * 0.5f), cs = __builtin_amdgcn_cosf(p * 0.5f);
-    v[d] = s;
-#pragma unroll
-    for (int b = 1; b < 6; ++b) {
-      const float u = s + s;
-      const float s2 = u * cs;
-      if (b < 5) cs = __builtin_fmaf(-u, s, 1.0f);
-      s = s2;
-      const int q = b < 4 ? 11 * b + d : 48 + 11 * (b - 4) + d;
-      v[q] = s;
-    }
-#else
 #pragma unroll
     for (int b = 0; b < 6; ++b) {
       const float arg = p * (0.5f * (float)(1 << b));
       const int q = b < 4 ? 11 * b + d : 48 + 11 * (b - 4) + d;
       v[q] = __builtin_amdgcn_sinf(arg);
     }
-#endif
   }
   const float one = (ONES && h == 0) ? 1.0f : 0.0f;
   v[44] = h == 0 ? t0 : 0.0f; v[45] = h == 0 ? t1 : 0.0f; v[46] = h == 0 ? t2 : 0.0f; v[47] = one;

@@ -729,7 +729,7 @@ extern "C" int cnr_field_fwd(const float* pts, const float* B, const void* packe
   const int64_t N = (int64_t)R * S;
   const int64_t ntiles = (N + 31) / 32;
   int64_t blocks = (ntiles + 3) / 4;
-  static const int64_t cap = getenv("CNR_FWD_BLOCKS") ? atoll(getenv("CNR_FWD_BLOCKS")) : 2048;
+  const int64_t cap = 2048;     // workgroups per class (grid-stride over tiles beyond)
   if (blocks > cap) blocks = cap;
   const size_t lds = packed_lo ? (size_t)LDS_LO_OFF + fz::PK_LO_BYTES
                                : (size_t)fz::PK_OFF_BWD + 66 * sizeof(float) + 8;

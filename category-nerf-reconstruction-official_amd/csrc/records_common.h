@@ -25,10 +25,7 @@ typedef unsigned short rec_t;
 __device__ __forceinline__ rec_t rec_pack(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }   // v_cvt_pk_bf16_f32: RNE
 __device__ __forceinline__ float rec_unpack(rec_t b) { return __builtin_bit_cast(float, (unsigned int)b << 16); }
 constexpr double ROWS_FIX_SCALE = 1099511627776.0;  // 2^40: bias-row sums as int64 fixed point (order-free atomics)
-#ifndef CNR_TAIL_EPB
-#define CNR_TAIL_EPB 64
-#endif
-constexpr int TAIL_EPB = CNR_TAIL_EPB;  // record entries per reducing block of the tail launch (256 / TAIL_EPB sub-ranges each)
+constexpr int TAIL_EPB = 64;  // record entries per reducing block of the tail launch (256 / TAIL_EPB sub-ranges each; 32 and 16 measured slower)
 constexpr int ROWS_FIX_COPIES = 8;  // the table is replicated: a workgroup adds into copy (its index & 7), which
                                     // cuts the same-address atomic queue 8-fold; consumers add the copies (exact)
 

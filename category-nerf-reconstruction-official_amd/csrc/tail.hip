@@ -344,6 +344,7 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
 }
 }  // namespace
 
+constexpr int LOCAL_MIN_OBJ = 5;   // classes of up to four objects take the one-trip latent blocks (latent_bwd_block_1trip)
 // dynamic LDS of a tail block: the reducing blocks' three partial arrays (768 floats), the general latent blocks' two whole
 // (n_obj, 4, 32) tables + norms, or the per-block form's own rows (latent_local_lds_floats) -- which is what lets a class hold up to
 // ROWS_TILE_MAX objects: 100 objects need 29 KB there, where the whole tables would need 103 KB and one block per CU
@@ -398,10 +399,7 @@ extern "C" int cnr_step_tail(const cnr_step_tail_args* args, void* stream) {
   const int64_t nlat_out = (int64_t)4 * 32 * L + 128 + (int64_t)2 * n_obj * L;
   a.NL = (int)((nlat_out + 255) / 256);
   if (a.NL > 256) a.NL = 256;
-#ifndef CNR_LOCAL_MIN_OBJ
-#define CNR_LOCAL_MIN_OBJ 5    // (tools/exp A/B: 1 = the per-block form for every class)
-#endif
-  a.local_latent = (do_latent && rows_fix && n_obj >= CNR_LOCAL_MIN_OBJ && latent_local_ok(L, n_obj)) ? 1 : 0;
+  a.local_latent = (do_latent && rows_fix && n_obj >= LOCAL_MIN_OBJ && latent_local_ok(L, n_obj)) ? 1 : 0;
   if (a.local_latent) a.NL = latent_local_blocks(L, n_obj);
   const int64_t n = (int64_t)C * class_stride;
   int64_t na = (n + 255) / 256;
@@ -436,7 +434,7 @@ extern "C" int cnr_step_grad(const float* theta, float* grad, int64_t class_stri
   const int64_t nlat_out = (int64_t)4 * 32 * L + 128 + (int64_t)2 * n_obj * L;
   a.NL = (int)((nlat_out + 255) / 256);
   if (a.NL > 256) a.NL = 256;
-  a.local_latent = (n_obj >= CNR_LOCAL_MIN_OBJ && latent_local_ok(L, n_obj)) ? 1 : 0;
+  a.local_latent = (n_obj >= LOCAL_MIN_OBJ && latent_local_ok(L, n_obj)) ? 1 : 0;
   if (a.local_latent) a.NL = latent_local_blocks(L, n_obj);
   a.records = (const cnr_rec::rec_t*)records; a.nwg = nwg; a.rows_fix = rows_fix; a.NR = cnr_rec::REC_ENTRIES / cnr_rec::TAIL_EPB;
   const unsigned grid = (unsigned)(a.NL * C + a.NR * C);

@@ -1,10 +1,10 @@
-"""A/B of two library builds on ONE box: CNR_HIP_LIB=<lib> python tools/exp/ab_step.py [R S [C [n_obj]]] prints the one-launch kernel's
+"""A/B of two library builds on ONE box: CNR_HIP_LIB=<lib> python tools/ab_step.py [R S [C [n_obj]]] prints the one-launch kernel's
 back-to-back time and the graph step time (medians of 5 x 400 steps)."""
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import cnr_amd

@@ -2,7 +2,7 @@
 # SQ counters of the fused background kernels (GPU box, repo root)
 root=$PWD
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS --output-format csv -d $root/gpurun_out/pmc_bg -o p -- python3 $root/tools/exp/time_bg.py fused > $root/gpurun_out/pmc_bg.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS --output-format csv -d $root/gpurun_out/pmc_bg -o p -- python3 $root/tools/time_bg.py fused > $root/gpurun_out/pmc_bg.log 2>&1
 cd $root
 python3 - <<'PY'
 import csv, collections, glob

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Instruction mix and LDS conflicts of the one-launch step kernel (two PMC passes, kernel-trace off): run on the GPU box from the repo
-# root; summary to stdout.  usage: tools/exp/pmc_mix.sh [R S]
+# root; summary to stdout.  usage: tools/pmc_mix.sh [R S]
 R=${1:-2048}; S=${2:-64}; root=$PWD; out=$root/gpurun_out/pmc_mix_${R}x${S}; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $out/a -o p -- python3 $root/tools/prof_one.py $R $S train > $out/a.log 2>&1

@@ -4,7 +4,7 @@ tag=${1:-bg}; shift
 root=$PWD
 for kv in "$@"; do export "$kv"; done
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $root/gpurun_out/prof_$tag --output-format csv -- python3 $root/tools/exp/time_bg.py fused > $root/gpurun_out/prof_$tag.log 2>&1
+rocprofv3 --kernel-trace --stats -d $root/gpurun_out/prof_$tag --output-format csv -- python3 $root/tools/time_bg.py fused > $root/gpurun_out/prof_$tag.log 2>&1
 cd $root
 f=$(ls gpurun_out/prof_$tag/*/*kernel_stats.csv | head -1)
 python3 - "$f" <<'PY'

@@ -1,4 +1,5 @@
-"""Launch each fused kernel a few times for rocprofv3 --kernel-trace / --pmc (backward variant: CNR_FIELD_BWD)."""
+"""Launch the fused kernels a few times for rocprofv3 --kernel-trace / --pmc: `prof_one.py R S train` = ten eager steps of the
+trainer (cnr_step_prologue | cnr_field_train | cnr_step_tail); `prof_one.py R S [blocks]` = the stand-alone forward and backward."""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -31,7 +32,7 @@ ray_row = (torch.randint(0, n_obj, (C, R), device=dev) + torch.arange(C, device=
 dsig = torch.randn(C, R, S, device=dev) * 1e-3
 drgb = torch.randn(C, R, S, 3, device=dev) * 1e-3
 dtrunk = torch.zeros(C, 13892, device=dev); dB = torch.zeros(C, 21, 3, device=dev); dbr = torch.zeros_like(brows)
-wsp = torch.empty(_C.field_bwd_workspace_bytes(C, 0, C * n_obj), device=dev, dtype=torch.uint8)
+wsp = torch.empty(_C.field_bwd_workspace_bytes(C, 0), device=dev, dtype=torch.uint8)
 sig = torch.empty(C, R, S, device=dev); rgb = torch.empty(C, R, S, 3, device=dev)
 for _ in range(10):
     _C.call("cnr_field_fwd", pts, B, packed, brows, ray_row, 2.0, sig, rgb, C, R, S, 0, None)

@@ -1,6 +1,6 @@
-"""Step / kernel time of the fused trainer at one shape: python tools/exp/quick_step.py [R S n_obj precise]"""
+"""Step / kernel time of the fused trainer at one shape: python tools/quick_step.py [R S n_obj precise]"""
 import sys, os, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import cnr_amd
 R, S, n_obj, precise = (int(v) for v in (sys.argv[1:5] + ["2048", "64", "4", "1"][len(sys.argv) - 1:]))
 dev = torch.device("cuda:0")

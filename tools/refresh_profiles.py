@@ -1,8 +1,8 @@
-"""Copy the judged summaries of a tools/collect_round.sh run (gpurun_out/<name>) into profiles/<round>_* (round tag: second
-argument, default r02)."""
+"""Copy the judged summaries of a tools/collect_round.sh run (gpurun_out/<tag>) into profiles/<round>_* :
+    python tools/refresh_profiles.py gpurun_out/<tag> r04"""
 import csv, json, os, subprocess, sys
 src = sys.argv[1]
-RND = sys.argv[2] if len(sys.argv) > 2 else "r02"
+RND = sys.argv[2] if len(sys.argv) > 2 else "r04"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
 open(os.path.join(P, RND + "_bench_2048x64.json"), "w").write(open(f"{src}/bench.json").read().strip().splitlines()[-1] + "\n")
@@ -31,5 +31,15 @@ if key in call:
 sq = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools/pmc_sq_summary.py"),
                               f"{src}/pmc_sq_2048x64/p_counter_collection.csv", f"{src}/pmc_sq_8192x128/p_counter_collection.csv"])
 open(os.path.join(P, RND + "_pmc_sq_mfma_busy.json"), "wb").write(sq)
-subprocess.check_call(["cp", f"{src}/bench_kernels.log", os.path.join(P, RND + "_bench_kernels.txt")])
+for name, dst in (("pmc_mix_2048x64.txt", "_pmc_instruction_mix.txt"), ("pmc_mix_8192x128.txt", "_pmc_instruction_mix_8192x128.txt"),
+                  ("bg_kernels.txt", "_bg_step_kernels.txt"), ("bg_pmc.txt", "_bg_step_pmc_sq.txt"),
+                  ("full_iteration.txt", "_full_iteration.txt"), ("steps.txt", "_step_times_by_shape.txt"),
+                  ("bench_c16.json", "_bench_c16_2048x64.json"), ("bench_8192x128.json", "_bench_8192x128.json"),
+                  ("bench_c8_4096x128_l32.json", "_bench_c8_4096x128_l32.json"), ("pytest_gpu.log", "_pytest_gpu_tail.txt")):
+    f = f"{src}/{name}"
+    if os.path.exists(f):
+        txt = open(f).read()
+        if name == "pytest_gpu.log":
+            txt = "\n".join(txt.strip().splitlines()[-3:]) + "\n"
+        open(os.path.join(P, RND + dst), "w").write(txt)
 print("profiles refreshed from", src)

@@ -1,11 +1,11 @@
 """Cycle stamps of the one-launch step body (cnr_field_train) inside a real trainer step; build the stamped library with
-tools/exp/build_timed_lib.sh and run with CNR_HIP_LIB pointing at it.  Prints, per wave of workgroup 0 (its last iteration):
+tools/build_timed_lib.sh and run with CNR_HIP_LIB pointing at it.  Prints, per wave of workgroup 0 (its last iteration):
 work between barriers and wait at barriers."""
 import ctypes
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import cnr_amd

@@ -1,12 +1,12 @@
-"""Which block type of tail_kernel finishes last?  Needs tools/exp/libs/libcnr_stamps.so = the library with tail.hip
+"""Which block type of tail_kernel finishes last?  Needs tools/libs/libcnr_stamps.so = the library with tail.hip
 compiled with -DCNR_TAIL_STAMPS (earliest start / latest end per block type, 100 MHz realtime counter)."""
 import sys, os, ctypes
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import cnr_amd
 from cnr_amd import _C
-_C.LIB_PATH = os.path.join(ROOT, "tools/exp/libs/libcnr_stamps.so")
+_C.LIB_PATH = os.path.join(ROOT, "tools/libs/libcnr_stamps.so")
 dev = torch.device("cuda:0")
 C, R, S, L, n_obj = 1, 2048, 64, 256, int(sys.argv[1]) if len(sys.argv) > 1 else 4
 cfg = cnr_amd.cfg.synthetic_config(device=str(dev), latent_dim=L, obj_scale=2.0, n_bins_cam2surface=S // 8, n_bins=S - S // 8)

@@ -1,6 +1,6 @@
-"""Background step timing: python tools/exp/time_bg.py [precision] -> per-step time (graph replay) and per-kernel HIP-event times"""
+"""Background step timing: python tools/time_bg.py [precision] -> per-step time (graph replay) and per-kernel HIP-event times"""
 import sys, os, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import cnr_amd
 prec = sys.argv[1] if len(sys.argv) > 1 else "fused"
 dev = torch.device("cuda:0")

@@ -1,6 +1,6 @@
-"""Whole iteration (background + one category) timing: python tools/exp/time_full.py [concurrent 0/1] [R S]"""
+"""Whole iteration (background + one category) timing: python tools/time_full.py [concurrent 0/1] [R S]"""
 import sys, os, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import cnr_amd
 conc = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 R, S = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (2048, 64)
