@@ -422,7 +422,9 @@ def main():
                          "(there is no fp8 train step: see DESIGN.md section 3.4); prints its own JSON line")
     ap.add_argument("--bwd-blocks", type=int, default=0)
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--unroll", type=int, default=16, help="train steps per hipGraph launch (2 = one graph launch per two steps)")
+    ap.add_argument("--unroll", type=int, default=0,
+                    help="train steps per hipGraph launch (2 = one graph launch per two steps); 0 = --steps rounded to even, within "
+                         "[16, 32]: a 20-step region then goes out as ONE launch (between two launches the GPU idles ~8 us)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -438,6 +440,8 @@ def main():
 
     if args.dtype == "fp8":
         return fp8_leg(args)
+    if args.unroll <= 0:
+        args.unroll = min(32, max(16, args.steps // 2 * 2))
     # ---- N ranks: --gpus N is what decides; the launcher's environment must agree ---------------------------------
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")

@@ -47,6 +47,11 @@ __device__ long long g_pipe8_stamps[8 * 64];
 #define P8ITER_DECL() do {} while (0)
 #endif
 #define P8SYNC() do { P8STAMP(); role_barrier(); P8STAMP(); } while (0)
+#ifdef CNR_ISA_MARKS  // tools/isa_mix.py --phases: named comments in the assembly (hipcc --save-temps -DCNR_ISA_MARKS), no instruction
+#define P8ISA(name) asm volatile("; CNRMARK " name)
+#else
+#define P8ISA(name) do {} while (0)
+#endif
 // LDS layout of the 8-wave kernel, by instantiation (WIDE = which row-sum form, GEO = precise geometry branch):
 //   [ packed image PK_BYTES | GEO: residual fragments PK_LO_BYTES | B rows 272 | bias rows of the class | 4 chain waves | exchange ]
 // A class's bias rows (512 B per object row) sit in LDS except in the one instantiation where the budget is spent
@@ -230,11 +235,20 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
       pd[d] = Blh[3 * d] * t0x + Blh[3 * d + 1] * t1x + Blh[3 * d + 2] * t2x;
       gpa[d] = 0.0f;
     }
+    // cos(pi 2^b p) for the six bands from ONE hardware cosine per direction and the double-angle recurrence c' = 2 c^2 - 1: two
+    // full-rate operations per band instead of an argument product and a quarter-rate v_cos (the recurrence doubles the error per
+    // band: 32 x the hardware cosine's 1e-6 at band 5, three orders under the f16 gradient it multiplies).  The band's factor
+    // pi 2^b rides on the cosine, the f16 gradient enters the multiply-add directly (v_fma_mix_f32): four instructions per
+    // (band, direction) where the plain form had eight issue slots.
 #pragma unroll
-    for (int q = 0; q < 66; ++q) {   // q < 44: d e1 (bands 0..3), then d e2 (bands 4, 5); 11 directions of this lane half per band
-      const int band = q / 11, d = q % 11, k = q < 44 ? q : 48 + (q - 44);
-      const float cs = __builtin_amdgcn_cosf(pd[d] * (0.5f * (float)(1 << band)));
-      gpa[d] = fmaf((float)dq[k >> 3][k & 7] * cs, 3.14159265358979f * (float)(1 << band), gpa[d]);
+    for (int d = 0; d < 11; ++d) {
+      float cs = __builtin_amdgcn_cosf(pd[d] * 0.5f);
+#pragma unroll
+      for (int band = 0; band < 6; ++band) {
+        const int q = 11 * band + d, k = q < 44 ? q : 48 + (q - 44);   // q < 44: d e1 (bands 0..3), then d e2 (bands 4, 5)
+        gpa[d] = fmaf((float)dq[k >> 3][k & 7], cs * (3.14159265358979f * (float)(1 << band)), gpa[d]);
+        if (band < 5) cs = fmaf(cs + cs, cs, -1.0f);
+      }
     }
 #pragma unroll
     for (int d = 0; d < 11; ++d) {
@@ -385,16 +399,16 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
           pd[d] = Bl_h[3 * d] * t0x + Bl_h[3 * d + 1] * t1x + Bl_h[3 * d + 2] * t2x;
           gpa[d] = 0.0f;
         }
+        // (the cosines as in pe_backward_h: one hardware cosine per direction at the first band of the call, double-angle upward)
 #pragma unroll
-        for (int b = 0; b < 3; ++b) {
-          if (b >= nblk) continue;
+        for (int d = 0; d < 11; ++d) {
+          float cs = __builtin_amdgcn_cosf(pd[d] * (0.5f * (float)(1 << band0)));
 #pragma unroll
-          for (int reg = 0; reg < 16; ++reg) {
-            const int q = 16 * b + reg;
-            if (q < nq) {
-              const int band = band0 + q / 11, d = q % 11;
-              const float cs = __builtin_amdgcn_cosf(pd[d] * (0.5f * (float)(1 << band)));
-              gpa[d] = fmaf(de[b][reg] * cs, 3.14159265358979f * (float)(1 << band), gpa[d]);
+          for (int bb = 0; bb < 4; ++bb) {
+            const int q = 11 * bb + d;
+            if (q < nq && (q >> 4) < nblk) {
+              gpa[d] = fmaf(de[q >> 4][q & 15], cs * (3.14159265358979f * (float)(1 << (band0 + bb))), gpa[d]);
+              cs = fmaf(cs + cs, cs, -1.0f);
             }
           }
         }
@@ -415,6 +429,7 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
         for (int i = 0; i < 33; ++i) Bh[i] = Bl_h[i];
         pe_slots<true, GEO>(Bh, t0x, t1x, t2x, h, E1f, E2f, E1l);
       }
+      P8ISA("pe_forward_done");
       // GEO: a geometry layer is three products per fragment, Wh xh + Wl xh + Wh xl (fused_common.h): wl = the residual
       // fragments, X*l = the residual of the layer input, formed from the fp32 accumulators while the first products run
       const unsigned char* lo_w = smem + l8_lo();
@@ -487,6 +502,7 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
         }
         return o;
       };
+      P8ISA("xyz_and_cat_e1_done");
       wq[0] = lds_frag(smem, KK_S1 + 0, lane); wq[1] = lds_frag(smem, KK_S1 + 1, lane);
       if constexpr (GEO) { wl[0] = lds_frag(lo_w, KK_S1 + 0, lane); wl[1] = lds_frag(lo_w, KK_S1 + 1, lane); }
       bq = acc_init(brow_l + 0 * 32, h);
@@ -506,6 +522,7 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
       bq = acc_init(cf + CF_B_ES, h);
       const h8 A3a = pack8(acc, 0, true), A3b = pack8(acc, 1, true);
       acc = hidden(A3a, A3b, acc, true, bq);
+      P8ISA("geometry_hidden_layers_done");
 #pragma unroll
       for (int s = 0; s < 5; ++s) wq[s] = lds_frag(smem, KK_VD + s, lane);
       bq = acc_init(cf + CF_B_VD, h);
@@ -540,6 +557,7 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
         const float dzl = cur.z - c_ml;
         c_M2 = seg_total<TWO>(seg_scan_add<TWO>(c_tl * dzl * dzl), lane);
       }
+      P8ISA("sigma_head_and_sigma_half_of_composite_done");
       const h8 Y4a = pack8(acc, 0, false), Y4b = pack8(acc, 1, false);
       acc = MFMA(wq[0], Y4a, bq);
       acc = MFMA(wq[1], Y4b, acc);
@@ -563,6 +581,7 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
       h8 Wn0 = lds_frag(bwf, KT_R0, lane), Wn1;
 
       P8MARK(7);
+      P8ISA("colour_branch_done");
       // rgb = sigmoid(logits in rows 0..2 = registers 0..2 of lane half 0)
       // (v_rcp_f32, 1 ulp, instead of an IEEE division: ten dependent instructions less per quotient, and this stretch of
       //  the iteration runs as one dependent chain with the SIMD's other wave idle)
@@ -619,6 +638,7 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
           for (int t = 0; t < KR; ++t) carry = t == tin ? cpre[t] : carry;
         }
         P8MARK(0);
+        P8ISA("composite_exchange_done");
         const float mean = so > 0.0f ? sd * __builtin_amdgcn_rcpf(so) : 0.0f;
         if constexpr (KR > 1) {
           float M2 = 0.0f;
@@ -661,6 +681,7 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
         const float dBl = ta.loss_scale * ta.color_scaling * sgn(rc2) * fo * wc_c;
         const float dO = ta.loss_scale * ta.opacity_scaling * sgn(ro) * fs * wo_c;
         P8MARK(2);
+        P8ISA("loss_gradient_scalars_done");
         // composite backward: d occ_i = T_i g_i - (sum_{j > i} term_j g_j) / f_i.  The sum over LATER tiles needs no second
         // exchange: a tile's total of term g is linear in the five ray-level factors, c_t (dD d_t + dR r_t + .. + dO w_t)
         float suf_carry = 0.0f;
@@ -688,6 +709,7 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
         DBS += (h == 0) ? draw : 0.0f;
       }
       P8MARK(5);
+      P8ISA("composite_backward_done");
       // ---- step R2: dPre9 = drgb * rgb (1 - rgb) in rows 0..2 (registers 0..2 of half 0)
       h8 D0 = zero8(), D1 = zero8();
       {
