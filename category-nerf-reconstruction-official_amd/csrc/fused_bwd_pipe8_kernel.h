@@ -165,17 +165,24 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
   // operands of the class -> LDS (weight fragments + constants, direction matrix, bias rows), by every thread.  Called inside the
   // role branches: the chain waves first put their own first global requests in flight (first tile's inputs, step state),
   // whose round trips then run under this copy instead of after it (~2 us of every workgroup at 2048 x 64)
-  auto copy_operands = [&]() {
+  // SPLIT (rays that span tiles, KR > 1): the transposed (backward) fragments -- 30 of the 81 KB, first needed ~9 k cycles into
+  // the first iteration -- are brought in by the dW waves alone, AFTER the workgroup barrier that releases the chain waves into
+  // their first forward (the dW waves idle through it); the iteration's composite-exchange barrier, which both roles pass before
+  // a chain wave's first read of a transposed fragment, orders the two.  Stamped at 2048 x 64: the copy was 5.4 k of a
+  // workgroup's 100 k cycles.
+  constexpr bool SPLIT_COPY = KR > 1;
+  auto copy_operands = [&](auto&& under_the_loads) {
     // 61 KB (+ 20 KB of residual fragments) per workgroup: EVERY 16-byte load of a thread is issued before its first LDS store
     // (one memory round trip; written as a load -> store loop the copy was eight dependent round trips: 7.5 k cycles of every
-    // workgroup, stamped)
-    constexpr int NV = (PK_BYTES / 16 + NTHR - 1) / NTHR, NVL = GEO ? (PK_LO_BYTES / 16 + NTHR - 1) / NTHR : 0;
+    // workgroup, stamped).  under_the_loads(): the caller's own dependent requests, issued while these are in flight.
+    constexpr int FIRST = SPLIT_COPY ? PK_OFF_BWD : PK_BYTES;     // bytes of the packed image every thread helps copy
+    constexpr int NV = (FIRST / 16 + NTHR - 1) / NTHR, NVL = GEO ? (PK_LO_BYTES / 16 + NTHR - 1) / NTHR : 0;
     const f4* src = reinterpret_cast<const f4*>(packed + (size_t)c * PK_BYTES);
     f4 v[NV], vl[NVL > 0 ? NVL : 1];
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
       const int i = threadIdx.x + k * NTHR;
-      v[k] = i < PK_BYTES / 16 ? src[i] : f4{0.f, 0.f, 0.f, 0.f};
+      v[k] = i < FIRST / 16 ? src[i] : f4{0.f, 0.f, 0.f, 0.f};
     }
     if constexpr (GEO) {   // residual fragments of the geometry branch behind the packed image
       const f4* lsrc = reinterpret_cast<const f4*>(packed_lo + (size_t)c * PK_LO_BYTES);
@@ -194,11 +201,12 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
       float* br = reinterpret_cast<float*>(smem + L8_BR);  // host guarantees 1 <= rows_per_class <= RS_ROWS
       for (int i = threadIdx.x; i < rows_per_class * 128; i += NTHR) br[i] = biasrows[(size_t)c * rows_per_class * 128 + i];
     }
+    under_the_loads();
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
       const int i = threadIdx.x + k * NTHR;
-      if (i < PK_BYTES / 16) reinterpret_cast<f4*>(smem)[i] = v[k];
+      if (i < FIRST / 16) reinterpret_cast<f4*>(smem)[i] = v[k];
     }
     if constexpr (GEO) {
 #pragma unroll
@@ -209,6 +217,24 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
     }
     __syncthreads();
     P8PHASE(1);
+  };
+  // (dW waves, SPLIT_COPY: the transposed fragments, behind the barrier above)
+  auto copy_transposed = [&]() {
+    constexpr int NDT = NDW * 64, NB = ((PK_BYTES - PK_OFF_BWD) / 16 + NDT - 1) / NDT;
+    const f4* src = reinterpret_cast<const f4*>(packed + (size_t)c * PK_BYTES + PK_OFF_BWD);
+    const int t = threadIdx.x - NCH * 64;
+    f4 v[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      const int i = t + k * NDT;
+      v[k] = i < (PK_BYTES - PK_OFF_BWD) / 16 ? src[i] : f4{0.f, 0.f, 0.f, 0.f};
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      const int i = t + k * NDT;
+      if (i < (PK_BYTES - PK_OFF_BWD) / 16) reinterpret_cast<f4*>(smem + PK_OFF_BWD)[i] = v[k];
+    }
   };
   const float* cf = reinterpret_cast<const float*>(smem + PK_OFF_CONST);
   const unsigned char* bwf = smem + PK_OFF_BWD;
@@ -351,17 +377,25 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
     TileIn cur = fetch(blockIdx.x * NCHW + wv), nxt = cur;     // in flight under the operand copy
     int64_t cursor0 = 0;
     if constexpr (KR > 0) cursor0 = ta.d_state ? ta.d_state[0] : 0;
-    copy_operands();
-    // ---- one-launch step: this class's loss weights from the epoch's mask-count table, loss partial sums ------------
+    // ---- one-launch step: this class's loss weights from the epoch's mask-count table.  The entry's address depends on the
+    // cursor (requested above): its six loads go out while the operand copy's are in flight, not behind the copy's barrier (a
+    // dependent round trip of ~2.5 k cycles in front of every workgroup's first tile, stamped)
+    float tbv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    copy_operands([&]() {
+      if constexpr (KR > 0) {
+        const int Cn = gridDim.y;
+        const float* tb = ta.counts_tab + (size_t)(cursor0 / R) * (size_t)(Cn + 1) * 4;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { tbv[k] = tb[Cn * 4 + k]; tbv[3 + k] = tb[c * 4 + k]; }
+      }
+    });
     float wd_c = 0.f, wc_c = 0.f, wo_c = 0.f, ld_acc = 0.f, lc_acc = 0.f, lo_acc = 0.f;
     int tab_flags = 0;
     if constexpr (KR > 0) {
-      const int Cn = gridDim.y;
-      const float* tb = ta.counts_tab + (size_t)(cursor0 / R) * (size_t)(Cn + 1) * 4;
-      const bool e_d = tb[Cn * 4 + 0] != 0.f, e_c = tb[Cn * 4 + 1] != 0.f, e_o = tb[Cn * 4 + 2] != 0.f;
-      wd_c = e_d ? 0.f : 1.0f / (tb[c * 4 + 0] + 1e-10f);
-      wc_c = e_c ? 0.f : 1.0f / (tb[c * 4 + 1] + 1e-10f);
-      wo_c = e_o ? 0.f : 1.0f / (tb[c * 4 + 2] + 1e-10f);
+      const bool e_d = tbv[0] != 0.f, e_c = tbv[1] != 0.f, e_o = tbv[2] != 0.f;
+      wd_c = e_d ? 0.f : 1.0f / (tbv[3] + 1e-10f);
+      wc_c = e_c ? 0.f : 1.0f / (tbv[4] + 1e-10f);
+      wo_c = e_o ? 0.f : 1.0f / (tbv[5] + 1e-10f);
       tab_flags = (e_d ? 2 : 0) | (e_c ? 4 : 0) | (e_o ? 8 : 0);
     }
     float* xch = reinterpret_cast<float*>(smem + l8_xch(NCH, WIDE, GEO));   // [4][8]
@@ -574,11 +608,12 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
       acc = MFMA(wq[0], A6a, bq);
       acc = MFMA(wq[1], A6b, acc);
       wq[0] = lds_frag(smem, KK_R2, lane);
-      wq[1] = lds_frag(bwf, KT_R2, lane);
+      if constexpr (!SPLIT_COPY) wq[1] = lds_frag(bwf, KT_R2, lane);
       bq = acc_init(cf + CF_B_R2, h);
       const h8 A7a = pack8(acc, 0, true);
       acc = MFMA(wq[0], A7a, bq);
-      h8 Wn0 = lds_frag(bwf, KT_R0, lane), Wn1;
+      h8 Wn0, Wn1;
+      if constexpr (!SPLIT_COPY) Wn0 = lds_frag(bwf, KT_R0, lane);   // (SPLIT_COPY: behind the exchange barrier, see copy_operands)
 
       P8MARK(7);
       P8ISA("colour_branch_done");
@@ -618,6 +653,10 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
             x[0] = f4{Pt, w_l, d_l, r_l}; x[1] = f4{g_l, b_l, M2_l, m_l};
           }
           P8SYNC();
+          if constexpr (SPLIT_COPY) {   // the first transposed fragments of the backward: in LDS since this barrier at the latest
+            wq[1] = lds_frag(bwf, KT_R2, lane);
+            Wn0 = lds_frag(bwf, KT_R0, lane);
+          }
           if constexpr (XREG) {
 #pragma unroll
             for (int t = 0; t < KR; ++t) {
@@ -885,7 +924,8 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
     // ===================================================================================================
     // dW role: 8 accumulator blocks per wave, six tiles per step
     // ===================================================================================================
-    copy_operands();
+    copy_operands([]() {});
+    if constexpr (SPLIT_COPY) copy_transposed();
     // row m of the row-sum block: m = rs * latent slot + object row for the four latent layers, then one
     // "ones" row each for the two plain biases (encoding_shape: group 4, rgb.0: group 5)
     constexpr int rs = RS_ROWS;  // rows per latent slot: a compile-time constant of the instantiation (a run-time stride cost 2.4 us)
