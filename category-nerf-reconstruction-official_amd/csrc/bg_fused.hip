@@ -274,7 +274,9 @@ __global__ __launch_bounds__(256, 2) void bg_fwd_kernel(BgFwdArgs a) {
   pe_images(a.pts, th + O_PE_B, a.inv_scale, m0, M, E1h, E1l, E2h);
   __syncthreads();
   // PE features (hi) -> global for the weight-gradient kernel: rows of 288 bytes = 18 x 16
-  for (int i = threadIdx.x; i < TS * 18; i += 256) {
+  // (a.act / a.eimg == NULL: the forward alone -- Trainer.eval_points' meshing queries: nothing is kept for a backward)
+  const bool keep = a.act != nullptr;
+  for (int i = threadIdx.x; keep && i < TS * 18; i += 256) {
     const int row = i / 18, ch = i % 18;
     if (m0 + row < M) {
       const f4 v = ch < 12 ? *reinterpret_cast<const f4*>(E1h + row * ST_E1B + ch * 16)
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void bg_fwd_kernel(BgFwdArgs a) {
   f_in.mma(E1h, E1l, ST_E1B, lane, acc);
   store_tile(Xh0, Xl0, c, w, h, acc, true);
   __syncthreads();
-  image_to_global(Xh0, a.act + 0 * MH, m0, M);
+  if (keep) image_to_global(Xh0, a.act + 0 * MH, m0, M);
   // ---- mid1: a1 -> a2 -------------------------------------------------------------------------------------------------
   init_tile(acc, th + O_M1_B, w, h, BH);
   Frags<8, true> f_m1;
@@ -299,7 +301,7 @@ __global__ __launch_bounds__(256, 2) void bg_fwd_kernel(BgFwdArgs a) {
   f_m1.mma(Xh0, Xl0, ST_X, lane, acc);
   store_tile(Xh1, Xl1, c, w, h, acc, true);
   __syncthreads();
-  image_to_global(Xh1, a.act + 1 * MH, m0, M);
+  if (keep) image_to_global(Xh1, a.act + 1 * MH, m0, M);
   // ---- cat_layer: [a2 | e1] -> a3 (image 0 = a1 was last read before the barrier above) ------------------------------
   init_tile(acc, th + O_CAT_B, w, h, BH);
   Frags<8, true> f_ca;
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void bg_fwd_kernel(BgFwdArgs a) {
   f_ce.mma(E1h, E1l, ST_E1B, lane, acc);
   store_tile(Xh0, Xl0, c, w, h, acc, true);
   __syncthreads();
-  image_to_global(Xh0, a.act + 2 * MH, m0, M);
+  if (keep) image_to_global(Xh0, a.act + 2 * MH, m0, M);
   // ---- mid2: a3 -> a4, and the x10 occupancy head as an fp32 dot product of the fp32 activations -----------------------
   init_tile(acc, th + O_M2_B, w, h, BH);
   Frags<8, true> f_m2;
@@ -331,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void bg_fwd_kernel(BgFwdArgs a) {
   }
   store_tile(Xh1, nullptr, c, w, h, acc, true);   // image 1 = a2: last read by cat_layer, a barrier ago
   __syncthreads();
-  image_to_global(Xh1, a.act + 3 * MH, m0, M);
+  if (keep) image_to_global(Xh1, a.act + 3 * MH, m0, M);
   if (threadIdx.x < TS && m0 + threadIdx.x < M) {
     const int s = threadIdx.x;   // alpha = raw * 10 (src/model.py:142)
     a.sigma[m0 + s] = 10.0f * (((sigp[s] + sigp[TS + s]) + (sigp[2 * TS + s] + sigp[3 * TS + s])) + th[O_OA_B]);
@@ -346,7 +348,7 @@ __global__ __launch_bounds__(256, 2) void bg_fwd_kernel(BgFwdArgs a) {
   f_c2.mma(E2h, nullptr, ST_E2B, lane, acc);
   store_tile(Xh0, nullptr, c, w, h, acc, true);   // image 0 = a3: last read by mid2
   __syncthreads();
-  image_to_global(Xh0, a.act + 4 * MH, m0, M);
+  if (keep) image_to_global(Xh0, a.act + 4 * MH, m0, M);
   // ---- out_color (3 outputs): wave 0, rows 0..2 = registers 0..2 of lane half 0 ------------------------------------------
   if (w == 0) {
     init_tile(acc, th + O_OC_B, 0, h, 3);
@@ -987,7 +989,8 @@ extern "C" int cnr_bg_pack(const float* theta, void* packed, void* stream) {
 
 extern "C" int cnr_bg_forward(const float* pts, const float* theta, const void* packed, float scale, int M, float* sigma,
                               float* rgb, void* act, void* eimg, void* stream) {
-  if (!pts || !theta || !packed || !sigma || !rgb || !act || !eimg || M <= 0 || !(scale > 0.f)) return CNR_E_ARG;
+  if (!pts || !theta || !packed || !sigma || !rgb || M <= 0 || !(scale > 0.f)) return CNR_E_ARG;
+  if ((act == nullptr) != (eimg == nullptr)) return CNR_E_ARG;    // both (a training step's forward) or neither (forward only)
   if (((uintptr_t)packed & 15) != 0 || ((uintptr_t)act & 15) != 0 || ((uintptr_t)eimg & 15) != 0) return CNR_E_ALIGN;
   static cnr::DeviceOnce once;
   const int er = cnr::set_max_dynamic_lds(once, (const void*)bg_fwd_kernel, BG_FWD_LDS);

@@ -31,6 +31,10 @@ class Trainer:
         self.extent_dict = None
         self.bound_extent = 0.995 if cls_id == 0 else 0.9
         self.scale_template = None
+        # eval_points of the BACKGROUND field: "fp32" = the exact modules (2e-5 of the reference; the default), "fused" = the f16-MFMA
+        # forward of csrc/bg_fused.hip (hidden size 128: occupancy 1e-6, colour 2e-4 on trained weights -- inside north_star's 1e-3 --
+        # and an order of magnitude faster: the reference's own note on this function is "2s/it 1000000 pts", src/trainer.py:134)
+        self.eval_precision = "fp32"
 
     def load_NeRF(self):
         self.fc_occ_map = model.OccupancyMap(self.emb_size1, self.emb_size2,
@@ -81,6 +85,19 @@ class Trainer:
                     sig, rgb = ops.field_fwd(pts.view(1, 1, -1, 3), B, packed, brows, row, self.pe._scale)
                     alpha.append(sig.reshape(-1))
                     color.append(rgb.reshape(-1, 3))
+            elif self.eval_precision == "fused" and self.hidden_feature_size == 128:
+                from . import _C
+                flat = torch.cat([p.reshape(-1) for p in self.fc_occ_map.parameters()] + [self.pe.B_layer.weight.reshape(-1)]).contiguous()
+                assert flat.numel() == int(_C.load().cnr_bg_param_count())
+                packed = torch.empty(int(_C.load().cnr_bg_pack_bytes()), device=flat.device, dtype=torch.uint8)
+                _C.call("cnr_bg_pack", flat, packed)
+                for k in range(n_chunks):
+                    pts = points[k * chunk_size:(k + 1) * chunk_size].float().contiguous()
+                    M = pts.shape[0]
+                    sig, rgb = torch.empty(M, device=pts.device), torch.empty(M, 3, device=pts.device)
+                    _C.call("cnr_bg_forward", pts, flat, packed, float(self.pe._scale), M, sig, rgb, None, None)
+                    alpha.append(sig)
+                    color.append(rgb)
             else:
                 for k in range(n_chunks):
                     emb = self.pe(points[k * chunk_size:(k + 1) * chunk_size, None, :])

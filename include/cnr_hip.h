@@ -611,7 +611,8 @@ int cnr_bg_dw_chunks(int M, int chunk);
 int cnr_bg_record_floats(void);
 int cnr_bg_pack(const float* theta, void* packed, void* stream);
 int cnr_bg_forward(const float* pts, const float* theta, const void* packed, float scale, int M, float* sigma, float* rgb,
-                   void* act, void* eimg, void* stream);
+                   void* act, void* eimg, void* stream);   /* act = eimg = NULL: the forward alone, nothing kept for a backward
+                                                              (Trainer.eval_points' meshing queries, src/trainer.py:125-151) */
 int cnr_bg_backward(const float* pts, const float* theta, const void* packed, float scale, int M, const float* d_sigma,
                     const float* d_rgb, const float* rgb, const void* act, void* dpre, float* records, int64_t* d_state,
                     int64_t add_rows, void* stream);
