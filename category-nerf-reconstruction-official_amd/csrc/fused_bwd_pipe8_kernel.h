@@ -1031,22 +1031,32 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
         // compiler keeps them in source order, so the lookahead is spelled out): all four, the registers are there
         constexpr int DEPTH = NCHW;
         // The lane-dependent parts of the LDS addresses (one VGPR per access pattern, formed once before the loop) are made
-        // opaque per step: a read's address is then ONE add of a constant here, instead of ~30 loop-invariant address
-        // registers hoisted out of the iteration loop (4 tiles x 7 images lie further apart than a 16-bit ds offset reaches),
-        // which spilled -- and instead of re-deriving the patterns from the lane index, which costs the dW wave ~300
-        // cycles at the start of every step, where the chain waves wait for it.
-        int a_lo = p_hs_lo, a_hi = p_hs_hi, a_e1 = p_e1, a_e2 = p_e2, a_r = p_r;
-        asm volatile("" : "+v"(a_lo), "+v"(a_hi), "+v"(a_e1), "+v"(a_e2), "+v"(a_r));
-        auto rd_hs = [&](const unsigned char* img, int sl) {   // = tr_frag_hs(img, sl, lane)
+        // opaque per step, so that nothing is hoisted out of the iteration loop (~30 loop-invariant address registers spilled
+        // when they were) and nothing is re-derived from the lane index at the start of a step, where the chain waves wait.
+        // The images of the four chain waves lie 83 .. 160 KB into the LDS, beyond a ds instruction's 16-bit offset field: with
+        // ONE base per pattern every read needed its own v_add (32 .. 48 per step and wave, seen in the ISA).  TWO bases per
+        // pattern -- chain waves 0 | 1 and 2 | 3, each carrying its pair's start -- leave every read a constant below 64 KB that
+        // folds into the instruction: ten adds per step.
+        constexpr int PAIR_OFF[2] = {L8_CHAIN, L8_CHAIN + 2 * K_BYTES};
+        int a_lo[2], a_hi[2], a_e1[2], a_e2[2], a_r[2];
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          a_lo[pr] = p_hs_lo + PAIR_OFF[pr]; a_hi[pr] = p_hs_hi + PAIR_OFF[pr]; a_e1[pr] = p_e1 + PAIR_OFF[pr];
+          a_e2[pr] = p_e2 + PAIR_OFF[pr]; a_r[pr] = p_r + PAIR_OFF[pr];
+          asm volatile("" : "+v"(a_lo[pr]), "+v"(a_hi[pr]), "+v"(a_e1[pr]), "+v"(a_e2[pr]), "+v"(a_r[pr]));
+        }
+        // (w: chain wave of the image, off: the image's offset inside that wave's region)
+        auto rd_hs = [&](int w, int off, int sl) {   // = tr_frag_hs(image, sl, lane)
           typedef __attribute__((address_space(3))) s4v* lds_s4;
+          const int k = (w & 1) * K_BYTES + off + sl * 1024;
           h8 out;
-          out.lo = __builtin_bit_cast(h4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(img + sl * 1024 + a_lo)));
-          out.hi = __builtin_bit_cast(h4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(img + sl * 1024 + a_hi)));
+          out.lo = __builtin_bit_cast(h4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(smem + a_lo[w >> 1] + k)));
+          out.hi = __builtin_bit_cast(h4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(smem + a_hi[w >> 1] + k)));
           return out;
         };
-        auto rd_pe = [&](const unsigned char* img, int stride, int col0, int sl) {   // = tr_frag(img, stride, col0, sl, lane)
+        auto rd_pe = [&](int w, int off, int stride, int col0, int sl) {   // = tr_frag(image, stride, col0, sl, lane)
           typedef __attribute__((address_space(3))) s4v* lds_s4;
-          const unsigned char* a = img + (stride == ST_E1 ? a_e1 : a_e2) + 16 * sl * stride + col0 * 2;
+          const unsigned char* a = smem + (stride == ST_E1 ? a_e1[w >> 1] : a_e2[w >> 1]) + ((w & 1) * K_BYTES + off + 16 * sl * stride + col0 * 2);
           h8 out;
           out.lo = __builtin_bit_cast(h4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(a)));
           out.hi = __builtin_bit_cast(h4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(a + 4 * stride)));
@@ -1056,20 +1066,18 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
         u4v fR[DEPTH][2];          // row one-hot operand of the row sums
         auto load_blk = [&](int w, auto kind_c, auto slot_c) {
           constexpr int kind = decltype(kind_c)::value, slot = decltype(slot_c)::value;
-          const unsigned char* cb = chain_base + w * K_BYTES;
-          const unsigned char* ximg;
-          int stride = 0, col0 = 0;
-          if (kind == BK_VD_E0 || kind == BK_VD_E1) { ximg = cb + K_E2; stride = ST_E2; col0 = kind == BK_VD_E1 ? 32 : 0; }
-          else if (kind == BK_CAT_E0 || kind == BK_XYZ_E0) { ximg = cb + K_E1; stride = ST_E1; col0 = 0; }
-          else if (kind == BK_CAT_E1 || kind == BK_XYZ_E1) { ximg = cb + K_E1; stride = ST_E1; col0 = 32; }
-          else if (kind == BK_CAT_E2 || kind == BK_XYZ_E2) { ximg = cb + K_E1; stride = ST_E1; col0 = 64; }
-          else ximg = cb + K_X + PAR;
+          int ximg, stride = 0, col0 = 0;     // (offset of the image inside chain wave w's region)
+          if (kind == BK_VD_E0 || kind == BK_VD_E1) { ximg = K_E2; stride = ST_E2; col0 = kind == BK_VD_E1 ? 32 : 0; }
+          else if (kind == BK_CAT_E0 || kind == BK_XYZ_E0) { ximg = K_E1; stride = ST_E1; col0 = 0; }
+          else if (kind == BK_CAT_E1 || kind == BK_XYZ_E1) { ximg = K_E1; stride = ST_E1; col0 = 32; }
+          else if (kind == BK_CAT_E2 || kind == BK_XYZ_E2) { ximg = K_E1; stride = ST_E1; col0 = 64; }
+          else ximg = K_X + PAR;
           if (stride == 0) {  // the step's input image (swizzled rows)
-            fX[w % DEPTH][slot][0] = rd_hs(ximg, 0);
-            fX[w % DEPTH][slot][1] = rd_hs(ximg, 1);
+            fX[w % DEPTH][slot][0] = rd_hs(w, ximg, 0);
+            fX[w % DEPTH][slot][1] = rd_hs(w, ximg, 1);
           } else {            // a PE image
-            fX[w % DEPTH][slot][0] = rd_pe(ximg, stride, col0, 0);
-            fX[w % DEPTH][slot][1] = rd_pe(ximg, stride, col0, 1);
+            fX[w % DEPTH][slot][0] = rd_pe(w, ximg, stride, col0, 0);
+            fX[w % DEPTH][slot][1] = rd_pe(w, ximg, stride, col0, 1);
           }
         };
         auto mma_blk = [&](int w, auto kind_c, auto slot_c) {
@@ -1078,15 +1086,14 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
           Wacc[li] = MFMA(fD[w % DEPTH][1], fX[w % DEPTH][slot][1], Wacc[li]);
         };
         auto load_tile = [&](int w) {
-          const unsigned char* cb = chain_base + w * K_BYTES;
-          fD[w % DEPTH][0] = rd_hs(cb + K_D + PAR, 0);
-          fD[w % DEPTH][1] = rd_hs(cb + K_D + PAR, 1);
+          fD[w % DEPTH][0] = rd_hs(w, K_D + PAR, 0);
+          fD[w % DEPTH][1] = rd_hs(w, K_D + PAR, 1);
           if constexpr (OWN0) load_blk(w, IC<K0>{}, IC<SL0>{});
           if constexpr (OWN1) load_blk(w, IC<K1>{}, IC<SL1>{});
           if constexpr (OWN2) load_blk(w, IC<K2>{}, IC<SL2>{});
           if constexpr (OWN3) load_blk(w, IC<K3>{}, IC<SL3>{});
           if constexpr (DO_RS && !ROWTILE) {
-            const unsigned char* rowoh = cb + K_SMALL + a_r;   // [m_row][32] halfs: this lane's k = 8 h .. and 16 + 8 h ..
+            const unsigned char* rowoh = smem + a_r[w >> 1] + ((w & 1) * K_BYTES + K_SMALL);   // [m_row][32] halfs: this lane's k = 8 h .. and 16 + 8 h ..
             fR[w % DEPTH][0] = __builtin_bit_cast(u4v, *reinterpret_cast<const h8*>(rowoh));
             fR[w % DEPTH][1] = __builtin_bit_cast(u4v, *reinterpret_cast<const h8*>(rowoh + 32));
           }
