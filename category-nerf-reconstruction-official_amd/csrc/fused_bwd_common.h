@@ -124,6 +124,33 @@ __device__ __forceinline__ float half_sum_dpp(float v) {
   return __builtin_bit_cast(float, x);
 }
 
+// Sums over the 32 lanes of each wave half of N per-lane values at once, through a wave-private LDS scratch of HALF_SUMS_STRIDE * N
+// floats: every lane stores its N values ([value][lane], rows 68 floats apart: the stores and the 16-byte re-reads are free of
+// bank conflicts up to N = 16, two-way beyond), lane t < 2 N then adds the 32 values of (value t >> 1, lane half t & 1) in lane
+// order and hands the sum to out(value, half, sum).  N half_sum_dpp calls are N dependent chains of five DPP adds with their
+// wait states and one predicated store each (~100 cycles apiece as measured behind the step body's loop: 50 of them 4.8 k cycles);
+// this is N stores + 8 reads + 32 adds.  LDS operations of one wave execute in order: no barrier, only the compiler is fenced.
+constexpr int HALF_SUMS_STRIDE = 68;
+template <int N, class F> __device__ __forceinline__ void half_sums_lds(const float (&v)[N], float* scratch, int lane, F&& out) {
+  static_assert(2 * N <= 64, "one (value, half) pair per lane");
+#pragma unroll
+  for (int i = 0; i < N; ++i) scratch[i * HALF_SUMS_STRIDE + lane] = v[i];
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  if (lane < 2 * N) {
+    const f4* row = reinterpret_cast<const f4*>(scratch + (lane >> 1) * HALF_SUMS_STRIDE + (lane & 1) * 32);
+    f4 q[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) q[k] = row[k];
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s = ((((s + q[k][0]) + q[k][1]) + q[k][2]) + q[k][3]);
+    out(lane >> 1, lane & 1, s);
+  }
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
 // ---- 32-lane scans on DPP row operations (a __shfl is a ds_bpermute: ~130 dependent cycles each, a 32-lane scan of five of
 // them ~700; these are five VALU instructions).  Each works on both 32-lane halves of the wave independently.
 // inclusive prefix sum over lanes 0..i of the half = half_sum_dpp (lane 31 / 63: the half's total)

@@ -135,6 +135,8 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
   constexpr int L8_BL = l8_bl(GEO), L8_BR = l8_br(GEO), L8_CHAIN = l8_chain(WIDE, GEO), C8_BYTES = c8_bytes(WIDE),
                 K8_SMALL_BYTES = k8_small(WIDE);
   constexpr bool BROWS_LDS = brows_in_lds8(WIDE, GEO);
+  constexpr int SUMS_SCRATCH = 25 * HALF_SUMS_STRIDE * 4;   // per wave, behind the loop (half_sums_lds), in the dead operand fragments
+  static_assert((NCH + NDW) * SUMS_SCRATCH <= PK_BYTES, "scratch of the closing sums");
   // PEDW: the PE backward (66 cosines and ~300 multiply-adds per sample, pure VALU work on the critical chain wave) runs on the
   // chain wave's dW partner -- the wave that shares its SIMD and idles through the forward phase.  d e2 / d e1 travel lane to
   // lane as f16 through LDS that is free at that point (the E2 image after step VD, three slot images after step XYZ); the
@@ -885,7 +887,9 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
       cur = nxt;
       any_iter = true;   // the barrier "dW waves are done with this tile's images" follows at the next iteration's image
     }                    // writes (below the PE arithmetic, which so runs beside the dW waves' last step), or here:
+    P8PHASE(3);
     if (any_iter) role_barrier();
+    P8PHASE(4);
     if constexpr (PEDW) {
       if (any_iter) {   // the workgroup's last tile: its d e1 / d e2 are still where this wave put them
         h8 dq[9];
@@ -896,29 +900,36 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
         pe_backward_h(dq, l0x, l1x, l2x, c_dbacc);
       }
     }
+    P8PHASE(6);
     {  // publish this wave's partial sums (the last barrier has passed: the dW waves no longer read the row table
-       // this aliases): [0..31] d w_sigma, [32] d b_sigma, [64..126] dB
+       // this aliases): [0..31] d w_sigma, [32] d b_sigma, [64..126] dB.  The 50 half-wave sums go through LDS (half_sums_lds; the
+       // operand fragments at the front of the LDS are dead behind the loop's last barrier: a wave's scratch lies there), in two
+       // batches of 25: stamped, 50 DPP reductions were 4.8 k cycles of every workgroup here.
       float* small = reinterpret_cast<float*>(cw + K_SMALL);
+      float* scr = reinterpret_cast<float*>(smem + wv * SUMS_SCRATCH);
+      auto put_db = [&](int i, int hh, float s) {   // dB entry i = 3 d + axis of lane half hh (direction 11 hh + d; 21 exist)
+        const int d = i / 3;
+        if (!(hh == 1 && d == 10)) small[64 + (11 * hh + d) * 3 + (i - 3 * d)] = s;
+      };
+      float va[25], vb[25];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float v = half_sum_dpp(DWS(i));
-        if (col == 31) small[acc_row(i, h)] = v;
-      }
-      {
-        const float v = half_sum_dpp(DBS);  // zero in lane half 1
-        if (lane == 31) small[32] = v;
-      }
+      for (int i = 0; i < 16; ++i) va[i] = DWS(i);
+      va[16] = DBS;   // zero in lane half 1
+#pragma unroll
+      for (int i = 0; i < 8; ++i) va[17 + i] = DBACC(i);
+#pragma unroll
+      for (int i = 0; i < 25; ++i) vb[i] = DBACC(8 + i);
+      half_sums_lds<25>(va, scr, lane, [&](int i, int hh, float s) {
+        if (i < 16) small[acc_row(i, hh)] = s;
+        else if (i == 16) { if (hh == 0) small[32] = s; }
+        else put_db(i - 17, hh, s);
+      });
+      half_sums_lds<25>(vb, scr, lane, [&](int i, int hh, float s) { put_db(8 + i, hh, s); });
       if constexpr (TWO) {   // two rays per tile: lanes 0 and 16 hold the two rays' shares
         ld_acc += lane_value(ld_acc, 16); lc_acc += lane_value(lc_acc, 16); lo_acc += lane_value(lo_acc, 16);
       }
       if (KR > 0 && lane == 0) { small[40] = ld_acc; small[41] = lc_acc; small[42] = lo_acc; small[43] = __int_as_float(tab_flags);
                                  small[44] = wd_c; small[45] = wc_c; small[46] = wo_c; }
-#pragma unroll
-      for (int i = 0; i < 33; ++i) {
-        const float v = half_sum_dpp(DBACC(i));
-        const int d = i / 3;
-        if (col == 31 && !(h == 1 && d == 10)) small[64 + (11 * h + d) * 3 + (i % 3)] = v;
-      }
     }
   } else {
     // ===================================================================================================
@@ -1187,6 +1198,7 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
     else if (dwid == 1) dw_loop(IC<1>{});
     else if (dwid == 2) dw_loop(IC<2>{});
     else dw_loop(IC<3>{});
+    P8PHASE(3);
     // ---- this wave's blocks -> the workgroup's record, straight from the accumulators -------------------------
     rec_t* rec = records + ((size_t)c * gridDim.x + blockIdx.x) * REC_ENTRIES;
 #define CNR_PSTORE8(KIND, NROWS)                                                               \
@@ -1204,6 +1216,7 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
     CNR_PSTORE8(BK_CAT_E0, 32) CNR_PSTORE8(BK_CAT_E1, 32) CNR_PSTORE8(BK_CAT_E2, 32) CNR_PSTORE8(BK_S1, 32)
     CNR_PSTORE8(BK_XYZ_E0, 32) CNR_PSTORE8(BK_XYZ_E1, 32) CNR_PSTORE8(BK_XYZ_E2, 32)
 #undef CNR_PSTORE8
+    P8PHASE(4);
     if (dwid == owner8<NDW>(BK_R0) && r2i0 >= 0) {  // rgb.2 out of rows 16..18 of rgb.0's block
       constexpr int li = local8<NDW>(BK_R0);
 #pragma unroll
@@ -1232,20 +1245,28 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
         }
       }
     }
+    P8PHASE(6);
     if constexpr (PEDW) {   // dB partial sums of the partner's tiles -> the partner's E1 image (free: the loop is over), 63 floats
       float* e1f = reinterpret_cast<float*>(chain_base + dwid * K_BYTES + K_E1);
-#pragma unroll
-      for (int i = 0; i < 33; ++i) {
-        const float v = half_sum_dpp(w_dbacc[i]);
+      float* scr = reinterpret_cast<float*>(smem + wv * SUMS_SCRATCH);
+      auto put_db = [&](int i, int hh, float s) {
         const int d = i / 3;
-        if (col == 31 && !(h == 1 && d == 10)) e1f[(11 * h + d) * 3 + (i % 3)] = v;
-      }
+        if (!(hh == 1 && d == 10)) e1f[(11 * hh + d) * 3 + (i - 3 * d)] = s;
+      };
+      float va[17], vb[16];
+#pragma unroll
+      for (int i = 0; i < 17; ++i) va[i] = w_dbacc[i];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) vb[i] = w_dbacc[17 + i];
+      half_sums_lds<17>(va, scr, lane, [&](int i, int hh, float s) { put_db(i, hh, s); });
+      half_sums_lds<16>(vb, scr, lane, [&](int i, int hh, float s) { put_db(17 + i, hh, s); });
     }
   }
 
   // ========================================= flush ====================================================
   // (the dW waves have written their blocks above; what is left are the chain waves' partial sums)
   rec_t* rec = records + ((size_t)c * gridDim.x + blockIdx.x) * REC_ENTRIES;
+  P8PHASE(7);
   __syncthreads();
   P8PHASE(2);
   {
@@ -1276,7 +1297,6 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
       }
     }
   }
-  P8PHASE(3); P8PHASE(4);
   P8PHASE(5);
 }
 }  // namespace

@@ -44,5 +44,7 @@ for w in range(8):
               "| suffix carry", mk[3] - mk[2], "| scan+docc", mk[4] - mk[3], "| dsg..DWS", mk[5] - mk[4], "| R2 stage+mfma", mk[6] - mk[5])
     its = [v for v in b[w * 64 + 30: w * 64 + 42] if v]
     print("    iteration starts (from loop start)", [v - b[w * 64 + 57] for v in its], "lengths", [its[i + 1] - its[i] for i in range(len(its) - 1)])
-    ph = b[w * 64 + 56: w * 64 + 62]
+    ph = b[w * 64 + 56: w * 64 + 64]
+    print("    behind the loop (from kernel start): loop left", ph[3] - ph[0], "| +", ph[4] - ph[3], "(chain: last barrier; dW: record blocks) | +", ph[6] - ph[4],
+          "(chain: last tile's PE backward; dW: rgb.2 + row-sum block) | +", ph[7] - ph[6], "(partial sums) | barrier +", ph[2] - ph[7])
     print("    phases: weights in LDS", ph[1] - ph[0], "| loops", ph[2] - ph[1], "| flush", ph[5] - ph[2], "| total", ph[5] - ph[0])
