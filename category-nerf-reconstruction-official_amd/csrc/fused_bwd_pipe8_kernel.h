@@ -542,21 +542,21 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
       wq[0] = lds_frag(smem, KK_S1 + 0, lane); wq[1] = lds_frag(smem, KK_S1 + 1, lane);
       if constexpr (GEO) { wl[0] = lds_frag(lo_w, KK_S1 + 0, lane); wl[1] = lds_frag(lo_w, KK_S1 + 1, lane); }
       bq = acc_init(brow_l + 0 * 32, h);
-      const h8 A0a = pack8(acc, 0, true), A0b = pack8(acc, 1, true);
+      const h8 A0a = GEO ? pack8_relu32(acc, 0) : pack8(acc, 0, true), A0b = GEO ? pack8_relu32(acc, 1) : pack8(acc, 1, true);
       acc = hidden(A0a, A0b, acc, true, bq);
       wq[0] = lds_frag(smem, KK_CAT + 0, lane); wq[1] = lds_frag(smem, KK_CAT + 1, lane);
       if constexpr (GEO) { wl[0] = lds_frag(lo_w, KK_CAT + 0, lane); wl[1] = lds_frag(lo_w, KK_CAT + 1, lane); }
-      const h8 A1a = pack8(acc, 0, true), A1b = pack8(acc, 1, true);
+      const h8 A1a = GEO ? pack8_relu32(acc, 0) : pack8(acc, 0, true), A1b = GEO ? pack8_relu32(acc, 1) : pack8(acc, 1, true);
       acc = hidden(A1a, A1b, acc, true, catp);
       wq[0] = lds_frag(smem, KK_S2 + 0, lane); wq[1] = lds_frag(smem, KK_S2 + 1, lane);
       if constexpr (GEO) { wl[0] = lds_frag(lo_w, KK_S2 + 0, lane); wl[1] = lds_frag(lo_w, KK_S2 + 1, lane); }
       bq = acc_init(brow_l + 2 * 32, h);
-      const h8 A2a = pack8(acc, 0, true), A2b = pack8(acc, 1, true);
+      const h8 A2a = GEO ? pack8_relu32(acc, 0) : pack8(acc, 0, true), A2b = GEO ? pack8_relu32(acc, 1) : pack8(acc, 1, true);
       acc = hidden(A2a, A2b, acc, true, bq);
       wq[0] = lds_frag(smem, KK_ES + 0, lane); wq[1] = lds_frag(smem, KK_ES + 1, lane);
       if constexpr (GEO) { wl[0] = lds_frag(lo_w, KK_ES + 0, lane); wl[1] = lds_frag(lo_w, KK_ES + 1, lane); }
       bq = acc_init(cf + CF_B_ES, h);
-      const h8 A3a = pack8(acc, 0, true), A3b = pack8(acc, 1, true);
+      const h8 A3a = GEO ? pack8_relu32(acc, 0) : pack8(acc, 0, true), A3b = GEO ? pack8_relu32(acc, 1) : pack8(acc, 1, true);
       acc = hidden(A3a, A3b, acc, true, bq);
       P8ISA("geometry_hidden_layers_done");
 #pragma unroll
@@ -966,7 +966,8 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
     // the record (no LDS image, no index table, no gather loop: 7 k -> 2.5 k cycles of every workgroup's tail).
     // the dW wave shares its SIMD with a chain wave; when both have an instruction ready the dW wave goes first: it is
     // the consumer every layer step waits for (measured: -2 % at 2048 x 64, -5 % at 8192 x 128; the reverse: no effect)
-    __builtin_amdgcn_s_setprio(3);
+    // (raised BEHIND the record-index setup below: those ~1 000 instructions run beside the chain waves' first forward and must
+    //  not take issue slots from it)
     int bi0[NACC], bst[NACC], r2i0 = -1, r2st = 0;
 #pragma unroll
     for (int i = 0; i < NACC; ++i) { bi0[i] = -1; bst[i] = 0; }
@@ -981,6 +982,8 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
     CNR_PIDX8(BK_XYZ_E0) CNR_PIDX8(BK_XYZ_E1) CNR_PIDX8(BK_XYZ_E2)
 #undef CNR_PIDX8
     if (owner8<NDW>(BK_R0) == dwid) { r2i0 = block_index(BK_R2, 0, col); r2st = block_index(BK_R2, 1, col) - r2i0; }
+    asm volatile("" : "+v"(r2i0));               // (keeps the raise below the setup)
+    __builtin_amdgcn_s_setprio(3);
     // The role branches on the dW wave's index ONCE, around the whole iteration loop: with the branch inside every layer step
     // the accumulator blocks met at a join after each step, and the compiler copied them between register ranges there (16
     // moves behind the step's last MFMA, in front of the barrier the chain waves wait at).

@@ -185,7 +185,7 @@ template <bool SPLIT>
 __device__ __forceinline__ f16v hidden_layer(const unsigned char* smem, const unsigned char* smem_lo, int kk0, int lane,
                                              const f16v& prev, const f16v& init) {
   const h8 w0 = lds_frag(smem, kk0, lane), w1 = lds_frag(smem, kk0 + 1, lane);
-  const h8 xa = pack8(prev, 0, true), xb = pack8(prev, 1, true);
+  const h8 xa = SPLIT ? pack8_relu32(prev, 0) : pack8(prev, 0, true), xb = SPLIT ? pack8_relu32(prev, 1) : pack8(prev, 1, true);
   f16v o = MFMA(w0, xa, init);
   o = MFMA(w1, xb, o);
   if (SPLIT) {
