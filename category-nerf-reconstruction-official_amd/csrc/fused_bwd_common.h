@@ -295,7 +295,15 @@ __device__ __forceinline__ u4v relu_mask(const h8& act) {
   return __builtin_bit_cast(u4v, (us8)((us8)(0) - t));
 }
 __device__ __forceinline__ h8 pack8_and(const f16v& a, int s, const u4v& m) {
-  return __builtin_bit_cast(h8, (u4v)(__builtin_bit_cast(u4v, pack8(a, s, false)) & m));
+  // (pair by pair on 32-bit words: through an h8 and back the compiler re-assembled every word from its halves -- one v_bfi x, x
+  //  per register, 36 per tile in the ISA)
+  u4v r;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f2 v = {a[8 * s + 2 * j], a[8 * s + 2 * j + 1]};
+    r[j] = __builtin_bit_cast(unsigned int, __builtin_convertvector(v, h2)) & m[j];
+  }
+  return __builtin_bit_cast(h8, r);
 }
 __device__ __forceinline__ h8 pack8_masked(const f16v& a, int s, const h8& act) { return pack8_and(a, s, relu_mask(act)); }
 __device__ __forceinline__ void role_barrier() {  // every wave of the workgroup executes the same number of these
