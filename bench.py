@@ -25,6 +25,18 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+
+def host_wait_spin():
+    """torch.cuda.synchronize() returns by polling instead of sleeping on an interrupt (hipDeviceScheduleSpin; must be set before the
+    first HIP call of the process, and in the HIP runtime torch has loaded).  A 20-step timed region is 1.15 ms of GPU work
+    between two synchronisations: the interrupt path's wake-up was ~25 us of it (tools/region_overhead.py: median region
+    1204.6 -> 1181.3 us); the GPU work is the same."""
+    import ctypes
+    try:
+        return ctypes.CDLL("libamdhip64.so").hipSetDeviceFlags(1) == 0
+    except OSError:
+        return False
+
 FLOP_PER_SAMPLE_STEP = 82140          # SURVEY.md section 8(d): 3 x 13 648 MAC + 2 x 63 MAC, 2 FLOP/MAC
 PEAK_MFMA_F16_TFLOPS = 2500.0         # MI355X dense bf16/f16 MFMA peak (MI355X_MICROARCH.md, chip-level table)
 
@@ -433,6 +445,12 @@ def main():
                     help="N > 1: categories in total of the strong_configs2 leg (BASELINE.json configs[2]'s stand-in count); 0 = skip")
     ap.add_argument("--launch-timeout", type=float, default=900.0,
                     help="seconds the self-started N-rank child tree may take before its process group is killed")
+    ap.add_argument("--pre-warm-seconds", type=float, default=0.25,
+                    help="seconds of untimed steps in FRONT of the W warm-up steps (reported as pre_warm_steps): the graph captures "
+                         "before them are ~50 ms of host work with the GPU idle, and a 20-step region right behind that ran 3 us "
+                         "per step slower than the same region in a running job; 0 = none")
+    ap.add_argument("--host-wait", choices=("spin", "default"), default="spin",
+                    help="how torch.cuda.synchronize() waits: spin = hipDeviceScheduleSpin (host_wait_spin), default = the runtime's")
     ap.add_argument("--launch-check", action="store_true",
                     help="bring the ranks up, all-reduce a one over the process group and print the world size the "
                          "backend reports -- no kernel runs (a check of the launcher, not a benchmark)")
@@ -459,6 +477,7 @@ def main():
         return launch_check(args, rank, local_rank, world, backend)
     if os.environ.get("CNR_SINGLE_DEVICE_REHEARSAL"):           # N ranks on one card (gloo), 1-GPU boxes only
         local_rank = 0
+    host_wait = "spin" if args.host_wait == "spin" and host_wait_spin() else "default"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     pg = None
@@ -537,6 +556,13 @@ def main():
         tr.run(1)
     # the W warm-up steps come LAST, directly in front of the timed region: the captures above are ~50 ms of host work with the GPU
     # idle, and the first region after them ran 2 us per step slower than every later one (tools/exp/region200.py)
+    pre_warm_steps = 0
+    if args.pre_warm_seconds > 0:      # the card back at its running-job clocks (the long_run leg below measures that state too)
+        t_pw = time.perf_counter()
+        while time.perf_counter() - t_pw < args.pre_warm_seconds:
+            tr.run(tr.unroll)
+            pre_warm_steps += tr.unroll
+            torch.cuda.synchronize()
     tr.run(max(args.warmup, 4))
     dbg("warmup issued")
     dt = timed(args.steps)                      # EXACTLY --steps steps between barriers + synchronize, max over ranks
@@ -604,7 +630,7 @@ def main():
     out = {"metric": "rays/sec (train step) Replica room_0, 2048 rays x 64 samples, 1/2/4/8 GPU",
            "value": rays_per_s, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak",
-           "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+           "vs_baseline": None, "dtype": "f16", "data": "synthetic", "host_wait": host_wait, "pre_warm_steps": pre_warm_steps,
            "config": {"workload": f"Replica room_0 shape: {C_glob} categor{'y' if C_glob == 1 else 'ies'} x {n_obj} objects, "
                                   f"{Rg} rays x {S} samples per category and step, latent {L}, W=32 CodeNeRF, random-pose "
                                   f"synthetic pool, random init",
