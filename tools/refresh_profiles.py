@@ -35,7 +35,9 @@ for name, dst in (("pmc_mix_2048x64.txt", "_pmc_instruction_mix.txt"), ("pmc_mix
                   ("bg_kernels.txt", "_bg_step_kernels.txt"), ("bg_pmc.txt", "_bg_step_pmc_sq.txt"),
                   ("full_iteration.txt", "_full_iteration.txt"), ("steps.txt", "_step_times_by_shape.txt"),
                   ("bench_c16.json", "_bench_c16_2048x64.json"), ("bench_8192x128.json", "_bench_8192x128.json"),
-                  ("bench_c8_4096x128_l32.json", "_bench_c8_4096x128_l32.json"), ("pytest_gpu.log", "_pytest_gpu_tail.txt")):
+                  ("bench_c8_4096x128_l32.json", "_bench_c8_4096x128_l32.json"), ("pytest_gpu.log", "_pytest_gpu_tail.txt"),
+                  ("bench_steps20.json", "_bench_2048x64_steps20_warmup5.json"), ("pmc_waits.txt", "_pmc_wait_counters.txt"),
+                  ("stamps_2048x64.txt", "_cycle_stamps_2048x64.txt"), ("micro_mfma_overlap.txt", "_micro_mfma_valu_overlap.txt")):
     f = f"{src}/{name}"
     if os.path.exists(f):
         txt = open(f).read()
