@@ -24,7 +24,7 @@ __global__ __launch_bounds__(512) void k(float* out, long long* cyc, int trips, 
     if (mode & 2)
       for (int t = 0; t < trips; ++t) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(x[i]) : "v"(x[(i + 1) % 16]));
+        for (int i = 0; i < 16; ++i) asm volatile("v_add_f32 %0, %0, %1" : "+v"(x[i]) : "v"(x[(i + 5) % 16]));
       }
   }
   const long long t1 = __builtin_readcyclecounter();
@@ -40,7 +40,7 @@ int main() {
   for (int mode = 1; mode <= 3; ++mode) {
     for (int r = 0; r < 2; ++r) { k<<<256, 512>>>(out, cyc, trips, mode); (void)hipDeviceSynchronize(); }
     long long c[8]; (void)hipMemcpy(c, cyc, 64, hipMemcpyDeviceToHost);
-    printf("mode %d (%s): MFMA wave %.1f cycles per MFMA | VALU wave %.2f cycles per v_fma\n", mode,
+    printf("mode %d (%s): MFMA wave %.1f cycles per MFMA | VALU wave %.2f cycles per v_add\n", mode,
            mode == 1 ? "MFMA waves alone" : mode == 2 ? "VALU waves alone" : "both", (double)c[0] / trips / 2, (double)c[4] / trips / 16);
   }
   return 0;
