@@ -558,11 +558,19 @@ def main():
     # idle, and the first region after them ran 2 us per step slower than every later one (tools/exp/region200.py)
     pre_warm_steps = 0
     if args.pre_warm_seconds > 0:      # the card back at its running-job clocks (the long_run leg below measures that state too)
+        # a step COUNT, the same on every rank (a class-sharded epoch end is a collective: ranks must not run different numbers of steps)
+        torch.cuda.synchronize()
         t_pw = time.perf_counter()
-        while time.perf_counter() - t_pw < args.pre_warm_seconds:
-            tr.run(tr.unroll)
-            pre_warm_steps += tr.unroll
-            torch.cuda.synchronize()
+        tr.run(tr.unroll)
+        torch.cuda.synchronize()
+        est = (time.perf_counter() - t_pw) / tr.unroll
+        n_pw = max(int(args.pre_warm_seconds / max(est, 1e-6)) // tr.unroll, 1) * tr.unroll
+        if world > 1:
+            tp = torch.tensor([n_pw], device=dev, dtype=torch.int64)
+            torch.distributed.all_reduce(tp, op=torch.distributed.ReduceOp.MAX)
+            n_pw = int(tp.item())
+        tr.run(n_pw)
+        pre_warm_steps = n_pw + tr.unroll
     tr.run(max(args.warmup, 4))
     dbg("warmup issued")
     dt = timed(args.steps)                      # EXACTLY --steps steps between barriers + synchronize, max over ranks

@@ -184,7 +184,8 @@ def test_kernels_contain_no_instruction_emitting_inline_asm():
     """hipcc pads no hazards around an inline-asm instruction and may hand its output a register an MFMA issued just before
     is still reading ("a hazard worth recording": run-to-run different gradients that the small fixtures
     never showed).  The kernels therefore use asm statements only as optimisation barriers: every asm template in csrc/ must
-    be the empty string."""
+    be the empty string -- or an assembler COMMENT ("; ..."), which emits nothing either (the phase marks of tools/isa_mix.py,
+    compiled in only with -DCNR_ISA_MARKS)."""
     csrc = os.path.join(ROOT, "category-nerf-reconstruction-official_amd", "csrc")
     bad = []
     for name in sorted(os.listdir(csrc)):
@@ -192,6 +193,6 @@ def test_kernels_contain_no_instruction_emitting_inline_asm():
             continue
         src = open(os.path.join(csrc, name)).read()
         for m in re.finditer(r"\basm\s*(?:volatile)?\s*\(\s*\"([^\"]*)\"", src):
-            if m.group(1).strip():
+            if m.group(1).strip() and not m.group(1).strip().startswith(";"):
                 bad.append((name, m.group(1)))
     assert not bad, bad
