@@ -458,24 +458,38 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
 
       // ------------------------------- forward recompute --------------------------------------------
       // (the previous iteration's last barrier has passed: every image of this wave is free)
-      h8 E1f[6], E2f[3], E1l[GEO ? 6 : 1];   // E1l: residual of the E1 features (GEO)
+      // ---- positional encoding, encoding_xyz and the e1 part of cat_layer (its own accumulator, started from the cat bias row) as a
+      // SOFTWARE PIPELINE over the six E1 fragments: stage s requests the weight fragments of s + 1, encodes fragment s + 1 (eight
+      // sines, conversions, residuals) and issues the (GEO: six) products on fragment s -- whose operands were requested and
+      // encoded one stage earlier.  The vector unit then encodes while the matrix core multiplies, and no product waits for an
+      // LDS read.  As "all 66 sines, then 36 products" the two units took turns: stamped ~3.3 k cycles of every tile.
+      // GEO: three products per fragment and accumulator, Wh xh + Wh xl + Wl xh (fused_common.h; fused_fwd.hip runs the same order:
+      // the two forwards agree bit for bit); wl* = the residual fragments, el = the residual of the features.
+      const unsigned char* lo_w = smem + l8_lo();
+      h8 wq[8], wl[GEO ? 6 : 1];
+      h8 E2f[3];
+      f16v acc, bq, catp;
+      float pdv[11];
       {
         float Bh[33];
 #pragma unroll
         for (int i = 0; i < 33; ++i) Bh[i] = Bl_h[i];
-        pe_slots<true, GEO>(Bh, t0x, t1x, t2x, h, E1f, E2f, E1l);
+        pe_dirs(Bh, t0x, t1x, t2x, pdv);
       }
-      P8ISA("pe_forward_done");
-      // GEO: a geometry layer is three products per fragment, Wh xh + Wl xh + Wh xl (fused_common.h): wl = the residual
-      // fragments, X*l = the residual of the layer input, formed from the fp32 accumulators while the first products run
-      const unsigned char* lo_w = smem + l8_lo();
-      h8 wq[8], wl[GEO ? 6 : 1], wc[6];
-      f16v acc, bq, catp;
-#pragma unroll
-      for (int s = 0; s < 6; ++s) {
-        wq[s] = lds_frag(smem, KK_XYZ + s, lane);
-        if constexpr (!GEO) wc[s] = lds_frag(smem, KK_CAT + 2 + s, lane);
-      }
+      struct E1Stage { h8 e, el, wx, wc, wlx, wlc; };
+      auto e1_request = [&](int s, E1Stage& st) {
+        st.wx = lds_frag(smem, KK_XYZ + s, lane); st.wc = lds_frag(smem, KK_CAT + 2 + s, lane);
+        if constexpr (GEO) { st.wlx = lds_frag(lo_w, KK_XYZ + s, lane); st.wlc = lds_frag(lo_w, KK_CAT + 2 + s, lane); }
+      };
+      auto e1_encode = [&](int s, E1Stage& st) {
+        float v[8];
+        pe_e1_slots<true>(pdv, t0x, t1x, t2x, h, s, v);
+        st.e = pack8f(v);
+        if constexpr (GEO) st.el = pack8f_lo(v, st.e);
+      };
+      E1Stage stg[2];
+      e1_request(0, stg[0]);
+      e1_encode(0, stg[0]);
       acc = acc_init(cf + CF_B_XYZ, h);
       catp = acc_init(brow_l + 1 * 32, h);
       if (any_iter) P8SYNC();   // the previous iteration's last barrier: the dW waves are done with this wave's images
@@ -487,44 +501,33 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
           if (r + h < rs) rowoh[(r + h) * 32 + col] = rl == r + h ? (_Float16)1 : (_Float16)0;
         if (h == 0) rowoh[rs * 32 + col] = (_Float16)1;
       }
-      {
-        unsigned char* b1 = E1img + col * ST_E1 + h * 96;
 #pragma unroll
-        for (int s = 0; s < 6; ++s) *reinterpret_cast<h8*>(b1 + 16 * s) = E1f[s];
-        unsigned char* b2 = E2img + col * ST_E2 + h * 48;
-#pragma unroll
-        for (int s = 0; s < 3; ++s) *reinterpret_cast<h8*>(b2 + 16 * s) = E2f[s];
+      for (int s = 0; s < 6; ++s) {
+        E1Stage& cu = stg[s & 1];
+        E1Stage& nx = stg[(s + 1) & 1];
+        if (s + 1 < 6) { e1_request(s + 1, nx); e1_encode(s + 1, nx); }
+        *reinterpret_cast<h8*>(E1img + col * ST_E1 + h * 96 + 16 * s) = cu.e;
+        acc = MFMA(cu.wx, cu.e, acc);
+        catp = MFMA(cu.wc, cu.e, catp);
+        if constexpr (GEO) {
+          acc = MFMA(cu.wx, cu.el, acc);
+          catp = MFMA(cu.wc, cu.el, catp);
+          acc = MFMA(cu.wlx, cu.e, acc);
+          catp = MFMA(cu.wlc, cu.e, catp);
+        }
       }
-      // encoding_xyz, and the e1 part of cat_layer right behind it (its own accumulator, started from the cat bias row): both
-      // read only the PE features, so the E1 operands die here, and the second runs under the packing of a0.
-      // GEO: six fragments in registers at a time -- Wh first (products with xh and xl), then Wl (product with xh); the
-      // scheduling barriers keep the compiler from fetching the next six early (24 fragments at once spill)
+      {   // the view-direction features (bands 4, 5): used by encoding_viewdir, behind the geometry branch
+        float v2[24];
+        pe_e2_slots<true>(pdv, h, v2);
 #pragma unroll
-      for (int s = 0; s < 6; ++s) acc = MFMA(wq[s], E1f[s], acc);
-      if constexpr (GEO) {
-#pragma unroll
-        for (int s = 0; s < 6; ++s) acc = MFMA(wq[s], E1l[s], acc);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int s = 0; s < 6; ++s) wl[s] = lds_frag(lo_w, KK_XYZ + s, lane);
-#pragma unroll
-        for (int s = 0; s < 6; ++s) acc = MFMA(wl[s], E1f[s], acc);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int s = 0; s < 6; ++s) wc[s] = lds_frag(smem, KK_CAT + 2 + s, lane);
+        for (int s = 0; s < 3; ++s) {
+          E2f[s] = pack8f(&v2[8 * s]);
+          *reinterpret_cast<h8*>(E2img + col * ST_E2 + h * 48 + 16 * s) = E2f[s];
+        }
       }
-#pragma unroll
-      for (int s = 0; s < 6; ++s) catp = MFMA(wc[s], E1f[s], catp);
-      if constexpr (GEO) {
-#pragma unroll
-        for (int s = 0; s < 6; ++s) catp = MFMA(wc[s], E1l[s], catp);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int s = 0; s < 6; ++s) wl[s] = lds_frag(lo_w, KK_CAT + 2 + s, lane);
-#pragma unroll
-        for (int s = 0; s < 6; ++s) catp = MFMA(wl[s], E1f[s], catp);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      P8MARK(8);
+      P8ISA("pe_forward_done");
+      P8MARK(9);
       // a 32-wide hidden layer on the input pair (xa, xb) = f16 of the previous accumulators; GEO: + the two residual products
       auto hidden = [&](const h8& xa, const h8& xb, const f16v& prev, bool relu, const f16v& init) {
         f16v o = MFMA(wq[0], xa, init);
@@ -558,6 +561,7 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
       bq = acc_init(cf + CF_B_ES, h);
       const h8 A3a = GEO ? pack8_relu32(acc, 0) : pack8(acc, 0, true), A3b = GEO ? pack8_relu32(acc, 1) : pack8(acc, 1, true);
       acc = hidden(A3a, A3b, acc, true, bq);
+      P8MARK(10);
       P8ISA("geometry_hidden_layers_done");
 #pragma unroll
       for (int s = 0; s < 5; ++s) wq[s] = lds_frag(smem, KK_VD + s, lane);
@@ -593,6 +597,7 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
         const float dzl = cur.z - c_ml;
         c_M2 = seg_total<TWO>(seg_scan_add<TWO>(c_tl * dzl * dzl), lane);
       }
+      P8MARK(11);
       P8ISA("sigma_head_and_sigma_half_of_composite_done");
       const h8 Y4a = pack8(acc, 0, false), Y4b = pack8(acc, 1, false);
       acc = MFMA(wq[0], Y4a, bq);

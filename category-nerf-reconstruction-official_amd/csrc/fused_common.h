@@ -202,32 +202,48 @@ __device__ __forceinline__ h8 lds_frag(const unsigned char* lds_w, int kk, int l
 // Positional encoding of one sample in B-operand layout.  Bh: this lane-half's 11 direction rows
 // (row 10 of half 1 is zero).  ONES puts 1.0 into two empty half-0 slots (E1 slot 47, E2 slot 22): their
 // forward weights are zero, and in the backward's dW products they collect the bias gradients.
+// (the pieces of pe_slots, for callers that interleave the encoding with the matrix products fragment by fragment)
+// the direction products p_d = B_d . t of this lane half's 11 directions
+__device__ __forceinline__ void pe_dirs(const float (&Bh)[33], float t0, float t1, float t2, float (&pd)[11]) {
+#pragma unroll
+  for (int d = 0; d < 11; ++d) pd[d] = Bh[3 * d] * t0 + Bh[3 * d + 1] * t1 + Bh[3 * d + 2] * t2;
+}
+// E1 feature slots 8 s .. 8 s + 7 (s = 0..5): slot q < 44 = sin(pi 2^b p_d) with b = q / 11, d = q % 11 (hardware sine takes
+// revolutions: v_sin(2^(b-1) p)); 44..46 = t (lane half 0), 47 = the ones slot
+template <bool ONES>
+__device__ __forceinline__ void pe_e1_slots(const float (&pd)[11], float t0, float t1, float t2, int h, int s, float (&v)[8]) {
+  const float one = (ONES && h == 0) ? 1.0f : 0.0f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int q = 8 * s + j;
+    if (q < 44) v[j] = __builtin_amdgcn_sinf(pd[q % 11] * (0.5f * (float)(1 << (q / 11))));
+    else v[j] = q == 47 ? one : (h == 0 ? (q == 44 ? t0 : q == 45 ? t1 : t2) : 0.0f);
+  }
+}
+// the 24 E2 slots: bands 4 and 5 of the 11 directions, the ones slot (22), an empty one
+template <bool ONES>
+__device__ __forceinline__ void pe_e2_slots(const float (&pd)[11], int h, float (&v)[24]) {
+#pragma unroll
+  for (int j = 0; j < 22; ++j) v[j] = __builtin_amdgcn_sinf(pd[j % 11] * (0.5f * (float)(1 << (4 + j / 11))));
+  v[22] = (ONES && h == 0) ? 1.0f : 0.0f;
+  v[23] = 0.0f;
+}
 template <bool ONES, bool LO = false>
 __device__ __forceinline__ void pe_slots(const float (&Bh)[33], float t0, float t1, float t2, int h,
                                          h8 (&E1f)[6], h8 (&E2f)[3], h8* E1lo = nullptr) {
-  float v[72];
+  float pd[11];
+  pe_dirs(Bh, t0, t1, t2, pd);
 #pragma unroll
-  for (int d = 0; d < 11; ++d) {
-    const float p = Bh[3 * d] * t0 + Bh[3 * d + 1] * t1 + Bh[3 * d + 2] * t2;
-    // sin(pi 2^b p) = v_sin(2^(b-1) p)  (hardware sine takes revolutions)
-#pragma unroll
-    for (int b = 0; b < 6; ++b) {
-      const float arg = p * (0.5f * (float)(1 << b));
-      const int q = b < 4 ? 11 * b + d : 48 + 11 * (b - 4) + d;
-      v[q] = __builtin_amdgcn_sinf(arg);
-    }
+  for (int s = 0; s < 6; ++s) {
+    float v[8];
+    pe_e1_slots<ONES>(pd, t0, t1, t2, h, s, v);
+    E1f[s] = pack8f(v);
+    if constexpr (LO) E1lo[s] = pack8f_lo(v, E1f[s]);   // residual of the E1 features (the geometry branch's inputs)
   }
-  const float one = (ONES && h == 0) ? 1.0f : 0.0f;
-  v[44] = h == 0 ? t0 : 0.0f; v[45] = h == 0 ? t1 : 0.0f; v[46] = h == 0 ? t2 : 0.0f; v[47] = one;
-  v[70] = one; v[71] = 0.0f;
+  float v2[24];
+  pe_e2_slots<ONES>(pd, h, v2);
 #pragma unroll
-  for (int s = 0; s < 6; ++s) E1f[s] = pack8f(&v[8 * s]);
-  if constexpr (LO) {   // residual of the E1 features (the geometry branch's inputs): slots 44..47 (t, ones) included
-#pragma unroll
-    for (int s = 0; s < 6; ++s) E1lo[s] = pack8f_lo(&v[8 * s], E1f[s]);
-  }
-#pragma unroll
-  for (int s = 0; s < 3; ++s) E2f[s] = pack8f(&v[48 + 8 * s]);
+  for (int s = 0; s < 3; ++s) E2f[s] = pack8f(&v2[8 * s]);
 }
 
 }  // namespace fz

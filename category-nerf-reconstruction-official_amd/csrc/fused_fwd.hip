@@ -171,12 +171,12 @@ __device__ __forceinline__ f16v pe_products(const unsigned char* smem, const uns
 #pragma unroll
   for (int s = 0; s < 6; ++s) w[s] = lds_frag(smem, kk0 + s, lane);
 #pragma unroll
-  for (int s = 0; s < 6; ++s) acc = MFMA(w[s], E1f[s], acc);
-  if (SPLIT) {
-#pragma unroll
-    for (int s = 0; s < 6; ++s) acc = MFMA(w[s], E1l[s], acc);
-#pragma unroll
-    for (int s = 0; s < 6; ++s) acc = MFMA(lds_frag(smem_lo, kk0 + s, lane), E1f[s], acc);
+  for (int s = 0; s < 6; ++s) {   // (fragment by fragment, as the one-launch kernel pipelines them with the encoding)
+    acc = MFMA(w[s], E1f[s], acc);
+    if (SPLIT) {
+      acc = MFMA(w[s], E1l[s], acc);
+      acc = MFMA(lds_frag(smem_lo, kk0 + s, lane), E1f[s], acc);
+    }
   }
   return acc;
 }

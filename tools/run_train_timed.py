@@ -37,9 +37,12 @@ for w in range(8):
     print("wave", w, "chain" if w < 4 else "dW", "t0", st[0] - base, "total", st[2 * nb] - st[0], "work", sum(work), "wait", sum(wait))
     print("    work", work)
     print("    wait", wait)
-    mk = b[w * 64 + 44: w * 64 + 52]
+    mk = b[w * 64 + 44: w * 64 + 56]
     if w < 4 and one:
         x1 = st[4]      # after the exchange barrier (the iteration's second)
+        print("    forward (cycles, the stamps themselves wait for outstanding LDS reads): top barrier -> encoding in registers", mk[8] - st[2],
+              "| -> xyz + cat[e1] products issued", mk[9] - mk[8], "| -> four hidden layers", mk[10] - mk[9], "| -> sigma head + sigma scans", mk[11] - mk[10],
+              "| -> colour branch", mk[7] - mk[11])
         print("    marks: fwd end->exch barrier", st[3] - mk[7], "| exch->sums", mk[0] - x1, "| var", mk[1] - mk[0], "| loss scalars", mk[2] - mk[1],
               "| suffix carry", mk[3] - mk[2], "| scan+docc", mk[4] - mk[3], "| dsg..DWS", mk[5] - mk[4], "| R2 stage+mfma", mk[6] - mk[5])
     its = [v for v in b[w * 64 + 30: w * 64 + 42] if v]
