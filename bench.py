@@ -569,7 +569,9 @@ def main():
             tp = torch.tensor([n_pw], device=dev, dtype=torch.int64)
             torch.distributed.all_reduce(tp, op=torch.distributed.ReduceOp.MAX)
             n_pw = int(tp.item())
-        tr.run(n_pw)
+        for _ in range(n_pw // tr.unroll):     # one group at a time: 200 graph launches queued ahead of the GPU left the NEXT region's
+            tr.run(tr.unroll)                  # launch slow (67-77 us per step over the 20 steps behind them, measured)
+            torch.cuda.synchronize()
         pre_warm_steps = n_pw + tr.unroll
     tr.run(max(args.warmup, 4))
     dbg("warmup issued")

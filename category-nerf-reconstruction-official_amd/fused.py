@@ -463,8 +463,7 @@ class FusedCategoryTrainer:
             if self.cursor >= self.pool_rows - self.Rg:
                 self._reshuffle()
             left = -(-(self.pool_rows - self.Rg - self.cursor) // self.Rg)     # steps before the next reshuffle
-            # the largest group of the ladder U0, U0 / 2, .., 2 that fits what is left of the request and of the epoch: an epoch
-            # of 63 steps goes out as 16 + 16 + 16 + 8 + 4 + 2 + 1 = 7 launches, not 3 + 15 (each launch boundary idles the GPU ~8 us)
+            # the largest even group that fits what is left of the request and of the epoch (each launch boundary idles the GPU ~8 us)
             U = 0
             if multi_ok and self.steps_done >= 2:
                 for u in self._group_sizes(U0):
@@ -489,12 +488,11 @@ class FusedCategoryTrainer:
 
     @staticmethod
     def _group_sizes(U0):
-        """even group sizes of the multi-step graphs, largest first: U0, then halves rounded down to even, down to 2"""
-        out, u = [], int(U0)
-        while u >= 2:
-            out.append(u)
-            u = (u // 2) // 2 * 2 if u > 2 else 0
-        return out
+        """group sizes of the multi-step graphs, largest first: EVERY even size U0, U0 - 2, .., 2.  (A halving ladder -- U0,
+        U0 / 2, .. -- sent the 7 steps in front of an epoch end and the 13 behind it out as 4 + 2 + 1 and 10 + 2 + 1: six graph
+        launches and the reshuffle's three kernels in a row, ~400 us of host work against ~400 us of GPU work queued: a 20-step
+        region with an epoch end inside ran 82 us per step.  With every even size it is 6 + 1 and 12 + 1.)"""
+        return list(range(int(U0) // 2 * 2, 1, -2))
 
     def _capture_multi(self, par, U):
         """Record (not run) U steps starting at state parity ``par`` as one graph."""
