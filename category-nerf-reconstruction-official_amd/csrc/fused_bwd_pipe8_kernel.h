@@ -792,14 +792,20 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
       stage_hs(Dimg0, D0, D1, col, h);
       stage_hs(Ximg0, A5a, A5b, col, h);
       P8SYNC();                   // A(T1)
+      // (the extra fragments of a step -- d e2 here, d e1 in steps CAT and S1 -- are requested at the TOP of the step, under the
+      //  packing of dPre: read in front of their products, each product waited out part of an LDS round trip)
+      h8 wE[6];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) wE[k] = lds_frag(bwf, KT_VD_E + k, lane);
+      __builtin_amdgcn_sched_barrier(0);
       D0 = pack8_and(acc, 0, Mn0); D1 = pack8_and(acc, 1, Mn1);
       acc = MFMA(Wn0, D0, zero16());
       acc = MFMA(Wn1, D1, acc);  // d y4 from the colour branch
       f16v de2[3];  // d e2 (two 16-slot blocks)
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
-        de2[b] = MFMA(lds_frag(bwf, KT_VD_E + 2 * b + 0, lane), D0, zero16());
-        de2[b] = MFMA(lds_frag(bwf, KT_VD_E + 2 * b + 1, lane), D1, de2[b]);
+        de2[b] = MFMA(wE[2 * b + 0], D0, zero16());
+        de2[b] = MFMA(wE[2 * b + 1], D1, de2[b]);
       }
       Wn0 = lds_frag(bwf, KT_ES + 0, lane); Wn1 = lds_frag(bwf, KT_ES + 1, lane);
       // ---- step VD : inputs [y4 | e2]
@@ -852,6 +858,9 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
       stage_hs(Dimg0, D0, D1, col, h);
       stage_hs(Ximg0, A1a, A1b, col, h);
       P8SYNC();                   // A(CAT)
+#pragma unroll
+      for (int k = 0; k < 6; ++k) wE[k] = lds_frag(bwf, KT_CAT_E + k, lane);
+      __builtin_amdgcn_sched_barrier(0);
       D0 = pack8_and(acc, 0, Mn0); D1 = pack8_and(acc, 1, Mn1);
       Mn0 = relu_mask(A0a); Mn1 = relu_mask(A0b);
       acc = MFMA(Wn0, D0, zero16());
@@ -859,18 +868,21 @@ __global__ __launch_bounds__((NCH + NDW) * 64, 1) void field_bwd_pipe8_kernel(
       f16v de[3];
 #pragma unroll
       for (int b = 0; b < 3; ++b) {
-        de[b] = MFMA(lds_frag(bwf, KT_CAT_E + 2 * b + 0, lane), Dc0, zero16());
-        de[b] = MFMA(lds_frag(bwf, KT_CAT_E + 2 * b + 1, lane), Dc1, de[b]);
+        de[b] = MFMA(wE[2 * b + 0], Dc0, zero16());
+        de[b] = MFMA(wE[2 * b + 1], Dc1, de[b]);
       }
       // ---- step S1 : input a0
       stage_hs(Dimg1, D0, D1, col, h);
       stage_hs(Ximg1, A0a, A0b, col, h);
       P8SYNC();                   // A(S1)
+#pragma unroll
+      for (int k = 0; k < 6; ++k) wE[k] = lds_frag(bwf, KT_XYZ_E + k, lane);
+      __builtin_amdgcn_sched_barrier(0);
       D0 = pack8_and(acc, 0, Mn0); D1 = pack8_and(acc, 1, Mn1);
 #pragma unroll
       for (int b = 0; b < 3; ++b) {
-        de[b] = MFMA(lds_frag(bwf, KT_XYZ_E + 2 * b + 0, lane), D0, de[b]);
-        de[b] = MFMA(lds_frag(bwf, KT_XYZ_E + 2 * b + 1, lane), D1, de[b]);
+        de[b] = MFMA(wE[2 * b + 0], D0, de[b]);
+        de[b] = MFMA(wE[2 * b + 1], D1, de[b]);
       }
       // ---- step XYZ : input e1 (its image)
       stage_hs(Dimg0, D0, D1, col, h);
