@@ -56,14 +56,35 @@ static_assert(OFF_R2_B + 3 == TRUNK, "trunk layout");
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 // wave64 sum via DPP-friendly shuffles
+// The value of lane ^ j (j a constant after unrolling; lane = the lane's index in its wave).  Distances inside a row of 16 lanes
+// are DPP moves on the vector unit -- quad permutes for 1 and 2, a row rotate for 8, a left and a right row shift and a select
+// for 4 --; only 16 and 32 go through ds_bpermute (the LDS crossbar, ~100 cycles of latency each).
+__device__ __forceinline__ float xor_lane(float v, int j, int lane) {
+  const int x = __builtin_bit_cast(int, v);
+  switch (j) {
+    case 1: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+    case 2: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+    case 4: {
+      const int up = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xf, 0xf, false);   // row_shl:4: lane i <- i + 4
+      const int dn = __builtin_amdgcn_update_dpp(x, x, 0x114, 0xf, 0xf, false);   // row_shr:4: lane i <- i - 4
+      return __builtin_bit_cast(float, (lane & 4) ? dn : up);
+    }
+    case 8: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(x, x, 0x128, 0xf, 0xf, false));   // row_ror:8
+    default: return __shfl_xor(v, j, 64);
+  }
+}
+// butterfly reductions over the wave, every lane gets the result; the same order of operations as a __shfl_xor butterfly
+// (32, 16, .., 1: bit-identical sums), four of the six steps without the LDS crossbar
 __device__ __forceinline__ float wave_sum(float v) {
+  const int lane = (int)(threadIdx.x & 63);
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  for (int o = 32; o > 0; o >>= 1) v += xor_lane(v, o, lane);
   return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
+  const int lane = (int)(threadIdx.x & 63);
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, xor_lane(v, o, lane));
   return v;
 }
 }  // namespace cnr

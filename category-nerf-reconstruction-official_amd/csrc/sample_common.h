@@ -47,31 +47,15 @@ __device__ __forceinline__ float linspace01(int i, int n) {
   return (i < steps / 2) ? step * (float)i : 1.0f - step * (float)(steps - i - 1);
 }
 
-// The value of lane ^ j (j a constant after unrolling).  Distances inside a row of 16 lanes are DPP moves on the vector unit --
-// quad permutes for 1 and 2, a row rotate for 8, a left and a right row shift and a select for 4 -- ; only 16 and 32 go through
-// ds_bpermute (the LDS crossbar, ~100 cycles of latency each: the network below was 54 of them per ray, ~3 k cycles of the one
-// wave that samples the ray, on the step's first launch's longest job).
-__device__ __forceinline__ float xor_lane(float v, int j, int lane) {
-  const int x = __builtin_bit_cast(int, v);
-  switch (j) {
-    case 1: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
-    case 2: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
-    case 4: {
-      const int up = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xf, 0xf, false);   // row_shl:4: lane i <- i + 4
-      const int dn = __builtin_amdgcn_update_dpp(x, x, 0x114, 0xf, 0xf, false);   // row_shr:4: lane i <- i - 4
-      return __builtin_bit_cast(float, (lane & 4) ? dn : up);
-    }
-    case 8: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(x, x, 0x128, 0xf, 0xf, false));   // row_ror:8
-    default: return __shfl_xor(v, j, 64);
-  }
-}
+// (cnr::xor_lane, cnr_common.h: lane ^ j on DPP moves for j = 1, 2, 4, 8, ds_bpermute for 16 and 32 -- the network below was 54
+//  ds_bpermute per ray, ~3 k cycles of the one wave that samples the ray, on the step's first launch's longest job)
 // compare-exchange network over the wave's 64 lanes (one element per lane), ascending
 __device__ __forceinline__ void bitonic64(float& v, int lane) {
 #pragma unroll
   for (int k = 2; k <= 64; k <<= 1) {
 #pragma unroll
     for (int j = k >> 1; j > 0; j >>= 1) {
-      const float p = xor_lane(v, j, lane);
+      const float p = cnr::xor_lane(v, j, lane);
       const bool upper = (lane & j) != 0, asc = (lane & k) == 0;
       v = (upper == asc) ? fmaxf(v, p) : fminf(v, p);
     }
@@ -88,8 +72,8 @@ __device__ __forceinline__ void bitonic128(float& v0, float& v1, int lane) {
         const float lo = fminf(v0, v1), hi = fmaxf(v0, v1);
         v0 = lo; v1 = hi;
       } else {
-        const float p0 = xor_lane(v0, j, lane);
-        const float p1 = xor_lane(v1, j, lane);
+        const float p0 = cnr::xor_lane(v0, j, lane);
+        const float p1 = cnr::xor_lane(v1, j, lane);
         const bool upper = (lane & j) != 0;
         const bool asc0 = ((lane) & k) == 0;          // element index lane
         const bool asc1 = ((lane + 64) & k) == 0;     // element index lane + 64
