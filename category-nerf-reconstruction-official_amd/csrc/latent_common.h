@@ -66,9 +66,9 @@ __device__ __forceinline__ void latent_fwd_block(const float* __restrict__ th, c
     float br = 0.0f;
 #pragma unroll
     for (int q = 0; q < 4; ++q) br = fmaf(tw[q], zs[p * 4 + q], br);
-    br += __shfl_xor(br, 1, 64);
-    br += __shfl_xor(br, 2, 64);
-    br += __shfl_xor(br, 4, 64);
+    br += xor_lane(br, 1, lane);
+    br += xor_lane(br, 2, lane);
+    br += xor_lane(br, 4, lane);
     if (p == 0) {
       const int64_t row = (int64_t)c * lay.n_obj + obj;
       zl[(row * 4 + k) * 32 + o] = zs[o];
