@@ -33,8 +33,12 @@ def host_wait_spin():
     1204.6 -> 1181.3 us); the GPU work is the same."""
     import ctypes
     try:
-        return ctypes.CDLL("libamdhip64.so").hipSetDeviceFlags(1) == 0
-    except OSError:
+        # the copy torch has mapped, by its path: a bare soname could load a second runtime from the system directories
+        paths = {line.split()[-1] for line in open("/proc/self/maps") if "libamdhip64" in line}
+        if len(paths) != 1:
+            return False
+        return ctypes.CDLL(paths.pop()).hipSetDeviceFlags(1) == 0
+    except (OSError, AttributeError):
         return False
 
 FLOP_PER_SAMPLE_STEP = 82140          # SURVEY.md section 8(d): 3 x 13 648 MAC + 2 x 63 MAC, 2 FLOP/MAC
