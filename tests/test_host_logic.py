@@ -146,3 +146,14 @@ def test_camera_rays_dirs_match_the_reference_fixture(cnr):
         W, H, fx, fy, cx, cy = z["cam%d" % i]
         info = cnr.scene_cateogries.cameraInfo(SimpleNamespace(W=int(W), H=int(H), fx=fx, fy=fy, cx=cx, cy=cy))
         assert np.array_equal(info.rays_dir_cache.numpy(), z["dirs%d" % i])
+
+
+def test_multi_step_graph_sizes_cover_every_even_length(cnr):
+    """run() sends the largest captured group that fits the request and what is left of the epoch; with every even size there an
+    epoch end inside a run costs two extra launches (n - 1 steps as one graph + one step), not a halving ladder of them."""
+    gs = cnr.fused.FusedCategoryTrainer._group_sizes
+    assert gs(20) == list(range(20, 1, -2))
+    assert gs(5) == [4, 2] and gs(2) == [2] and gs(1) == []
+    for left in range(2, 33):                      # what goes out in front of an epoch end `left` steps away
+        first = next(u for u in gs(32) if u <= left)
+        assert left - first in (0, 1)
